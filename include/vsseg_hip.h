@@ -1,0 +1,164 @@
+/* vsseg_hip.h — C ABI of libvsseg_hip.so: the MI355X (gfx950) hot path of the VS_Seg 2.5D attention U-Net.
+ *
+ * The reference (KCL-BMEIS/VS_Seg) has no FFI of its own: its seam is the Python object protocol between
+ * `VSparams` and the model/loss objects.  This library sits *behind* that protocol; every entry
+ * point below replaces the torch/ATen/cuDNN work the reference dispatches from the cited lines.  Plain pointers and
+ * sizes only, no torch types; the caller owns every buffer; all calls are asynchronous on `stream` (a hipStream_t)
+ * and return 0 or a negative VSSEG_E* code (text via vsseg_last_error()).
+ *
+ * Data layout: activations are channels-last [N][X][Y][Z][C] ("NDHWC", identical to torch.channels_last_3d strides
+ * of a [N,C,X,Y,Z] tensor) described by vsseg_tensor; `pitch` lets a tensor be a channel slice of a wider buffer so
+ * that the skip-connection concat (MONAI SkipConnection, ref:params/networks/nets/unet2d5_spvPA.py:89) is never
+ * materialised by a copy.
+ */
+#ifndef VSSEG_HIP_H
+#define VSSEG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSSEG_F32 0
+#define VSSEG_BF16 1
+
+#define VSSEG_OK 0
+#define VSSEG_EINVAL (-1)
+#define VSSEG_ELAUNCH (-2)
+
+#define VSSEG_ACT_NONE 0
+#define VSSEG_ACT_PRELU 1
+#define VSSEG_ACT_RELU 2
+#define VSSEG_ACT_SIGMOID 3
+
+#define VSSEG_RES_NONE 0
+#define VSSEG_RES_ADD 1      /* out = f(acc) + res                      (ResidualUnit add, ref:.../convolutions.py:252-255) */
+#define VSSEG_RES_RELUMASK 2 /* out = acc * (res > 0)                   (backward of the attention ReLU)                   */
+
+#define VSSEG_MAX_TAPS 27
+#define VSSEG_STAT_SHARDS 256
+
+typedef struct {
+  void* ptr;     /* first element of the view (channel offset already applied) */
+  int32_t dtype; /* VSSEG_F32 | VSSEG_BF16 */
+  int32_t c;     /* channels in the view */
+  int32_t pitch; /* elements between consecutive voxels (>= c) */
+  int32_t n, x, y, z;
+} vsseg_tensor;
+
+/* One implicit-GEMM launch over an output lattice q in [0,q): out[q*os+oo][n] = epi( sum_t sum_c in[q*is+off_t][c] * W[t][c][n] ).
+ * Covers Conv3d forward, every parity class of ConvTranspose3d forward, and both data-gradients
+ * (ref:params/networks/blocks/convolutions.py:114-146 and their autograd at ref:params/VSparams.py:461). */
+typedef struct {
+  vsseg_tensor in, out;
+  int32_t q[3];            /* lattice extent */
+  int32_t is[3], os[3], oo[3];
+  int32_t ntaps;
+  int32_t tap_off[VSSEG_MAX_TAPS][3]; /* input offset of each tap relative to q*is */
+  int32_t tile[3];         /* output-lattice tile per workgroup; product must be 64*mtw */
+  int32_t mtw;             /* 16-voxel M-tiles per wave: 1, 2 or 4 */
+  int32_t nt;              /* 16-channel output tiles per workgroup (1..6) */
+  int32_t nsplit;          /* output-channel splits (grid.y); packed weights hold nsplit*nt tiles */
+  int32_t ck;              /* input channels staged per chunk (multiple of 8, divides padded Cin) */
+  int32_t nchunks;
+  int32_t ksteps;          /* K-steps (4 groups of 8 channels) per chunk */
+  const void* wpack;       /* [nsplit][nchunks][ksteps][nt][64 lanes][8] in the compute dtype (== in.dtype) */
+  /* epilogue: v = acc + bias; stats(v); v = v*scale+shift; v = act(v); residual; accumulate; store */
+  const float* bias;       /* [cout] or NULL */
+  const float* scale;      /* [cout] or NULL (eval-mode BatchNorm folded) */
+  const float* shift;
+  const float* alpha;      /* device pointer to the PReLU slope (1 element) */
+  int32_t act;
+  int32_t res_mode;
+  vsseg_tensor res;
+  int32_t accumulate;      /* out += value (gradient accumulation at fan-out points) */
+  double* stats;           /* [VSSEG_STAT_SHARDS][2][cout_padded] sum / sum-of-squares of v, or NULL */
+  int32_t stats_stride;    /* cout_padded */
+} vsseg_igemm_desc;
+
+/* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
+ * Conv3d: P = dY, H = X.  ConvTranspose3d: P = X, H = dY. */
+typedef struct {
+  vsseg_tensor p, h;
+  int32_t q[3];            /* lattice = spatial extent of P */
+  int32_t hs[3];
+  int32_t ntaps;
+  int32_t tap_off[VSSEG_MAX_TAPS][3];
+  int32_t tap_widx[VSSEG_MAX_TAPS]; /* flat index of the tap inside the weight's kernel dims */
+  int32_t tile[3];         /* product must be a multiple of 32 */
+  int32_t ntp;             /* 16-channel tiles of P */
+  float* dw;               /* destination weight-gradient tensor (pre-zeroed or holding earlier contributions) */
+  int64_t stride_p, stride_h, stride_tap; /* element strides of dw along cP, cH, tap */
+  int32_t cp_valid, ch_valid;
+  int32_t persistent_blocks;
+} vsseg_wgrad_desc;
+
+const char* vsseg_last_error(void);
+int vsseg_version(void);
+
+int vsseg_igemm(const vsseg_igemm_desc* d, void* stream);
+int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d);
+int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream);
+
+/* dst[i] = map[i] >= 0 ? cast(src[map[i]]) : 0 — (re)packs the fp32 master weights into MFMA fragment order. */
+int vsseg_gather_cast(const float* src, const int32_t* map, void* dst, int64_t n, int32_t dst_dtype, void* stream);
+
+/* dst[n][x][y][z][0..cpad) <- src window (crop + zero-pad outside + zero-extend channels + cast). src is [N][SX][SY][SZ] f32, 1 channel.
+ * Used for the network input (ref:params/VSparams.py:456) and for sliding-window crops (MONAI sliding_window_inference step 6). */
+int vsseg_stage_input(const float* src, int32_t n, const int32_t sdims[3], const int32_t origin[3], vsseg_tensor dst, void* stream);
+
+/* BatchNorm statistics: reduce shards -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale; running-stat update
+ * (torch BatchNorm3d training semantics, momentum 0.1, unbiased running var; ref:.../convolutions.py:152). */
+int vsseg_bn_finalize(const double* stats, int32_t stride, int32_t c, double count, const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* eval mode: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale for every BN layer at once (flat param addressing). */
+int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int32_t c, void* stream);
+
+/* out = PReLU(dropout(y*scale+shift)) [+ res]   (ref:.../convolutions.py:148-156; residual add :252-255).
+ * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables. */
+int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
+                     vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
+/* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, alpha_acc[shard] += dA*d(d<0). */
+int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            const float* alpha, float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream);
+/* finalize: dgamma, dbeta, dalpha (+= into flat grads) and the two per-channel means used by pass 2 */
+int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
+                              float* mean_dz, float* mean_dzx, void* stream);
+/* pass 2: dy = gamma*invstd*(dz - mean_dz - xhat*mean_dzx) */
+int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream);
+/* debug/parity: write the keep-mask (0/1 as f32, [voxel][c]) the forward used */
+int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint64_t seed, uint32_t salt, void* stream);
+
+/* AttentionBlock2: out = x * (1 + att)   (ref:params/networks/blocks/attentionblock.py:43-47); att is f32 [voxel]. */
+int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream);
+/* dx (+)= dout*(1+att);  dpre[voxel][0] = (sum_c dout*x + datt_ext) * att*(1-att)  (sigmoid backward), channels 1..7 zero. */
+int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, void* stream);
+
+/* generic helpers */
+int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);
+int vsseg_add_inplace(vsseg_tensor dst, vsseg_tensor src, void* stream); /* dst += src */
+int vsseg_copy_cast(vsseg_tensor src, vsseg_tensor dst, void* stream);
+
+/* Dice_spvPA (ref:params/losses/dice_spvPA.py:238-297).  sums layout: see loss.hip. */
+int vsseg_maxpool_label(const float* src, int32_t n, const int32_t sdims[3], const int32_t ratio[3], float* dst, void* stream);
+int vsseg_dice_pred_sums(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, double* sums /* [n][2][3] */, void* stream);
+int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t nvox, double* sums /* [n][3] */, void* stream);
+int vsseg_dice_finalize(const double* pred_sums, const double* att_sums, int32_t n, int32_t nlevels, float* loss, float* coef /* [n][2][2] + [levels][n][2] */, void* stream);
+int vsseg_dice_pred_bwd(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, float* dlogits, void* stream);
+int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, const float* coef, float inv_levels, const float* gscale, float* datt, void* stream);
+
+/* torch.optim.Adam(lr, weight_decay) over the flat parameter buffer (ref:params/VSparams.py:388-391,462). */
+int vsseg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2, float gscale, void* stream);
+
+/* Sliding-window blend (MONAI sliding_window_inference steps 6-7; call site ref:params/VSparams.py:568-574). */
+int vsseg_swi_accumulate(const float* seg /* [rx][ry][rz][c] */, const float* imap /* [rx][ry][rz] */, const int32_t roi[3], const int32_t start[3], int32_t c,
+                         float* out /* [PX][PY][PZ][c] */, float* cnt /* [PX][PY][PZ] */, const int32_t pdims[3], void* stream);
+int vsseg_swi_finalize(const float* out, const float* cnt, const int32_t pdims[3], const int32_t pad_before[3], const int32_t dims[3], int32_t c, float* dst /* [X][Y][Z][c] */, void* stream);
+/* hard Dice of argmax vs label (ref:params/VSparams.py:393-408): counts[0]=|P∩G|, [1]=|P|, [2]=|G| */
+int vsseg_hard_dice_counts(const float* logits, int32_t pitch, const float* label, int64_t nvox, double* counts, void* stream);
+int vsseg_argmax2(const float* logits, int32_t pitch, int64_t nvox, uint8_t* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

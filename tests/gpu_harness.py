@@ -1,0 +1,97 @@
+"""Helpers for the -m gpu parity tests: drive single kernels through the C ABI (ctypes) on torch-allocated device memory."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from vs_seg_amd import _lib as L
+from vs_seg_amd import planner as P
+
+DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tdesc(t: torch.Tensor, c=None, c0=0) -> L.Tensor:
+    """t is channels-last [N,X,Y,Z,C]."""
+    n, x, y, z, pitch = t.shape
+    return L.Tensor(t.data_ptr() + c0 * t.element_size(), L.F32 if t.dtype == torch.float32 else L.BF16, c or (pitch - c0), pitch, n, x, y, z)
+
+
+def to_cl(x: torch.Tensor, dtype, cpad=None) -> torch.Tensor:
+    """NCDHW fp32/64 cpu -> channels-last device tensor of dtype, channels zero-padded to cpad."""
+    v = x.detach().permute(0, 2, 3, 4, 1).to(torch.float32)
+    if cpad and cpad > v.shape[-1]:
+        v = torch.cat([v, torch.zeros(*v.shape[:-1], cpad - v.shape[-1])], -1)
+    return v.contiguous().to("cuda").to(dtype)
+
+
+def from_cl(t: torch.Tensor, c=None) -> torch.Tensor:
+    v = t.detach().to(torch.float32).cpu()
+    if c:
+        v = v[..., :c]
+    return v.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def pack(plan: P.IgemmPlan, w: torch.Tensor, dtype) -> torch.Tensor:
+    lib = L.lib()
+    wf = w.detach().to(torch.float32).reshape(-1).contiguous().cuda()
+    m = torch.from_numpy(plan.pack_map).cuda()
+    out = torch.zeros(m.numel(), dtype=dtype, device="cuda")
+    L.check(lib.vsseg_gather_cast(wf.data_ptr(), m.data_ptr(), out.data_ptr(), m.numel(), L.F32 if dtype == torch.float32 else L.BF16, stream()), "gather_cast")
+    return out
+
+
+def igemm_desc(plan: P.IgemmPlan, wpack: torch.Tensor, inp: L.Tensor, out: L.Tensor, **kw) -> L.IgemmDesc:
+    d = L.IgemmDesc()
+    d.inp, d.out = inp, out
+    d.q, d.is_, d.os, d.oo = L.i3(plan.q), L.i3(plan.cls.is_), L.i3(plan.cls.os), L.i3(plan.cls.oo)
+    d.ntaps = plan.ntaps
+    for t, (off, _) in enumerate(plan.cls.taps):
+        d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
+    d.tile = L.i3(plan.tile)
+    d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps = plan.mtw, plan.nt, plan.nsplit, plan.ck, plan.nchunks, plan.ksteps
+    d.wpack = wpack.data_ptr()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+def run_lattice_op(kind, w, x_cl: torch.Tensor, out_cl: torch.Tensor, stride, **epi):
+    """Run every lattice class of a conv-like op; x_cl/out_cl are channels-last device tensors."""
+    lib = L.lib()
+    kernel = tuple(w.shape[2:])
+    es = x_cl.element_size()
+    odims = tuple(out_cl.shape[1:4])
+    keep = []
+    for cls in P.lattice_classes(kind, kernel, stride):
+        q = odims if kind in ("conv_fwd", "convT_dgrad") else tuple((o + s - 1) // s for o, s in zip(odims, stride))
+        plan = P.plan_igemm(kind, tuple(w.shape), cls, q, es, kc_pad=x_cl.shape[-1], **({"lds_budget": epi.pop("lds_budget")} if "lds_budget" in epi else {}))
+        wp = pack(plan, w, x_cl.dtype)
+        d = igemm_desc(plan, wp, tdesc(x_cl), tdesc(out_cl), **epi)
+        keep.append((wp, d))
+        L.check(lib.vsseg_igemm(C.byref(d), stream()), "igemm")
+    torch.cuda.synchronize()
+    return keep
+
+
+def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid):
+    lib = L.lib()
+    es = p_cl.element_size()
+    wp = P.plan_wgrad(transposed, wshape, kernel, stride, tuple(p_cl.shape[1:4]), es)
+    dw = torch.zeros(int(np.prod(wshape)), dtype=torch.float32, device="cuda")
+    d = L.WgradDesc()
+    d.p, d.h, d.cp_valid, d.ch_valid = tdesc(p_cl), tdesc(h_cl), cp_valid, ch_valid
+    d.q, d.hs, d.ntaps = L.i3(wp.q), L.i3(wp.hs), len(wp.taps)
+    for t, (off, widx) in enumerate(wp.taps):
+        d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
+        d.tap_widx[t] = widx
+    d.tile, d.ntp = L.i3(wp.tile), wp.ntp
+    d.dw = dw.data_ptr()
+    d.stride_p, d.stride_h, d.stride_tap = wp.stride_p, wp.stride_h, wp.stride_tap
+    d.persistent_blocks = wp.blocks
+    L.check(lib.vsseg_wgrad(C.byref(d), stream()), "wgrad")
+    torch.cuda.synchronize()
+    return dw.cpu().reshape(wshape)

@@ -1,0 +1,291 @@
+"""-m gpu: per-kernel parity of the HIP path (through the C ABI) against the CPU oracle / torch fp32-fp64 definitions.
+
+Tolerances: fp32 path = exact-fp32 MFMA, differences are summation-order only (<= 1e-4 relative to the output scale,
+well inside the 1e-3 bar of BASELINE.json's north_star).  bf16 path = bf16 operands, fp32 accumulate: inputs are
+pre-rounded to bf16 on both sides so the only difference left is the output rounding (2^-8 relative).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vsseg_oracle as O  # noqa: E402
+from tests import gpu_harness as H  # noqa: E402
+from tests.helpers import load, synth_input, synth_label  # noqa: E402
+from vs_seg_amd import _lib as L  # noqa: E402
+from vs_seg_amd import planner as P  # noqa: E402
+
+CONVS = [
+    # kernel, stride, cin, cout, dims
+    ((3, 3, 1), (1, 1, 1), 16, 16, (16, 16, 8)),
+    ((3, 3, 3), (1, 1, 1), 32, 48, (8, 8, 8)),
+    ((1, 1, 1), (1, 1, 1), 32, 16, (8, 8, 8)),
+    ((3, 3, 1), (2, 2, 1), 16, 16, (16, 16, 4)),
+    ((3, 3, 3), (2, 2, 2), 48, 48, (8, 8, 8)),
+    ((3, 3, 3), (1, 1, 1), 40, 1, (4, 4, 8)),
+    ((3, 3, 1), (1, 1, 1), 32, 2, (8, 8, 4)),
+    ((3, 3, 3), (1, 1, 1), 160, 80, (6, 2, 8)),
+    ((3, 3, 3), (1, 1, 1), 96, 96, (3, 1, 4)),  # bottleneck-sized, ragged tiles
+]
+
+
+def _round(x, dt):
+    return x.to(H.DT[dt]).to(torch.float32) if dt == "bf16" else x
+
+
+def _tol(dt, ref):
+    scale = float(ref.abs().max()) + 1e-12
+    return (2e-5 if dt == "fp32" else 1.2e-2) * scale
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,s,cin,cout,dims", CONVS)
+def test_conv_forward_and_dgrad(k, s, cin, cout, dims, dt):
+    torch.manual_seed(1)
+    pad = P.same_pad(k)
+    x = _round(torch.randn(2, cin, *dims), dt).requires_grad_(True)
+    w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k)) ** 0.5, dt)
+    b = torch.randn(cout)
+    y = F.conv3d(x.double(), w.double(), b.double(), stride=s, padding=pad)
+    out = torch.zeros(2, *y.shape[2:], cout, dtype=H.DT[dt], device="cuda")
+    bias = b.cuda()
+    H.run_lattice_op("conv_fwd", w, H.to_cl(x, H.DT[dt], P.round_up(cin, 8)), out, s, bias=bias.data_ptr())
+    np.testing.assert_allclose(H.from_cl(out).numpy(), y.detach().float().numpy(), atol=_tol(dt, y))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    dx = torch.zeros(2, *dims, cin, dtype=H.DT[dt], device="cuda")
+    H.run_lattice_op("conv_dgrad", w, H.to_cl(gy, H.DT[dt], P.round_up(cout, 8)), dx, s)
+    np.testing.assert_allclose(H.from_cl(dx).numpy(), x.grad.float().numpy(), atol=_tol(dt, x.grad))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,s,cin,cout,dims", [((3, 3, 1), (2, 2, 1), 32, 16, (8, 8, 4)), ((3, 3, 3), (2, 2, 2), 96, 80, (3, 1, 4)), ((3, 3, 3), (2, 2, 2), 48, 32, (6, 4, 4))])
+def test_conv_transpose_forward_and_dgrad(k, s, cin, cout, dims, dt):
+    torch.manual_seed(2)
+    pad = P.same_pad(k)
+    opad = tuple(ss + 2 * p - (kk - 1) - 1 for ss, p, kk in zip(s, pad, k))
+    x = _round(torch.randn(2, cin, *dims), dt).requires_grad_(True)
+    w = _round(torch.randn(cin, cout, *k) / (cin * np.prod(k) / 4) ** 0.5, dt)
+    y = F.conv_transpose3d(x.double(), w.double(), stride=s, padding=pad, output_padding=opad)
+    out = torch.zeros(2, *y.shape[2:], cout, dtype=H.DT[dt], device="cuda")
+    H.run_lattice_op("convT_fwd", w, H.to_cl(x, H.DT[dt]), out, s)
+    np.testing.assert_allclose(H.from_cl(out).numpy(), y.detach().float().numpy(), atol=_tol(dt, y))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    dx = torch.zeros(2, *dims, cin, dtype=H.DT[dt], device="cuda")
+    H.run_lattice_op("convT_dgrad", w, H.to_cl(gy, H.DT[dt]), dx, s)
+    np.testing.assert_allclose(H.from_cl(dx).numpy(), x.grad.float().numpy(), atol=_tol(dt, x.grad))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_igemm_epilogue_and_channel_chunks(dt):
+    """bias + folded BN + PReLU + residual add + statistics; a tight LDS budget forces several channel chunks."""
+    torch.manual_seed(3)
+    k, s, cin, cout, dims = (3, 3, 3), (1, 1, 1), 64, 32, (8, 8, 8)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * 27) ** 0.5, dt)
+    b, sc, sh, al = torch.randn(cout), torch.rand(cout) + 0.5, torch.randn(cout), torch.tensor([0.2])
+    r = _round(torch.randn(2, cout, *dims), dt)
+    pre = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    y = F.prelu(pre * sc.view(1, -1, 1, 1, 1).double() + sh.view(1, -1, 1, 1, 1).double(), al.double()) + r.double()
+    out = torch.zeros(2, *dims, cout, dtype=H.DT[dt], device="cuda")
+    dev = [t.cuda() for t in (b, sc, sh, al)]
+    stats = torch.zeros(L.STAT_SHARDS * 2 * 32, dtype=torch.float64, device="cuda")
+    rcl = H.to_cl(r, H.DT[dt])
+    H.run_lattice_op("conv_fwd", w, H.to_cl(x, H.DT[dt]), out, s, bias=dev[0].data_ptr(), scale=dev[1].data_ptr(), shift=dev[2].data_ptr(), alpha=dev[3].data_ptr(), act=L.ACT_PRELU,
+                     res_mode=L.RES_ADD, res=H.tdesc(rcl), stats=stats.data_ptr(), stats_stride=32, lds_budget=24 * 1024)
+    np.testing.assert_allclose(H.from_cl(out).numpy(), y.float().numpy(), atol=_tol(dt, y))
+    st = stats.cpu().view(L.STAT_SHARDS, 2, 32).sum(0)
+    np.testing.assert_allclose(st[0].numpy(), pre.sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(st[1].numpy(), (pre * pre).sum((0, 2, 3, 4)).numpy(), rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,s,cin,cout,dims,tr", [((3, 3, 1), (1, 1, 1), 16, 16, (16, 16, 8), False), ((3, 3, 3), (1, 1, 1), 96, 48, (8, 8, 8), False), ((1, 1, 1), (1, 1, 1), 32, 16, (8, 8, 8), False),
+                                                    ((3, 3, 3), (2, 2, 2), 48, 48, (8, 8, 8), False), ((3, 3, 1), (2, 2, 1), 16, 16, (16, 8, 4), False), ((3, 3, 3), (1, 1, 1), 40, 1, (4, 4, 8), False),
+                                                    ((3, 3, 1), (1, 1, 1), 1, 16, (16, 16, 4), False), ((3, 3, 3), (2, 2, 2), 96, 80, (3, 1, 4), True), ((3, 3, 1), (2, 2, 1), 32, 16, (8, 8, 4), True)])
+def test_wgrad(k, s, cin, cout, dims, tr, dt):
+    torch.manual_seed(4)
+    pad = P.same_pad(k)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    if tr:
+        w = torch.randn(cin, cout, *k, dtype=torch.float64, requires_grad=True)
+        opad = tuple(ss + 2 * p - (kk - 1) - 1 for ss, p, kk in zip(s, pad, k))
+        y = F.conv_transpose3d(x.double(), w, stride=s, padding=pad, output_padding=opad)
+    else:
+        w = torch.randn(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(x.double(), w, stride=s, padding=pad)
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    xcl, gcl = H.to_cl(x, H.DT[dt], P.round_up(cin, 8)), H.to_cl(gy, H.DT[dt], P.round_up(cout, 8))
+    if tr:
+        dw = H.run_wgrad(True, tuple(w.shape), k, s, xcl, gcl, cin, cout)
+    else:
+        dw = H.run_wgrad(False, tuple(w.shape), k, s, gcl, xcl, cout, cin)
+    ref = w.grad.float()
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=(5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_bn_dropout_prelu_forward_backward(dt, p_drop):
+    """Training-mode BN -> Dropout -> PReLU (+residual): statistics, running stats, forward and all gradients vs the oracle
+    fed with the HIP path's own keep-mask (torch's dropout stream cannot be reproduced)."""
+    lib = L.lib()
+    torch.manual_seed(5)
+    c, dims, n = 48, (8, 8, 4), 2
+    y = _round(torch.randn(n, c, *dims) * 1.5 + 0.3, dt)
+    r = _round(torch.randn(n, c, *dims), dt)
+    gout = _round(torch.randn(n, c, *dims), dt)
+    sd = {"b.conv.weight": torch.zeros(c, c, 1, 1, 1), "b.conv.bias": torch.zeros(c), "b.norm.weight": torch.rand(c) + 0.5, "b.norm.bias": torch.randn(c) * 0.1,
+          "b.norm.running_mean": torch.randn(c) * 0.1, "b.norm.running_var": torch.rand(c) + 0.5, "b.norm.num_batches_tracked": torch.zeros((), dtype=torch.long), "b.act.weight": torch.tensor([0.2])}
+    ycl, rcl, gcl = H.to_cl(y, H.DT[dt]), H.to_cl(r, H.DT[dt]), H.to_cl(gout, H.DT[dt])
+    nvox = n * int(np.prod(dims))
+    # statistics through the same sharded fp64 buffer the conv epilogue fills
+    stats = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
+    yf = H.from_cl(ycl).double()
+    stats[0, 0] = yf.sum((0, 2, 3, 4)).cuda()
+    stats[0, 1] = (yf * yf).sum((0, 2, 3, 4)).cuda()
+    g, be, al = sd["b.norm.weight"].cuda(), sd["b.norm.bias"].cuda(), sd["b.act.weight"].cuda()
+    rm, rv, nb = sd["b.norm.running_mean"].cuda(), sd["b.norm.running_var"].cuda(), torch.zeros(1, dtype=torch.int64, device="cuda")
+    vec = torch.zeros(6, c, device="cuda")
+    S = H.stream()
+    L.check(lib.vsseg_bn_finalize(stats.data_ptr(), c, c, float(nvox), g.data_ptr(), be.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), nb.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), S))
+    out = torch.zeros_like(ycl)
+    seed, salt = 0x1234ABCD5678, 7
+    L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, H.tdesc(rcl), 1, H.tdesc(out), S))
+    mask = torch.ones(n, *dims, c, device="cuda")
+    L.check(lib.vsseg_dropout_mask(mask.data_ptr(), nvox, c, p_drop, seed, salt, S))
+    torch.cuda.synchronize()
+    if p_drop > 0:
+        assert 0.85 < float(mask.mean()) < 0.95
+    # oracle: BN->dropout(mask)->PReLU on the same y, plus residual
+    yy = H.from_cl(ycl).double().requires_grad_(True)
+    sd64 = {k2: (v.double() if v.is_floating_point() else v) for k2, v in sd.items()}
+    for k2 in ("b.norm.weight", "b.norm.bias", "b.act.weight"):
+        sd64[k2].requires_grad_(True)
+    ctx = O.Ctx(True, p_drop, masks={"b": mask.cpu().permute(0, 4, 1, 2, 3).double()})
+    mean, var = yy.mean((0, 2, 3, 4)), yy.var((0, 2, 3, 4), unbiased=False)
+    sh = (1, -1, 1, 1, 1)
+    z = (yy - mean.view(sh)) / torch.sqrt(var.view(sh) + 1e-5) * sd64["b.norm.weight"].view(sh) + sd64["b.norm.bias"].view(sh)
+    if p_drop > 0:
+        z = z * ctx.masks["b"] / (1 - p_drop)
+    ref = F.prelu(z, sd64["b.act.weight"]) + H.from_cl(rcl).double()
+    np.testing.assert_allclose(H.from_cl(out).numpy(), ref.detach().float().numpy(), atol=_tol(dt, ref))
+    np.testing.assert_allclose(rm.cpu().numpy(), (0.9 * sd["b.norm.running_mean"] + 0.1 * mean.detach().float()).numpy(), atol=1e-5)
+    np.testing.assert_allclose(rv.cpu().numpy(), (0.9 * sd["b.norm.running_var"] + 0.1 * (var.detach() * nvox / (nvox - 1)).float()).numpy(), atol=1e-5)
+    assert int(nb) == 1
+    # backward
+    ref.backward(H.from_cl(gcl).double())
+    sums = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
+    aacc = torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
+    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), S))
+    dg, db, da = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
+    L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), S))
+    dy = torch.zeros_like(ycl)
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), S))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(H.from_cl(dy).numpy(), yy.grad.float().numpy(), atol=_tol(dt, yy.grad))
+    np.testing.assert_allclose(dg.cpu().numpy(), sd64["b.norm.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), sd64["b.norm.bias"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(da.cpu().numpy(), sd64["b.act.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_attention_gate_forward_backward(dt):
+    lib = L.lib()
+    torch.manual_seed(6)
+    c, dims, n = 32, (8, 8, 4), 2
+    x = _round(torch.randn(n, c, *dims), dt).double().requires_grad_(True)
+    pre = torch.randn(n, 1, *dims, dtype=torch.float64, requires_grad=True)
+    att = torch.sigmoid(pre)
+    out = att * x + x
+    gout = _round(torch.randn(n, c, *dims), dt)
+    gatt_ext = torch.randn(n, 1, *dims)
+    (out * gout.double()).sum().add((att * gatt_ext.double()).sum()).backward()
+    xcl, gcl = H.to_cl(x, H.DT[dt]), H.to_cl(gout, H.DT[dt])
+    attd = att.detach().float().reshape(n, *dims).contiguous().cuda()
+    o = torch.zeros_like(xcl)
+    S = H.stream()
+    L.check(lib.vsseg_att_apply_fwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(o), S))
+    dx = torch.zeros_like(xcl)
+    dpre = torch.zeros(n, *dims, 8, dtype=H.DT[dt], device="cuda")
+    ge = gatt_ext.reshape(n, *dims).contiguous().cuda()
+    L.check(lib.vsseg_att_apply_bwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(gcl), ge.data_ptr(), H.tdesc(dx), 0, H.tdesc(dpre), S))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(H.from_cl(o).numpy(), out.detach().float().numpy(), atol=_tol(dt, out))
+    np.testing.assert_allclose(H.from_cl(dx).numpy(), x.grad.float().numpy(), atol=_tol(dt, x.grad))
+    np.testing.assert_allclose(H.from_cl(dpre, 1).numpy(), pre.grad.float().numpy(), atol=_tol(dt, pre.grad))
+    assert float(dpre[..., 1:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("att", [True, False])
+@pytest.mark.parametrize("hard", [True, False])
+def test_dice_spvpa_loss_matches_reference_golden(att, hard):
+    """Loss value and gradients against the golden captured from the REFERENCE's Dice_spvPA (tests/golden/loss.npz)."""
+    import vs_seg_amd as V
+
+    g = load("loss.npz")
+    shape = (2, 1, 32, 32, 8)
+    att_shapes = [(2, 1, 1, 1, 1), (2, 1, 2, 2, 2), (2, 1, 4, 4, 4), (2, 1, 8, 8, 8), (2, 1, 16, 16, 8), (2, 1, 32, 32, 8)]
+    y = synth_label(31, shape).cuda()
+    logits = (2.0 * synth_input(32, (2, 2, 32, 32, 8))).cuda().requires_grad_(True)
+    atts = [torch.sigmoid(synth_input(40 + i, s)).cuda().requires_grad_(True) for i, s in enumerate(att_shapes)] if att else []
+    loss = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=att, hardness_weighting=hard)((logits, atts), y)
+    assert loss.dim() == 0
+    loss.backward()
+    tag = f"att{int(att)}_hard{int(hard)}"
+    assert abs(loss.item() - float(g[tag + ":loss"])) < 5e-6
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), g[tag + ":dlogits"], atol=2e-9, rtol=2e-4)
+    for i, a in enumerate(atts):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), g[f"{tag}:datt{i}"], atol=2e-9, rtol=2e-4)
+
+
+def test_adam_matches_torch_golden():
+    g = load("adam.npz")
+    lib = L.lib()
+    p = torch.from_numpy(g["p0"].copy()).cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step, gr in enumerate(g["grads"], 1):
+        gd = torch.from_numpy(gr.copy()).cuda()
+        L.check(lib.vsseg_adam(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1e-4, 0.9, 0.999, 1e-8, 1e-7, 1 - 0.9**step, 1 - 0.999**step, 1.0, H.stream()))
+        np.testing.assert_allclose(p.cpu().numpy(), g["after"][step - 1], atol=2e-7, rtol=1e-6)
+
+
+@pytest.mark.parametrize("vol,roi,ov,mode,swb", [((40, 36, 20), (16, 16, 32), 0.5, "gaussian", 1), ((48, 40, 24), (32, 16, 16), 0.25, "gaussian", 3), ((20, 20, 20), (16, 16, 8), 0.25, "constant", 2)])
+def test_sliding_window_blend_matches_oracle(vol, roi, ov, mode, swb):
+    """Same (cheap, deterministic) predictor on both sides: isolates window indexing, Gaussian map, blend, normalise, crop."""
+    import vs_seg_amd as V
+
+    torch.manual_seed(7)
+    x = torch.randn(2, 1, *vol)
+
+    def pred(w):
+        return torch.cat([w * 2.0 + 1.0, torch.tanh(w) - 0.5], 1)
+
+    want, starts = O.sliding_window_inference(x, roi, swb, pred, overlap=ov, mode=mode, return_windows=True)
+    got = V.sliding_window_inference(x.cuda(), roi, swb, pred, overlap=ov, mode=mode)
+    assert tuple(got.shape) == tuple(want.shape)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=2e-6, rtol=2e-6)
+    from vs_seg_amd.inferers import importance_map, window_geometry
+
+    assert window_geometry(vol, roi, ov)[4] == starts  # bit-exact patch indexing
+    if mode == "gaussian":
+        r = window_geometry(vol, roi, ov)[0]
+        np.testing.assert_array_equal(importance_map(r, "gaussian", "cpu").numpy(), O.gaussian_importance_map(r).numpy())
+
+
+def test_hard_dice_matches_oracle():
+    import vs_seg_amd as V
+
+    torch.manual_seed(8)
+    logits = torch.randn(1, 2, 24, 20, 12)
+    label = synth_label(3, (1, 1, 24, 20, 12))
+    want = O.compute_dice_score(logits, label)
+    got = V.compute_dice_score(logits.cuda(), label.cuda())
+    assert tuple(got.shape) == (1, 1)
+    assert abs(float(got) - float(want)) < 1e-6

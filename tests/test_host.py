@@ -1,0 +1,56 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, plans lower without a GPU."""
+import ctypes
+import re
+
+import pytest
+import torch
+
+from vs_seg_amd import _lib as L
+from vs_seg_amd.engine import Engine, ParamLayout
+from vs_seg_amd.graph import build_program, state_manifest
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.lib()
+    header = open("include/vsseg_hip.h").read()
+    declared = set(re.findall(r"\b(vsseg_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.vsseg_version() >= 1
+
+
+def test_invalid_descriptor_is_rejected_with_message():
+    lib = L.lib()
+    d = L.IgemmDesc()
+    assert lib.vsseg_igemm_lds_bytes(ctypes.byref(d)) < 0
+    assert b"vsseg_igemm" in lib.vsseg_last_error()
+
+
+@pytest.mark.parametrize("att", [True, False])
+@pytest.mark.parametrize("dt", ["bf16", "fp32"])
+def test_plans_lower_on_cpu(att, dt):
+    lay = ParamLayout(state_manifest(att))
+    flat = torch.zeros(lay.n_param)
+    eng = Engine(att, dt, flat, torch.zeros_like(flat), torch.zeros(lay.n_buf), torch.zeros(lay.n_cnt, dtype=torch.int64), lay, dry_run=True)
+    tr = eng.plan(2, (64, 32, 16), True)
+    ev = eng.plan(1, (64, 32, 16), False)
+    prog = build_program(att)
+    n_conv = len(prog.layers)
+    igemms = [r for r in tr.fwd if r[0] is eng.lib.vsseg_igemm]
+    assert len(igemms) >= n_conv  # transposed convs launch one igemm per output-parity class
+    assert sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_wgrad) == n_conv
+    assert len(ev.bwd) == 0 and len(ev.fwd) < len(tr.fwd)
+    assert len(tr.seed_slots) == 3 * sum(1 for L_ in prog.layers if L_.has_bn)
+    # the LDS request the C side computes equals the planner's (mirrored formula)
+    for rec in igemms[:10]:
+        d = rec[1][0]._obj
+        assert eng.lib.vsseg_igemm_lds_bytes(ctypes.byref(d)) > 0
+
+
+def test_bad_spatial_size_raises():
+    lay = ParamLayout(state_manifest(True))
+    flat = torch.zeros(lay.n_param)
+    eng = Engine(True, "bf16", flat, torch.zeros_like(flat), torch.zeros(lay.n_buf), torch.zeros(lay.n_cnt, dtype=torch.int64), lay, dry_run=True)
+    with pytest.raises(ValueError):
+        eng.plan(1, (48, 32, 8), False)

@@ -1,0 +1,118 @@
+"""CPU tests of the host-side planner: lattice classes, tap tables and weight pack maps.
+
+`planner.simulate_igemm` restates igemm_kernel's indexing literally in numpy, so a wrong tap offset, parity class or
+pack-map entry fails here, without a GPU.  The expected values come from the convolution definitions themselves
+(torch.nn.functional on CPU and its autograd, the same calls the oracle makes).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vs_seg_amd import planner as P
+
+CASES = [
+    # kernel, stride, cin, cout, dims
+    ((3, 3, 1), (1, 1, 1), 16, 16, (8, 8, 4)),
+    ((3, 3, 3), (1, 1, 1), 16, 40, (6, 8, 4)),
+    ((1, 1, 1), (1, 1, 1), 32, 16, (4, 4, 4)),
+    ((3, 3, 1), (2, 2, 1), 16, 16, (8, 8, 4)),
+    ((3, 3, 3), (2, 2, 2), 24, 16, (8, 4, 8)),
+    ((3, 3, 3), (1, 1, 1), 8, 2, (4, 4, 4)),
+    ((3, 3, 3), (1, 1, 1), 112, 100, (4, 4, 2)),  # nsplit=2 and several chunks
+]
+
+
+def _cl(x):  # NCDHW torch -> NDHWC numpy
+    return x.permute(0, 2, 3, 4, 1).contiguous().numpy()
+
+
+def _run(kind, w, x_cl, out_shape, lds_budget=64 * 1024):
+    out = None
+    wshape = tuple(w.shape)
+    k = wshape[2:]
+    classes = P.lattice_classes(kind, k, _run.stride)
+    for cls in classes:
+        if kind in ("conv_fwd", "convT_dgrad"):
+            q = out_shape
+        else:
+            q = tuple((o + s - 1) // s for o, s in zip(out_shape, _run.stride))
+        plan = P.plan_igemm(kind, wshape, cls, q, es=2, kc_pad=x_cl.shape[-1], lds_budget=lds_budget)
+        assert plan.tile[0] * plan.tile[1] * plan.tile[2] == 64 * plan.mtw
+        assert plan.lds <= P.LDS_LIMIT
+        part = P.simulate_igemm(plan, x_cl, w.numpy().reshape(-1), out_shape)
+        out = part if out is None else out + part
+    return out
+
+
+@pytest.mark.parametrize("k,s,cin,cout,dims", CASES)
+def test_conv_fwd_and_dgrad(k, s, cin, cout, dims):
+    torch.manual_seed(0)
+    pad = P.same_pad(k)
+    x = torch.randn(2, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64)
+    y = F.conv3d(x, w, stride=s, padding=pad)
+    _run.stride = s
+    got = _run("conv_fwd", w, _cl(x.detach()), tuple(y.shape[2:]))
+    np.testing.assert_allclose(got, _cl(y.detach()), atol=1e-9)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    cpad = P.round_up(cout, 8)
+    gy_cl = np.zeros((2, *y.shape[2:], cpad))
+    gy_cl[..., :cout] = _cl(gy)
+    got = _run("conv_dgrad", w, gy_cl, dims)
+    np.testing.assert_allclose(got, _cl(x.grad), atol=1e-9)
+
+
+@pytest.mark.parametrize("k,s,cin,cout,dims", [((3, 3, 1), (2, 2, 1), 16, 8, (4, 4, 4)), ((3, 3, 3), (2, 2, 2), 16, 24, (4, 2, 4)), ((3, 3, 3), (2, 2, 2), 96, 80, (2, 2, 2))])
+def test_convT_fwd_and_dgrad(k, s, cin, cout, dims):
+    torch.manual_seed(1)
+    pad = P.same_pad(k)
+    opad = tuple(ss + 2 * p - (kk - 1) - 1 for ss, p, kk in zip(s, pad, k))
+    x = torch.randn(2, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cin, cout, *k, dtype=torch.float64)
+    y = F.conv_transpose3d(x, w, stride=s, padding=pad, output_padding=opad)
+    assert tuple(y.shape[2:]) == P.out_dims("convT_fwd", dims, k, s)
+    _run.stride = s
+    got = _run("convT_fwd", w, _cl(x.detach()), tuple(y.shape[2:]))
+    np.testing.assert_allclose(got, _cl(y.detach()), atol=1e-9)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    got = _run("convT_dgrad", w, _cl(gy), dims)
+    np.testing.assert_allclose(got, _cl(x.grad), atol=1e-9)
+
+
+def test_small_lds_budget_forces_channel_chunks():
+    torch.manual_seed(2)
+    k, s = (3, 3, 3), (1, 1, 1)
+    x = torch.randn(1, 96, 8, 8, 8, dtype=torch.float64)
+    w = torch.randn(48, 96, *k, dtype=torch.float64)
+    y = F.conv3d(x, w, padding=1)
+    _run.stride = s
+    cls = P.lattice_classes("conv_fwd", k, s)[0]
+    plan = P.plan_igemm("conv_fwd", tuple(w.shape), cls, (8, 8, 8), es=2, lds_budget=40 * 1024)
+    assert plan.nchunks > 1 and plan.ck * plan.nchunks == 96
+    got = P.simulate_igemm(plan, _cl(x), w.numpy().reshape(-1), (8, 8, 8))
+    np.testing.assert_allclose(got, _cl(y), atol=1e-9)
+
+
+def test_every_network_layer_has_a_feasible_plan():
+    """All 50 convolutions of the network at the benchmark patch, both dtypes, fwd + dgrad + wgrad."""
+    from vs_seg_amd.graph import conv_layers
+
+    for es in (2, 4):
+        for L in conv_layers(attention=True):
+            dims = L.in_dims((384, 128, 128))
+            kind = "convT_fwd" if L.transposed else "conv_fwd"
+            od = P.out_dims(kind, dims, L.kernel, L.stride)
+            wshape = L.wshape
+            for knd, q_of in ((kind, od if not L.transposed else dims), ("convT_dgrad" if L.transposed else "conv_dgrad", None)):
+                for cls in P.lattice_classes(knd, L.kernel, L.stride):
+                    if knd in ("conv_fwd", "convT_dgrad"):
+                        q = od if knd == "conv_fwd" else dims
+                    else:
+                        q = dims if knd == "convT_fwd" else tuple((d + s - 1) // s for d, s in zip(dims, L.stride))
+                    plan = P.plan_igemm(knd, wshape, cls, q, es)
+                    assert plan.lds <= P.LDS_LIMIT and 1 <= plan.nt <= 6 and plan.mtw in (1, 2, 4)
+            wp = P.plan_wgrad(L.transposed, wshape, L.kernel, L.stride, dims if L.transposed else od, es)
+            assert wp.lds <= P.LDS_LIMIT and wp.ntp <= 6 and (wp.tile[0] * wp.tile[1] * wp.tile[2]) % 32 == 0

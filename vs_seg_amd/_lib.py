@@ -1,0 +1,140 @@
+"""ctypes binding of libvsseg_hip.so (C ABI declared in include/vsseg_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libvsseg_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_RELUMASK = 0, 1, 2
+MAX_TAPS = 27
+STAT_SHARDS = 256
+
+
+class Tensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("c", C.c_int32), ("pitch", C.c_int32), ("n", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32)]
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [
+        ("inp", Tensor),
+        ("out", Tensor),
+        ("q", C.c_int32 * 3),
+        ("is_", C.c_int32 * 3),
+        ("os", C.c_int32 * 3),
+        ("oo", C.c_int32 * 3),
+        ("ntaps", C.c_int32),
+        ("tap_off", (C.c_int32 * 3) * MAX_TAPS),
+        ("tile", C.c_int32 * 3),
+        ("mtw", C.c_int32),
+        ("nt", C.c_int32),
+        ("nsplit", C.c_int32),
+        ("ck", C.c_int32),
+        ("nchunks", C.c_int32),
+        ("ksteps", C.c_int32),
+        ("wpack", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("scale", C.c_void_p),
+        ("shift", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("act", C.c_int32),
+        ("res_mode", C.c_int32),
+        ("res", Tensor),
+        ("accumulate", C.c_int32),
+        ("stats", C.c_void_p),
+        ("stats_stride", C.c_int32),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("p", Tensor),
+        ("h", Tensor),
+        ("q", C.c_int32 * 3),
+        ("hs", C.c_int32 * 3),
+        ("ntaps", C.c_int32),
+        ("tap_off", (C.c_int32 * 3) * MAX_TAPS),
+        ("tap_widx", C.c_int32 * MAX_TAPS),
+        ("tile", C.c_int32 * 3),
+        ("ntp", C.c_int32),
+        ("dw", C.c_void_p),
+        ("stride_p", C.c_int64),
+        ("stride_h", C.c_int64),
+        ("stride_tap", C.c_int64),
+        ("cp_valid", C.c_int32),
+        ("ch_valid", C.c_int32),
+        ("persistent_blocks", C.c_int32),
+    ]
+
+
+# every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
+SYMBOLS = [
+    "vsseg_last_error", "vsseg_version", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_stage_input",
+    "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
+    "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
+    "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
+    "vsseg_adam", "vsseg_swi_accumulate", "vsseg_swi_finalize", "vsseg_hard_dice_counts", "vsseg_argmax2",
+]  # fmt: skip
+
+_lib = None
+
+
+def lib():
+    """Load libvsseg_hip.so (built in-tree by `__graft_entry__.build()` / `make -C vs_seg_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(f"vs_seg_amd: HIP extension {SO_PATH} is missing — build it with `make -C vs_seg_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(SO_PATH)
+        L.vsseg_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            fn = getattr(L, name)
+            if name != "vsseg_last_error":
+                fn.restype = C.c_int
+        vp, i32, i64, f32, f64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_uint32
+        I3 = C.POINTER(C.c_int32)
+        L.vsseg_igemm.argtypes = [C.POINTER(IgemmDesc), vp]
+        L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
+        L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
+        L.vsseg_gather_cast.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.vsseg_stage_input.argtypes = [vp, i32, I3, I3, Tensor, vp]
+        L.vsseg_bn_finalize.argtypes = [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.vsseg_bn_fold_eval.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
+        L.vsseg_bn_act_fwd.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, Tensor, i32, Tensor, vp]
+        L.vsseg_bn_act_bwd_reduce.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, f32, u64, u32, vp, i32, vp, vp]
+        L.vsseg_bn_act_bwd_finalize.argtypes = [vp, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp]
+        L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp]
+        L.vsseg_dropout_mask.argtypes = [vp, i64, i32, f32, u64, u32, vp]
+        L.vsseg_att_apply_fwd.argtypes = [Tensor, vp, Tensor, vp]
+        L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp]
+        L.vsseg_channel_sum.argtypes = [Tensor, vp, vp]
+        L.vsseg_add_inplace.argtypes = [Tensor, Tensor, vp]
+        L.vsseg_copy_cast.argtypes = [Tensor, Tensor, vp]
+        L.vsseg_maxpool_label.argtypes = [vp, i32, I3, I3, vp, vp]
+        L.vsseg_dice_pred_sums.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp]
+        L.vsseg_dice_att_sums.argtypes = [vp, vp, i32, i64, vp, vp]
+        L.vsseg_dice_finalize.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+        L.vsseg_dice_pred_bwd.argtypes = [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp]
+        L.vsseg_dice_att_bwd.argtypes = [vp, i32, i64, vp, f32, vp, vp, vp]
+        L.vsseg_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]
+        L.vsseg_swi_accumulate.argtypes = [vp, vp, I3, I3, i32, vp, vp, I3, vp]
+        L.vsseg_swi_finalize.argtypes = [vp, vp, I3, I3, I3, i32, vp, vp]
+        L.vsseg_hard_dice_counts.argtypes = [vp, i32, vp, i64, vp, vp]
+        L.vsseg_argmax2.argtypes = [vp, i32, i64, vp, vp]
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"vsseg {what} failed ({rc}): {lib().vsseg_last_error().decode()}")
+
+
+def i3(v):
+    return (C.c_int32 * 3)(*[int(a) for a in v])

@@ -1,0 +1,128 @@
+// Device/host helpers shared by the gfx950 kernels of libvsseg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/vsseg_hip.h"
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+extern "C" void vsseg_set_error(const char* fmt, ...);
+
+#define VSSEG_CHECK(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      vsseg_set_error(__VA_ARGS__);       \
+      return VSSEG_EINVAL;                \
+    }                                     \
+  } while (0)
+
+#define VSSEG_LAUNCH_CHECK(name)                                                   \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      vsseg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return VSSEG_ELAUNCH;                                                        \
+    }                                                                              \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (NaN not expected on this path)
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load / store 4 consecutive channels as floats (p 8-byte aligned for bf16, 16-byte for f32)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  uint2 u;
+  u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+  u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+// 8 consecutive channels
+struct f8 { float v[8]; };
+__device__ __forceinline__ f8 ld8(const float* p) {
+  float4 a = ld4(p), b = ld4(p + 4);
+  return f8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ f8 ld8(const bf16_t* p) {
+  uint4 u = *reinterpret_cast<const uint4*>(p);
+  return f8{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+             __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+}
+__device__ __forceinline__ void st8(float* p, const f8& a) {
+  st4(p, make_float4(a.v[0], a.v[1], a.v[2], a.v[3]));
+  st4(p + 4, make_float4(a.v[4], a.v[5], a.v[6], a.v[7]));
+}
+__device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
+  uint4 u;
+  u.x = (unsigned)f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16);
+  u.y = (unsigned)f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
+  u.z = (unsigned)f2bf(a.v[4]) | ((unsigned)f2bf(a.v[5]) << 16);
+  u.w = (unsigned)f2bf(a.v[6]) | ((unsigned)f2bf(a.v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+
+// ---- Philox4x32-10 counter-based RNG: dropout keep-masks are regenerated in backward instead of stored ----
+__device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
+  const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    unsigned hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
+    unsigned hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
+    key.x += W0;
+    key.y += W1;
+  }
+  return ctr;
+}
+// keep-mask for the 8 elements [8*i8, 8*i8+8) of a layer's activation tensor (logical [voxel][c] order, pitch-free)
+__device__ __forceinline__ unsigned dropout_keep8(uint64_t seed, uint32_t salt, uint64_t i8, float p) {
+  uint4 r0 = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  uint4 r1 = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 1u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  unsigned thr = (unsigned)(p * 4294967296.0f);  // keep iff r >= thr  (P[keep] = 1-p)
+  unsigned m = 0;
+  m |= (r0.x >= thr) << 0; m |= (r0.y >= thr) << 1; m |= (r0.z >= thr) << 2; m |= (r0.w >= thr) << 3;
+  m |= (r1.x >= thr) << 4; m |= (r1.y >= thr) << 5; m |= (r1.z >= thr) << 6; m |= (r1.w >= thr) << 7;
+  return m;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}

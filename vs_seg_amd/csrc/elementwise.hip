@@ -1,0 +1,425 @@
+// HBM-bound kernels of the hot path: BatchNorm/Dropout/PReLU forward+backward, attention gate, staging, Adam.
+// All are one-pass streaming kernels with 16-byte (8 x bf16) accesses along the channel axis of the channels-last layout.
+#include "common.h"
+
+#define DISPATCH_T(dtype, ...)                         \
+  do {                                                 \
+    if ((dtype) == VSSEG_F32) { typedef float T; __VA_ARGS__; } \
+    else { typedef bf16_t T; __VA_ARGS__; }            \
+  } while (0)
+
+// block size such that every thread keeps one fixed 8-channel group while striding over voxels
+static inline int block_for_cgs(int cgs) {
+  int a = cgs, b = 64;
+  while (b) { int t = a % b; a = b; b = t; }
+  int blk = 64 * (cgs / a);
+  while (blk < 256 && (blk * 2) % cgs == 0) blk *= 2;
+  return blk > 1024 ? 0 : blk;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// gather-cast (weight packing), input staging, copies
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ map, T* __restrict__ dst, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int m = map[i];
+    Elem<T>::st(dst + i, m >= 0 ? src[m] : 0.f);
+  }
+}
+extern "C" int vsseg_gather_cast(const float* src, const int32_t* map, void* dst, int64_t n, int32_t dst_dtype, void* stream) {
+  VSSEG_CHECK(src && map && dst && n >= 0, "vsseg_gather_cast: bad arguments");
+  if (n == 0) return VSSEG_OK;
+  DISPATCH_T(dst_dtype, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), src, map, (T*)dst, n));
+  VSSEG_LAUNCH_CHECK("vsseg_gather_cast");
+  return VSSEG_OK;
+}
+
+template <typename T> __global__ void stage_input_kernel(const float* __restrict__ src, int n, int sx, int sy, int sz, int ox, int oy, int oz, vsseg_tensor dst) {
+  const int64_t per = (int64_t)dst.x * dst.y * dst.z, total = per * n;
+  T* out = reinterpret_cast<T*>(dst.ptr);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = i / per, r = i - b * per;
+    int z = (int)(r % dst.z); r /= dst.z;
+    int y = (int)(r % dst.y);
+    int x = (int)(r / dst.y);
+    int gx = x + ox, gy = y + oy, gz = z + oz;
+    float v = 0.f;
+    if ((unsigned)gx < (unsigned)sx && (unsigned)gy < (unsigned)sy && (unsigned)gz < (unsigned)sz) v = src[((b * sx + gx) * sy + gy) * (int64_t)sz + gz];
+    T* o = out + i * dst.pitch;
+    if ((dst.c & 7) == 0) {
+      f8 e{{v, 0, 0, 0, 0, 0, 0, 0}};
+      for (int c = 0; c < dst.c; c += 8) { st8(o + c, e); e.v[0] = 0.f; }
+    } else {  // plain crop (c == 1) or an odd channel count: scalar stores
+      Elem<T>::st(o, v);
+      for (int c = 1; c < dst.c; ++c) Elem<T>::st(o + c, 0.f);
+    }
+  }
+}
+extern "C" int vsseg_stage_input(const float* src, int32_t n, const int32_t sdims[3], const int32_t origin[3], vsseg_tensor dst, void* stream) {
+  VSSEG_CHECK(src && dst.ptr && dst.c >= 1 && dst.pitch >= dst.c && dst.n == n, "vsseg_stage_input: bad arguments");
+  VSSEG_CHECK(dst.c % 8 != 0 || dst.pitch % 8 == 0, "vsseg_stage_input: vectorised path needs pitch %% 8 == 0");
+  int64_t total = tensor_voxels(dst);
+  DISPATCH_T(dst.dtype, hipLaunchKernelGGL(stage_input_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), src, n, sdims[0], sdims[1], sdims[2], origin[0], origin[1], origin[2], dst));
+  VSSEG_LAUNCH_CHECK("vsseg_stage_input");
+  return VSSEG_OK;
+}
+
+template <typename S, typename D, bool ADD> __global__ void copy_kernel(const S* __restrict__ src, int sp, D* __restrict__ dst, int dp, int c, int64_t nvox) {
+  const int64_t total = nvox * c;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = i / c;
+    int ch = (int)(i - v * c);
+    float x = Elem<S>::ld(src + v * sp + ch);
+    D* o = dst + v * dp + ch;
+    Elem<D>::st(o, ADD ? Elem<D>::ld(o) + x : x);
+  }
+}
+template <bool ADD> static int copy_impl(vsseg_tensor src, vsseg_tensor dst, void* stream, const char* name) {
+  VSSEG_CHECK(src.ptr && dst.ptr && src.c == dst.c && tensor_voxels(src) == tensor_voxels(dst), "%s: shape mismatch", name);
+  int64_t nv = tensor_voxels(src), total = nv * src.c;
+  dim3 g(grid_for(total, 256)), b(256);
+  hipStream_t s = as_stream(stream);
+  if (src.dtype == VSSEG_F32 && dst.dtype == VSSEG_F32) hipLaunchKernelGGL((copy_kernel<float, float, ADD>), g, b, 0, s, (const float*)src.ptr, src.pitch, (float*)dst.ptr, dst.pitch, src.c, nv);
+  else if (src.dtype == VSSEG_F32) hipLaunchKernelGGL((copy_kernel<float, bf16_t, ADD>), g, b, 0, s, (const float*)src.ptr, src.pitch, (bf16_t*)dst.ptr, dst.pitch, src.c, nv);
+  else if (dst.dtype == VSSEG_F32) hipLaunchKernelGGL((copy_kernel<bf16_t, float, ADD>), g, b, 0, s, (const bf16_t*)src.ptr, src.pitch, (float*)dst.ptr, dst.pitch, src.c, nv);
+  else hipLaunchKernelGGL((copy_kernel<bf16_t, bf16_t, ADD>), g, b, 0, s, (const bf16_t*)src.ptr, src.pitch, (bf16_t*)dst.ptr, dst.pitch, src.c, nv);
+  VSSEG_LAUNCH_CHECK(name);
+  return VSSEG_OK;
+}
+extern "C" int vsseg_copy_cast(vsseg_tensor src, vsseg_tensor dst, void* stream) { return copy_impl<false>(src, dst, stream, "vsseg_copy_cast"); }
+extern "C" int vsseg_add_inplace(vsseg_tensor dst, vsseg_tensor src, void* stream) { return copy_impl<true>(src, dst, stream, "vsseg_add_inplace"); }
+
+// ------------------------------------------------------------------------------------------------------------
+// BatchNorm statistics
+// ------------------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride, int c, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                   float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0 && num_batches) *num_batches += 1;
+  if (ch >= c) return;
+  double s = 0, q = 0;
+  for (int sh = 0; sh < VSSEG_STAT_SHARDS; ++sh) {
+    s += stats[(int64_t)sh * 2 * stride + ch];
+    q += stats[(int64_t)sh * 2 * stride + stride + ch];
+  }
+  double m = s / count;
+  double var = q / count - m * m;
+  if (var < 0) var = 0;
+  float is = (float)(1.0 / sqrt(var + (double)eps));
+  mean[ch] = (float)m;
+  invstd[ch] = is;
+  float sc = gamma[ch] * is;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - (float)m * sc;
+  if (running_mean) {
+    double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)m;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+  }
+}
+extern "C" int vsseg_bn_finalize(const double* stats, int32_t stride, int32_t c, double count, const float* gamma, const float* beta, float eps, float momentum,
+                                 float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  VSSEG_CHECK(stats && gamma && beta && mean && invstd && scale && shift && c > 0 && c <= stride, "vsseg_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), stats, stride, c, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd, scale, shift);
+  VSSEG_LAUNCH_CHECK("vsseg_bn_finalize");
+  return VSSEG_OK;
+}
+__global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int c) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - rm[ch] * sc;
+}
+extern "C" int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int32_t c, void* stream) {
+  VSSEG_CHECK(gamma && beta && rm && rv && scale && shift && c > 0, "vsseg_bn_fold_eval: bad arguments");
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), gamma, beta, rm, rv, eps, scale, shift, c);
+  VSSEG_LAUNCH_CHECK("vsseg_bn_fold_eval");
+  return VSSEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// BN -> Dropout -> PReLU (+ residual) forward            ref:params/networks/blocks/convolutions.py:148-156, 252-255
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, bool RES>
+__global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ alpha_p,
+                                  float p_drop, uint64_t seed, uint32_t salt, const T* __restrict__ res, int rp, T* __restrict__ out, int op, int cgs, int64_t nvox) {
+  const int64_t total = nvox * cgs;
+  const float alpha = *alpha_p, inv_keep = 1.f / (1.f - p_drop);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = i / cgs;
+    int c = (int)(i - v * cgs) * 8;
+    f8 x = ld8(y + v * yp + c);
+    unsigned keep = p_drop > 0.f ? dropout_keep8(seed, salt, (uint64_t)i, p_drop) : 0xffu;
+    f8 r;
+    if (RES) r = ld8(res + v * rp + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float z = x.v[j] * scale[c + j] + shift[c + j];
+      z = ((keep >> j) & 1u) ? z * inv_keep : 0.f;  // p_drop == 0: keep == 0xff and inv_keep == 1
+      z = z > 0.f ? z : alpha * z;
+      x.v[j] = RES ? z + r.v[j] : z;
+    }
+    st8(out + v * op + c, x);
+  }
+}
+extern "C" int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
+                                vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream) {
+  VSSEG_CHECK(y.ptr && out.ptr && scale && shift && alpha && y.c % 8 == 0 && y.pitch % 8 == 0 && out.pitch % 8 == 0 && out.c == y.c && out.dtype == y.dtype, "vsseg_bn_act_fwd: bad arguments");
+  VSSEG_CHECK(!has_res || (res.ptr && res.dtype == y.dtype && res.c == y.c && res.pitch % 8 == 0), "vsseg_bn_act_fwd: bad residual");
+  VSSEG_CHECK(p_drop >= 0.f && p_drop < 1.f, "vsseg_bn_act_fwd: dropout p out of range");
+  int64_t nv = tensor_voxels(y);
+  int cgs = y.c / 8;
+  dim3 g(grid_for(nv * cgs, 256)), b(256);
+  DISPATCH_T(y.dtype, if (has_res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)res.ptr, res.pitch, (T*)out.ptr, out.pitch, cgs, nv);
+             else hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)nullptr, 0, (T*)out.ptr, out.pitch, cgs, nv));
+  VSSEG_LAUNCH_CHECK("vsseg_bn_act_fwd");
+  return VSSEG_OK;
+}
+
+__global__ void dropout_mask_kernel(float* mask, int64_t n8, float p, uint64_t seed, uint32_t salt) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned keep = p > 0.f ? dropout_keep8(seed, salt, (uint64_t)i, p) : 0xffu;
+    for (int j = 0; j < 8; ++j) mask[i * 8 + j] = (float)((keep >> j) & 1u);
+  }
+}
+extern "C" int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint64_t seed, uint32_t salt, void* stream) {
+  VSSEG_CHECK(mask && c % 8 == 0, "vsseg_dropout_mask: bad arguments");
+  int64_t n8 = nvox * (c / 8);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, as_stream(stream), mask, n8, p_drop, seed, salt);
+  VSSEG_LAUNCH_CHECK("vsseg_dropout_mask");
+  return VSSEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// backward of BN -> Dropout -> PReLU.  dz = d(loss)/d(BN output); pass 1 reduces, pass 2 applies.
+// ------------------------------------------------------------------------------------------------------------
+struct BnBwdArgs {
+  const float *mean, *invstd, *gamma, *beta, *alpha;
+  float p_drop;
+  uint64_t seed;
+  uint32_t salt;
+};
+// recompute the forward for 8 channels and return dz (in dz) and xhat (in xh); returns the dalpha contribution
+__device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, int64_t i, const BnBwdArgs& a, float alpha, f8& dz, f8& xh) {
+  const float inv_keep = 1.f / (1.f - a.p_drop);
+  unsigned keep = a.p_drop > 0.f ? dropout_keep8(a.seed, a.salt, (uint64_t)i, a.p_drop) : 0xffu;
+  float dal = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float xhat = (y.v[j] - a.mean[c + j]) * a.invstd[c + j];
+    float z = a.gamma[c + j] * xhat + a.beta[c + j];
+    bool k = (keep >> j) & 1u;
+    float d = k ? z * inv_keep : 0.f;
+    float g = da.v[j];
+    float dd = d > 0.f ? g : alpha * g;
+    if (d < 0.f) dal += g * d;
+    dz.v[j] = k ? dd * inv_keep : 0.f;
+    xh.v[j] = xhat;
+  }
+  return dal;
+}
+
+template <typename T>
+__global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc) {
+  extern __shared__ float red[];  // [2][c] + [1]
+  const int C = cgs * 8;
+  for (int i = threadIdx.x; i < 2 * C + 1; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const float alpha = *a.alpha;
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+  const int cg = (int)(gt % cgs);
+  const int c = cg * 8;
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
+  for (int64_t v = gt / cgs; v < nvox; v += nthreads / cgs) {
+    f8 yy = ld8(y + v * yp + c), da = ld8(dout + v * dp + c), dz, xh;
+    dal += bn_bwd_elem8(yy, da, c, v * cgs + cg, a, alpha, dz, xh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] += dz.v[j]; s2[j] += dz.v[j] * xh.v[j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); }
+  dal = wave_sum(dal);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&red[2 * C], dal);
+  __syncthreads();
+  const int shard = blockIdx.x % VSSEG_STAT_SHARDS;
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&sums[(int64_t)shard * 2 * stride + (i / C) * stride + (i % C)], (double)red[i]);
+  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[2 * C]);
+}
+extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* alpha,
+                                       float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream) {
+  VSSEG_CHECK(y.ptr && dout.ptr && y.dtype == dout.dtype && y.c == dout.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && sums && alpha_acc && stride >= y.c, "vsseg_bn_act_bwd_reduce: bad arguments");
+  int cgs = y.c / 8, blk = block_for_cgs(cgs);
+  VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
+  int64_t nv = tensor_voxels(y);
+  BnBwdArgs a{mean, invstd, gamma, beta, alpha, p_drop, seed, salt};
+  int grid = grid_for(nv * cgs, blk, 256 * 8);
+  size_t lds = (2 * y.c + 1) * sizeof(float);
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
+  VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
+  return VSSEG_OK;
+}
+
+__global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int stride, const double* __restrict__ alpha_acc, int c, double count, float* dgamma, float* dbeta, float* dalpha, float* mean_dz, float* mean_dzx) {
+  int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch == 0) {
+    double a = 0;
+    for (int sh = 0; sh < VSSEG_STAT_SHARDS; ++sh) a += alpha_acc[sh];
+    *dalpha += (float)a;
+  }
+  if (ch >= c) return;
+  double s = 0, q = 0;
+  for (int sh = 0; sh < VSSEG_STAT_SHARDS; ++sh) {
+    s += sums[(int64_t)sh * 2 * stride + ch];
+    q += sums[(int64_t)sh * 2 * stride + stride + ch];
+  }
+  dbeta[ch] += (float)s;
+  dgamma[ch] += (float)q;
+  mean_dz[ch] = (float)(s / count);
+  mean_dzx[ch] = (float)(q / count);
+}
+extern "C" int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
+                                         float* mean_dz, float* mean_dzx, void* stream) {
+  VSSEG_CHECK(sums && alpha_acc && dgamma && dbeta && dalpha && mean_dz && mean_dzx && c > 0, "vsseg_bn_act_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx);
+  VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_finalize");
+  return VSSEG_OK;
+}
+
+template <typename T>
+__global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, const float* __restrict__ mean_dz, const float* __restrict__ mean_dzx,
+                                        T* __restrict__ dy, int dyp, int cgs, int64_t nvox) {
+  const int64_t total = nvox * cgs;
+  const float alpha = *a.alpha;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = i / cgs;
+    int c = (int)(i - v * cgs) * 8;
+    f8 yy = ld8(y + v * yp + c), da = ld8(dout + v * dp + c), dz, xh;
+    bn_bwd_elem8(yy, da, c, i, a, alpha, dz, xh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dz.v[j] = a.gamma[c + j] * a.invstd[c + j] * (dz.v[j] - mean_dz[c + j] - xh.v[j] * mean_dzx[c + j]);
+    st8(dy + v * dyp + c, dz);
+  }
+}
+extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* alpha,
+                                      float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream) {
+  VSSEG_CHECK(y.ptr && dout.ptr && dy.ptr && y.dtype == dout.dtype && y.dtype == dy.dtype && y.c == dout.c && y.c == dy.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && dy.pitch % 8 == 0,
+              "vsseg_bn_act_bwd_apply: bad arguments");
+  int cgs = y.c / 8;
+  int64_t nv = tensor_voxels(y);
+  BnBwdArgs a{mean, invstd, gamma, beta, alpha, p_drop, seed, salt};
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(nv * cgs, 256)), dim3(256), 0, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, mean_dz, mean_dzx, (T*)dy.ptr, dy.pitch, cgs, nv));
+  VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_apply");
+  return VSSEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// attention gate  out = x*(1+att)                       ref:params/networks/blocks/attentionblock.py:43-47
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void att_apply_fwd_kernel(const T* __restrict__ x, int xp, const float* __restrict__ att, T* __restrict__ out, int op, int cgs, int64_t nvox) {
+  const int64_t total = nvox * cgs;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = i / cgs;
+    int c = (int)(i - v * cgs) * 8;
+    const float g = 1.f + att[v];
+    f8 a = ld8(x + v * xp + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a.v[j] *= g;
+    st8(out + v * op + c, a);
+  }
+}
+extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream) {
+  VSSEG_CHECK(x.ptr && att && out.ptr && x.dtype == out.dtype && x.c == out.c && x.c % 8 == 0 && x.pitch % 8 == 0 && out.pitch % 8 == 0, "vsseg_att_apply_fwd: bad arguments");
+  int cgs = x.c / 8;
+  int64_t nv = tensor_voxels(x);
+  DISPATCH_T(x.dtype, hipLaunchKernelGGL(att_apply_fwd_kernel<T>, dim3(grid_for(nv * cgs, 256)), dim3(256), 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (T*)out.ptr, out.pitch, cgs, nv));
+  VSSEG_LAUNCH_CHECK("vsseg_att_apply_fwd");
+  return VSSEG_OK;
+}
+
+// one thread per voxel: dx = dout*(1+att) (optionally += ), dpre = (sum_c dout*x + datt_ext)*att*(1-att) in channel 0 of an 8-wide row
+template <typename T, bool ACC>
+__global__ void att_apply_bwd_kernel(const T* __restrict__ x, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
+                                     T* __restrict__ dx, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox) {
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    const float a = att[v], g = 1.f + a;
+    float dot = 0.f;
+    for (int cg = 0; cg < cgs; ++cg) {
+      f8 xx = ld8(x + v * xp + cg * 8), d = ld8(dout + v * dp + cg * 8);
+      f8 o;
+      if (ACC) o = ld8(dx + v * dxp + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        dot += d.v[j] * xx.v[j];
+        o.v[j] = ACC ? o.v[j] + d.v[j] * g : d.v[j] * g;
+      }
+      st8(dx + v * dxp + cg * 8, o);
+    }
+    if (datt_ext) dot += datt_ext[v];
+    f8 r{{dot * a * (1.f - a), 0, 0, 0, 0, 0, 0, 0}};
+    st8(dpre + v * dprep, r);
+  }
+}
+extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, void* stream) {
+  VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && dpre.ptr && x.dtype == dout.dtype && x.dtype == dx.dtype && x.dtype == dpre.dtype && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 && dpre.c == 8 &&
+                  x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && dpre.pitch % 8 == 0,
+              "vsseg_att_apply_bwd: bad arguments");
+  int cgs = x.c / 8;
+  int64_t nv = tensor_voxels(x);
+  dim3 g(grid_for(nv, 256)), b(256);
+  DISPATCH_T(x.dtype, if (accumulate_dx) hipLaunchKernelGGL((att_apply_bwd_kernel<T, true>), g, b, 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv);
+             else hipLaunchKernelGGL((att_apply_bwd_kernel<T, false>), g, b, 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv));
+  VSSEG_LAUNCH_CHECK("vsseg_att_apply_bwd");
+  return VSSEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-channel sum (bias gradients of convolutions that are not followed by BatchNorm)
+// ------------------------------------------------------------------------------------------------------------
+template <typename T> __global__ void channel_sum_kernel(const T* __restrict__ t, int pitch, int c, int64_t nvox, float* __restrict__ out) {
+  extern __shared__ float red[];
+  for (int i = threadIdx.x; i < c; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+  // thread keeps channel ch = gt % cpad fixed (cpad = c rounded to a divisor-friendly size handled by the host: blockDim % c == 0)
+  const int ch = (int)(gt % c);
+  float s = 0.f;
+  for (int64_t v = gt / c; v < nvox; v += nthreads / c) s += Elem<T>::ld(t + v * pitch + ch);
+  atomicAdd(&red[ch], s);
+  __syncthreads();
+  for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(&out[i], red[i]);
+}
+extern "C" int vsseg_channel_sum(vsseg_tensor t, float* out, void* stream) {
+  VSSEG_CHECK(t.ptr && out && t.c >= 1 && t.c <= 256, "vsseg_channel_sum: bad arguments");
+  int blk = t.c;
+  while (blk < 256) blk += t.c;  // multiple of c so that a thread's channel is loop-invariant
+  int64_t nv = tensor_voxels(t);
+  int grid = grid_for(nv * t.c, blk, 1024);
+  DISPATCH_T(t.dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, dim3(grid), dim3(blk), t.c * sizeof(float), as_stream(stream), (const T*)t.ptr, t.pitch, t.c, nv, out));
+  VSSEG_LAUNCH_CHECK("vsseg_channel_sum");
+  return VSSEG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Adam over the flat fp32 parameter buffer           torch.optim.Adam(lr, weight_decay) — ref:params/VSparams.py:388-391
+// ------------------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, float gscale) {
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float pp = p[i];
+    float gg = g[i] * gscale + wd * pp;
+    float mm = b1 * m[i] + (1.f - b1) * gg;
+    float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    p[i] = pp - step_size * mm / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+  }
+}
+extern "C" int vsseg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2, float gscale, void* stream) {
+  VSSEG_CHECK(p && g && m && v && n >= 0, "vsseg_adam: bad arguments");
+  if (n == 0) return VSSEG_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, wd, bc1, bc2, gscale);
+  VSSEG_LAUNCH_CHECK("vsseg_adam");
+  return VSSEG_OK;
+}

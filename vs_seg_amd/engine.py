@@ -1,0 +1,400 @@
+"""Lowers the static network program (vs_seg_amd.graph) to HIP launches through the C ABI and runs them.
+
+One `Plan` per (batch, spatial size, train/eval) signature holds every activation/gradient buffer, every prepared
+ctypes descriptor and two launch lists (forward, backward).  Running a step is a flat loop over prepared launches on
+torch's current HIP stream — no allocation, no host synchronisation, capturable in a hipGraph.
+
+torch tensors are used only as device-memory containers.  There is no CPU/eager fallback: a missing extension raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import planner as P
+from .graph import HP, AttGate, ConvBnAct, ConvPlain, Layer, Program, TensorSpec, build_program, level_dims
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm3d defaults (ref:params/networks/blocks/convolutions.py:152 passes no arguments)
+BN_MOMENTUM = 0.1
+ACT_CODE = {"none": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID}
+
+
+def _tdtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+class ParamLayout:
+    """Offsets of every state_dict entry inside the flat buffers owned by the model (params fp32, buffers fp32, counters int64)."""
+
+    def __init__(self, manifest):
+        self.param_off: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.buf_off: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.cnt_off: Dict[str, int] = {}
+        self.order = [k for k, _ in manifest]
+        po = bo = co = 0
+        for key, shape in manifest:
+            n = int(np.prod(shape)) if len(shape) else 1
+            if key.endswith("num_batches_tracked"):
+                self.cnt_off[key] = co
+                co += 1
+            elif "running_" in key:
+                self.buf_off[key] = (bo, tuple(shape))
+                bo += n
+            else:
+                self.param_off[key] = (po, tuple(shape))
+                po += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned inside the flat buffer
+        self.n_param, self.n_buf, self.n_cnt = po, bo, co
+
+
+@dataclass
+class _ConvPlans:
+    fwd: list  # [(IgemmPlan, wpack element offset)]
+    dgrad: list
+    wgrad: Optional[P.WgradPlan]
+
+
+class _Slot:
+    """A launch argument that is filled in at run time (dropout seed, external gradient pointers)."""
+
+    def __init__(self, kind, name=None):
+        self.kind, self.name = kind, name
+
+
+SEED = _Slot("seed")
+
+
+def _memset(buf, _stream):
+    buf.zero_()
+    return 0
+
+
+class Plan:
+    def __init__(self, eng: "Engine", n: int, dims: Tuple[int, int, int], train: bool):
+        self.eng, self.n, self.dims, self.train = eng, n, tuple(dims), train
+        self.lv = level_dims(dims, eng.hp)
+        self.fwd: List[list] = []
+        self.bwd: List[list] = []
+        self.keep: list = []  # ctypes objects that must outlive the launches
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.flat_ptr = eng.flat.data_ptr()
+        self._plan_layers()
+        self._lower()
+        self._index_slots()
+
+    # ------------------------------------------------------------------ helpers
+    def _alloc(self, spec: TensorSpec, store: Dict[str, torch.Tensor]) -> torch.Tensor:
+        root = spec.root
+        if root.name not in store:
+            dt = torch.float32 if root.kind == "f32" else self.eng.tdtype
+            store[root.name] = torch.zeros((self.n, *self.lv[root.level], root.c), dtype=dt, device=self.eng.device)
+        return store[root.name]
+
+    def _desc(self, spec: TensorSpec, store=None) -> L.Tensor:
+        buf = self._alloc(spec, self.bufs if store is None else store)
+        x, y, z = self.lv[spec.level]
+        return L.Tensor(buf.data_ptr() + spec.c0 * buf.element_size(), _tdtype(buf), spec.c, spec.root.c, self.n, x, y, z)
+
+    def _raw(self, name: str, level: int, c: int, dtype=None) -> torch.Tensor:
+        if name not in self.bufs:
+            self.bufs[name] = torch.zeros((self.n, *self.lv[level], c), dtype=dtype or self.eng.tdtype, device=self.eng.device)
+        return self.bufs[name]
+
+    def _tdesc(self, buf: torch.Tensor, level: int, c: Optional[int] = None) -> L.Tensor:
+        x, y, z = self.lv[level]
+        return L.Tensor(buf.data_ptr(), _tdtype(buf), c or buf.shape[-1], buf.shape[-1], self.n, x, y, z)
+
+    def _pp(self, key: str) -> int:  # device address of a parameter inside the flat fp32 buffer
+        return self.flat_ptr + 4 * self.eng.layout.param_off[key][0]
+
+    def _gp(self, key: str) -> int:  # ... of its gradient
+        return self.eng.gflat.data_ptr() + 4 * self.eng.layout.param_off[key][0]
+
+    def _bp(self, key: str) -> int:
+        return self.eng.bflat.data_ptr() + 4 * self.eng.layout.buf_off[key][0]
+
+    def _cp(self, key: str) -> int:
+        return self.eng.cflat.data_ptr() + 8 * self.eng.layout.cnt_off[key]
+
+    def _vox(self, level: int) -> int:
+        x, y, z = self.lv[level]
+        return self.n * x * y * z
+
+    # ------------------------------------------------------------------ conv planning + weight pack buffer
+    def _plan_layers(self):
+        eng = self.eng
+        maps: List[np.ndarray] = []
+        self._map_len = 0
+
+        def add_map(m: np.ndarray, param_off: int) -> int:
+            off = self._map_len
+            maps.append(np.where(m >= 0, m + param_off, -1).astype(np.int32))
+            self._map_len += m.size
+            return off
+
+        self.cplans: Dict[str, _ConvPlans] = {}
+        for op in eng.prog.ops:
+            if not isinstance(op, (ConvBnAct, ConvPlain)):
+                continue
+            Lr = op.layer
+            woff = eng.layout.param_off[Lr.wkey][0]
+            dims_in = self.lv[Lr.level]
+            kind = "convT_fwd" if Lr.transposed else "conv_fwd"
+            dims_out = P.out_dims(kind, dims_in, Lr.kernel, Lr.stride)
+            assert dims_out == self.lv[Lr.out_level]
+            fwd, dgrad, wg = [], [], None
+            for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
+                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c)
+                fwd.append((pl, add_map(pl.pack_map, woff)))
+            if self.train:
+                if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
+                    dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
+                    for cls in P.lattice_classes(dk, Lr.kernel, Lr.stride):
+                        q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
+                        pl = P.plan_igemm(dk, Lr.wshape, cls, q, eng.es, kc_pad=P.round_up(Lr.cout, 8))
+                        dgrad.append((pl, add_map(pl.pack_map, woff)))
+                wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
+            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg)
+        self.pack_map = torch.from_numpy(np.concatenate(maps)).to(eng.device)
+        self.wpack = torch.zeros(self._map_len, dtype=eng.tdtype, device=eng.device)
+
+    def _igemm(self, lst, pl: P.IgemmPlan, woff: int, inp: L.Tensor, out: L.Tensor, *, bias=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0):
+        d = L.IgemmDesc()
+        d.inp, d.out = inp, out
+        d.q, d.is_, d.os, d.oo = L.i3(pl.q), L.i3(pl.cls.is_), L.i3(pl.cls.os), L.i3(pl.cls.oo)
+        d.ntaps = pl.ntaps
+        for t, (off, _) in enumerate(pl.cls.taps):
+            d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
+        d.tile = L.i3(pl.tile)
+        d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps
+        d.wpack = self.wpack.data_ptr() + self.eng.es * woff
+        d.bias, d.scale, d.shift, d.alpha = bias or None, scale or None, shift or None, alpha or None
+        d.act, d.res_mode, d.accumulate = act, res_mode, accumulate
+        if res is not None:
+            d.res = res
+        d.stats, d.stats_stride = stats or None, stats_stride
+        self.keep.append(d)
+        lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)]])
+
+    # ------------------------------------------------------------------ lowering
+    def _lower(self):
+        eng, prog, lib, dev = self.eng, self.eng.prog, self.eng.lib, self.eng.device
+        ops = prog.ops
+        bn_layers = [op.layer for op in ops if isinstance(op, ConvBnAct)]
+        cpad = {Lr.prefix: P.round_up(Lr.cout, 16) for Lr in bn_layers}
+        tot_c = max(sum(cpad.values()), 1)
+        nsh = L.STAT_SHARDS
+        # fp64 sharded statistics: row 0 forward (sum, sumsq), row 1 backward (sum dz, sum dz*xhat) + PReLU-slope accumulators
+        self.stats = torch.zeros(2, nsh * 2 * tot_c + nsh * max(len(bn_layers), 1), dtype=torch.float64, device=dev)
+        self.vec = torch.zeros(6, tot_c, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift, mean_dz, mean_dzx
+        st_off, v_off, a_off = {}, {}, {}
+        o = v = 0
+        for i, Lr in enumerate(bn_layers):
+            st_off[Lr.prefix], v_off[Lr.prefix], a_off[Lr.prefix] = o, v, nsh * 2 * tot_c + nsh * i
+            o += nsh * 2 * cpad[Lr.prefix]
+            v += cpad[Lr.prefix]
+        row = self.stats.shape[1]
+        sptr = lambda which, pre: self.stats.data_ptr() + 8 * (which * row + st_off[pre])
+        aptr = lambda pre: self.stats.data_ptr() + 8 * (row + a_off[pre])
+        vptr = lambda r, pre: self.vec.data_ptr() + 4 * (r * tot_c + v_off[pre])
+        salt = {Lr.prefix: i + 1 for i, Lr in enumerate(bn_layers)}
+        p_drop = float(eng.dropout_p) if self.train else 0.0
+        self.bn_info = {Lr.prefix: (Lr, salt[Lr.prefix]) for Lr in bn_layers}
+
+        # ---- forward
+        F = self.fwd
+        grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
+        for op in ops:
+            if isinstance(op, ConvBnAct):
+                Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
+                xin, out = self._desc(op.x), self._desc(op.out)
+                res = self._desc(op.res) if op.res is not None else None
+                gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
+                rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
+                if self.train:
+                    yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
+                    for pl, woff in cp.fwd:
+                        self._igemm(F, pl, woff, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre])
+                    F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
+                                                      self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
+                    F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
+                else:
+                    F.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
+                    for pl, woff in cp.fwd:
+                        self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
+                                    res_mode=L.RES_ADD if res is not None else L.RES_NONE)
+            elif isinstance(op, ConvPlain):
+                Lr, cp = op.layer, self.cplans[op.layer.prefix]
+                xin, out = self._desc(op.x), self._desc(op.out)
+                res = self._desc(op.res) if op.res is not None else None
+                for pl, woff in cp.fwd:
+                    self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), act=ACT_CODE[op.act], res=res, res_mode=L.RES_ADD if res is not None else L.RES_NONE)
+            elif isinstance(op, AttGate):
+                F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
+            if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
+                grad_alias[op.res.name] = op.out
+        self.out_logits = self._alloc(prog.logits, self.bufs)
+        self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
+        if not self.train:
+            return
+
+        # ---- backward
+        B = self.bwd
+        written: Dict[str, bool] = {}
+        dlog8 = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
+        x0, y0, z0 = self.lv[0]
+        B.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0)]])
+
+        def gdesc(spec: TensorSpec) -> L.Tensor:
+            return self._desc(spec, self.grads)
+
+        def contribution(spec: TensorSpec) -> int:
+            """accumulate flag for adding a gradient contribution into g[spec] (first full-width contribution overwrites)."""
+            root = spec.root.name
+            if written.get(root):
+                return 1
+            written[root] = True
+            if spec.c != spec.root.c:  # first contribution covers only a channel slice: start from zero
+                B.append([_memset, [self._alloc(spec, self.grads)]])
+                return 1
+            return 0
+
+        def grad_of_out(t: TensorSpec) -> L.Tensor:
+            t = grad_alias.get(t.name, t)
+            if t.kind == "f32":  # logits: the loss' fp32 gradient staged in an 8-channel compute-dtype buffer
+                assert t.name == prog.logits.name
+                return self._tdesc(dlog8, 0)
+            assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
+            return gdesc(t)
+
+        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None):
+            cp = self.cplans[Lr.prefix]
+            wg = cp.wgrad
+            xin = self._desc(x)
+            d = L.WgradDesc()
+            if Lr.transposed:
+                d.p, d.h, d.cp_valid, d.ch_valid = xin, dy, Lr.cin, Lr.cout
+            else:
+                d.p, d.h, d.cp_valid, d.ch_valid = dy, xin, Lr.cout, Lr.cin
+            d.q, d.hs, d.ntaps = L.i3(wg.q), L.i3(wg.hs), len(wg.taps)
+            for t, (off, widx) in enumerate(wg.taps):
+                d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
+                d.tap_widx[t] = widx
+            d.tile, d.ntp = L.i3(wg.tile), wg.ntp
+            d.dw = self._gp(Lr.wkey)
+            d.stride_p, d.stride_h, d.stride_tap = wg.stride_p, wg.stride_h, wg.stride_tap
+            d.persistent_blocks = wg.blocks
+            self.keep.append(d)
+            B.append([lib.vsseg_wgrad, [C.byref(d)]])
+            if bias_grad:
+                B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
+            if cp.dgrad:
+                acc = contribution(x)
+                gx = gdesc(x)
+                for pl, woff in cp.dgrad:
+                    self._igemm(B, pl, woff, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE)
+
+        relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
+        for op in reversed(ops):
+            if isinstance(op, ConvBnAct):
+                Lr, pre = op.layer, op.layer.prefix
+                yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
+                dA = grad_of_out(op.out)
+                gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
+                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)]])
+                B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
+                                                          self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre)]])
+                dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
+                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd]])
+                if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
+                    if contribution(op.res):
+                        B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA]])
+                    else:
+                        B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)]])
+                conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
+            elif isinstance(op, ConvPlain):
+                Lr = op.layer
+                assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
+                dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
+                conv_backward(Lr, op.x, dy, bias_grad=True, relumask=relu_out.get(op.x.name))
+            elif isinstance(op, AttGate):
+                gout = grad_of_out(op.out)
+                acc = contribution(op.x)
+                dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level)]])
+
+    def _index_slots(self):
+        self.seed_slots, self.ext_slots = [], []
+        for lst in (self.fwd, self.bwd):
+            for rec in lst:
+                for i, a in enumerate(rec[1]):
+                    if a is SEED:
+                        self.seed_slots.append((rec[1], i))
+                    elif isinstance(a, _Slot):
+                        self.ext_slots.append((rec[1], i, a))
+
+    # ------------------------------------------------------------------ run
+    def set_seed(self, seed: int):
+        for args, i in self.seed_slots:
+            args[i] = seed
+
+    def set_external_grads(self, glogits: L.Tensor, gatt: Dict[str, Optional[int]]):
+        for args, i, slot in self.ext_slots:
+            args[i] = glogits if slot.kind == "glogits" else gatt.get(slot.name)
+
+    def pack_weights(self, stream):
+        L.check(self.eng.lib.vsseg_gather_cast(self.eng.flat.data_ptr(), self.pack_map.data_ptr(), self.wpack.data_ptr(), self.pack_map.numel(), L.BF16 if self.eng.es == 2 else L.F32, stream), "gather_cast")
+
+    def run(self, lst, stream):
+        for fn, args in lst:
+            rc = fn(*args, stream)
+            if rc:
+                L.check(rc, getattr(fn, "__name__", "launch"))
+
+    def memory_bytes(self) -> int:
+        tot = sum(t.numel() * t.element_size() for t in self.bufs.values()) + sum(t.numel() * t.element_size() for t in self.grads.values())
+        return tot + self.wpack.numel() * self.wpack.element_size() + self.pack_map.numel() * 4
+
+
+class Engine:
+    """Owns the per-signature plans over the model's flat parameter / gradient / buffer storage."""
+
+    def __init__(self, attention: bool, dtype: str, flat: torch.Tensor, gflat: torch.Tensor, bflat: torch.Tensor, cflat: torch.Tensor, layout: ParamLayout, hp=HP, dropout_p: Optional[float] = None, dry_run: bool = False):
+        self.lib = L.lib()
+        if not flat.is_cuda and not dry_run:  # dry_run: build plans on CPU to check the lowering (tests); nothing can be launched
+            raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
+        self.device = flat.device
+        self.attention, self.hp = attention, hp
+        self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
+        self.es = 2 if dtype == "bf16" else 4
+        self.flat, self.gflat, self.bflat, self.cflat, self.layout = flat, gflat, bflat, cflat, layout
+        self.prog: Program = build_program(attention, hp)
+        self.dropout_p = hp["dropout"] if dropout_p is None else dropout_p
+        self.plans: Dict[tuple, Plan] = {}
+
+    def plan(self, n, dims, train) -> Plan:
+        key = (int(n), tuple(int(d) for d in dims), bool(train))
+        pl = self.plans.get(key)
+        if pl is None:
+            for d, m in zip(key[1], self.min_multiple()):
+                if d % m:
+                    raise ValueError(f"spatial size {key[1]} must be a multiple of {self.min_multiple()} (product of the network strides)")
+            pl = Plan(self, *key)
+            self.plans[key] = pl
+        return pl
+
+    def min_multiple(self):
+        m = [1, 1, 1]
+        for s in self.hp["strides"]:
+            m = [a * b for a, b in zip(m, s)]
+        return tuple(m)

@@ -1,0 +1,47 @@
+"""Fused Adam over the model's flat parameter buffer: one HIP launch instead of 178 per-tensor updates.
+
+Semantics = torch.optim.Adam(params, lr, weight_decay) exactly as constructed at ref:params/VSparams.py:388-391 (coupled
+L2 decay, bias correction, eps outside the sqrt-of-v̂); `param_groups[i]["lr"]` stays mutable for the halving schedule
+(ref:params/VSparams.py:517-523) and `zero_grad()` / `step()` keep their meaning (ref :457, :462).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._owners = []
+        for group in self.param_groups:
+            owners = {id(getattr(p, "_vsseg_owner", None)): getattr(p, "_vsseg_owner", None) for p in group["params"]}
+            if None in owners.values() or len(owners) != 1:
+                raise ValueError("vs_seg_amd.optim.Adam updates the flat parameter buffer of one vs_seg_amd model per group; use torch.optim.Adam for other parameters")
+            owner = next(iter(owners.values()))
+            if len(group["params"]) != len(owner._params):
+                raise ValueError("pass model.parameters() (all of them) to vs_seg_amd.optim.Adam")
+            self._owners.append(owner)
+        self._state = [None] * len(self.param_groups)
+        self.grad_scale = 1.0  # multiplied into the gradient inside the kernel (data-parallel mean without an extra pass)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = L.lib()
+        stream = torch.cuda.current_stream().cuda_stream
+        for gi, (group, owner) in enumerate(zip(self.param_groups, self._owners)):
+            flat, gflat = owner.flat_parameters()
+            st = self._state[gi]
+            if st is None or st["m"].device != flat.device or st["flat_ptr"] != flat.data_ptr():
+                st = dict(m=torch.zeros_like(flat), v=torch.zeros_like(flat), step=0 if st is None else st["step"], flat_ptr=flat.data_ptr())
+                self._state[gi] = st
+            if all(p.grad is None for p in group["params"]):
+                continue
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            t = st["step"]
+            L.check(lib.vsseg_adam(flat.data_ptr(), gflat.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                   float(group["weight_decay"]), 1.0 - b1**t, 1.0 - b2**t, float(self.grad_scale), stream), "adam")
+        return loss

@@ -1,0 +1,314 @@
+"""Host-side planning for the implicit-GEMM kernels: lattice classes, tap tables, weight pack maps, tile/LDS choices.
+
+Pure numpy — no GPU needed — so every index rule is unit-tested on CPU (tests/test_planner.py) by running
+`simulate_igemm`, a literal restatement of the kernel's indexing, against the convolution definitions.
+
+Lattice form of every convolution-like op of the network (ref:params/networks/blocks/convolutions.py:114-146 and the
+autograd of those ops):
+
+    out[q*os + oo][n] = sum_t sum_c in[q*is + off_t][c] * W[t][c][n]
+
+  kind           in      out     classes   per-dim rule (k = kernel, s = stride, p = (k-1)//2)
+  conv_fwd       X       Y       1         os=1 oo=0 is=s, taps off=d-p                      (d = 0..k-1)
+  convT_dgrad    dY      dX      1         same as conv_fwd
+  convT_fwd      X       Y       prod(s)   os=s oo=par is=1, taps off=e with d=par+p-s*e in [0,k)
+  conv_dgrad     dY      dX      prod(s)   same as convT_fwd
+"""
+from __future__ import annotations
+
+import itertools
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+LDS_LIMIT = 160 * 1024
+
+
+@dataclass
+class LatticeClass:
+    os: Tuple[int, int, int]
+    oo: Tuple[int, int, int]
+    is_: Tuple[int, int, int]
+    taps: List[Tuple[Tuple[int, int, int], Tuple[int, int, int]]]  # (input offset, kernel index) per tap
+
+
+def same_pad(kernel):
+    return tuple((k - 1) // 2 for k in kernel)
+
+
+def lattice_classes(kind: str, kernel: Sequence[int], stride: Sequence[int]) -> List[LatticeClass]:
+    pad = same_pad(kernel)
+    per_dim = []
+    for k, s, p in zip(kernel, stride, pad):
+        opts = []
+        if kind in ("conv_fwd", "convT_dgrad"):
+            opts.append((1, 0, s, [(d - p, d) for d in range(k)]))
+        elif kind in ("convT_fwd", "conv_dgrad"):
+            for par in range(s):
+                taps = []
+                for e in range(-k, k + 1):
+                    d = par + p - s * e
+                    if 0 <= d < k:
+                        taps.append((e, d))
+                assert taps, "a parity class without taps would leave output voxels unwritten"
+                opts.append((s, par, 1, sorted(taps)))
+        else:
+            raise ValueError(kind)
+        per_dim.append(opts)
+    classes = []
+    for ox, oy, oz in itertools.product(*per_dim):
+        taps = [((a[0], b[0], c[0]), (a[1], b[1], c[1])) for a in ox[3] for b in oy[3] for c in oz[3]]
+        classes.append(LatticeClass((ox[0], oy[0], oz[0]), (ox[1], oy[1], oz[1]), (ox[2], oy[2], oz[2]), taps))
+    return classes
+
+
+def weight_flat_index(kind: str, wshape: Sequence[int], c: np.ndarray, n: np.ndarray, d: np.ndarray) -> np.ndarray:
+    """Flat index into the torch-layout weight for GEMM-K channel c, GEMM-N channel n, flat kernel index d."""
+    K = int(np.prod(wshape[2:]))
+    if kind == "conv_fwd":  # W[co=n][ci=c]
+        return (n * wshape[1] + c) * K + d
+    if kind == "convT_fwd":  # W[ci=c][co=n]
+        return (c * wshape[1] + n) * K + d
+    if kind == "conv_dgrad":  # K = co, N = ci: W[co=c][ci=n]
+        return (c * wshape[1] + n) * K + d
+    if kind == "convT_dgrad":  # K = co, N = ci: W[ci=n][co=c]
+        return (n * wshape[1] + c) * K + d
+    raise ValueError(kind)
+
+
+def gemm_dims(kind: str, wshape: Sequence[int]) -> Tuple[int, int]:
+    """(K channels, N channels) of the implicit GEMM."""
+    if kind == "conv_fwd":
+        return wshape[1], wshape[0]
+    if kind == "convT_fwd":
+        return wshape[0], wshape[1]
+    if kind == "conv_dgrad":
+        return wshape[0], wshape[1]
+    if kind == "convT_dgrad":
+        return wshape[1], wshape[0]
+    raise ValueError(kind)
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+@dataclass
+class IgemmPlan:
+    kind: str
+    cls: LatticeClass
+    q: Tuple[int, int, int]
+    kc: int  # padded K channels (multiple of 8) as laid out in the input tensor
+    nc: int  # true N channels
+    tile: Tuple[int, int, int]
+    mtw: int
+    nt: int
+    nsplit: int
+    ck: int
+    nchunks: int
+    ksteps: int
+    lds: int
+    pack_map: np.ndarray = field(repr=False, default=None)  # int32, -1 = zero
+
+    @property
+    def ntaps(self):
+        return len(self.cls.taps)
+
+
+def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es):
+    halo = 1
+    for a in range(3):
+        offs = [t[0][a] for t in taps]
+        halo *= (tile[a] - 1) * is_[a] + (max(offs) - min(offs) + 1)
+    return round_up(ksteps * 16, 16) + 64 * mtw * 4 + ksteps * nt * 64 * 8 * es + halo * ck * es
+
+
+def _pow2_floor(v):
+    p = 1
+    while p * 2 <= v:
+        p *= 2
+    return p
+
+
+def choose_tile(q, taps, voxels):
+    """Lattice tile with `voxels` points: keep the contiguous z run >= 4 and spend the rest where the halo is."""
+    ext = [max(t[0][a] for t in taps) - min(t[0][a] for t in taps) for a in range(3)]
+    cap = [max(1, _pow2_floor(max(1, v))) if v >= 1 else 1 for v in q]
+    cap = [c if c >= qq else c * 2 for c, qq in zip(cap, q)]  # allow one partial tile (next pow2 >= q)
+    tile = [1, 1, 1]
+    tile[2] = min(cap[2], 4 if ext[2] == 0 else 8, voxels)
+    rem = voxels // tile[2]
+    # distribute the remainder over x,y (then z) as evenly as possible
+    order = [1, 0, 2]
+    while rem > 1:
+        grew = False
+        for a in sorted(order, key=lambda a: tile[a] / (1 + ext[a])):
+            if tile[a] * 2 <= cap[a] and rem > 1:
+                tile[a] *= 2
+                rem //= 2
+                grew = True
+                break
+        if not grew:  # lattice smaller than the tile: pad the last axis that still fits nothing
+            tile[2] *= rem
+            rem = 1
+    return tuple(tile)
+
+
+def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=64 * 1024, mtw=None) -> IgemmPlan:
+    kreal, nreal = gemm_dims(kind, wshape)
+    kc = round_up(kreal, 8) if kc_pad is None else kc_pad
+    nt_total = (nreal + 15) // 16
+    nsplit = (nt_total + 5) // 6
+    nt = (nt_total + nsplit - 1) // nsplit
+    nvox = q[0] * q[1] * q[2]
+    if mtw is None:
+        mtw = 4 if nvox >= 2048 else (2 if nvox >= 512 else 1)
+        if nt >= 5 and mtw == 4:
+            mtw = 2
+    tile = choose_tile(q, cls.taps, 64 * mtw)
+    ntaps = len(cls.taps)
+    best = None
+    for ck in sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}, reverse=True):
+        ksteps = (ntaps * (ck // 8) + 3) // 4
+        lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw, es)
+        if lds <= lds_budget:
+            best = (ck, ksteps, lds)
+            break
+        if lds <= LDS_LIMIT - 1024 and best is None:
+            pass
+    if best is None:  # nothing fits the soft budget: take the largest chunk that fits the hard limit, preferring small
+        for ck in sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}):
+            ksteps = (ntaps * (ck // 8) + 3) // 4
+            lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw, es)
+            if lds <= LDS_LIMIT - 1024:
+                best = (ck, ksteps, lds)
+                break
+    if best is None:
+        raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} tile={tile}")
+    ck, ksteps, lds = best
+    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds)
+    plan.pack_map = pack_map(plan, wshape)
+    return plan
+
+
+def pack_map(plan: IgemmPlan, wshape) -> np.ndarray:
+    """int32 gather map [nsplit][nchunks][ksteps][nt][64][8] -> flat weight index (or -1)."""
+    kreal, nreal = gemm_dims(plan.kind, wshape)
+    kdims = wshape[2:]
+    cgs = plan.ck // 8
+    ntaps = plan.ntaps
+    S, CH, KS, NT = plan.nsplit, plan.nchunks, plan.ksteps, plan.nt
+    split, ch, ks, t, lane, j = np.meshgrid(np.arange(S), np.arange(CH), np.arange(KS), np.arange(NT), np.arange(64), np.arange(8), indexing="ij")
+    g = lane >> 4
+    p = ks * 4 + g
+    tap = p // cgs
+    cg = p % cgs
+    c = ch * plan.ck + cg * 8 + j
+    n = (split * NT + t) * 16 + (lane & 15)
+    valid = (p < ntaps * cgs) & (c < kreal) & (n < nreal)
+    tapc = np.clip(tap, 0, ntaps - 1)
+    widx = np.array([(w[0] * kdims[1] + w[1]) * kdims[2] + w[2] for _, w in plan.cls.taps], dtype=np.int64)
+    d = widx[tapc]
+    flat = weight_flat_index(plan.kind, wshape, np.where(valid, c, 0), np.where(valid, n, 0), d)
+    return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
+
+
+def out_dims(kind, in_dims, kernel, stride):
+    pad = same_pad(kernel)
+    if kind == "conv_fwd":
+        return tuple((d + 2 * p - k) // s + 1 for d, p, k, s in zip(in_dims, pad, kernel, stride))
+    if kind == "convT_fwd":  # output_padding = s + 2p - (k-1) - 1  ->  out = in * s   (ref:.../convolutions.py:117-123)
+        return tuple(d * s for d, s in zip(in_dims, stride))
+    raise ValueError(kind)
+
+
+def simulate_igemm(plan: IgemmPlan, x: np.ndarray, wflat: np.ndarray, out_shape) -> np.ndarray:
+    """Literal numpy restatement of igemm_kernel's indexing: x [N,X,Y,Z,kc] -> out [N,*out_shape,nc] (float64 accumulate)."""
+    N, X, Y, Z, C = x.shape
+    assert C == plan.kc
+    wpack = np.where(plan.pack_map >= 0, wflat[np.clip(plan.pack_map, 0, None)], 0.0).reshape(plan.nsplit, plan.nchunks, plan.ksteps, plan.nt, 64, 8)
+    cls = plan.cls
+    q = plan.q
+    cgs = plan.ck // 8
+    acc = np.zeros((N, *q, plan.nsplit * plan.nt * 16), np.float64)
+    qi = [np.arange(q[a]) for a in range(3)]
+    for ch in range(plan.nchunks):
+        for ks in range(plan.ksteps):
+            for g in range(4):
+                p = ks * 4 + g
+                if p >= plan.ntaps * cgs:
+                    continue
+                tap, cg = divmod(p, cgs)
+                off = cls.taps[tap][0]
+                idx = [qi[a] * cls.is_[a] + off[a] for a in range(3)]
+                ok = [(idx[a] >= 0) & (idx[a] < (X, Y, Z)[a]) for a in range(3)]
+                xs = x[:, np.clip(idx[0], 0, X - 1)][:, :, np.clip(idx[1], 0, Y - 1)][:, :, :, np.clip(idx[2], 0, Z - 1)][..., ch * plan.ck + cg * 8 : ch * plan.ck + cg * 8 + 8].astype(np.float64)
+                mask = ok[0][:, None, None] & ok[1][None, :, None] & ok[2][None, None, :]
+                xs = xs * mask[None, ..., None]
+                for split in range(plan.nsplit):
+                    for t in range(plan.nt):
+                        W = wpack[split, ch, ks, t, g * 16 : (g + 1) * 16, :].astype(np.float64)  # [n16][j]
+                        n0 = (split * plan.nt + t) * 16
+                        acc[..., n0 : n0 + 16] += np.einsum("nxyzj,cj->nxyzc", xs, W)
+    out = np.zeros((N, *out_shape, plan.nc), np.float64)
+    o = [qi[a] * cls.os[a] + cls.oo[a] for a in range(3)]
+    sel = [o[a] < out_shape[a] for a in range(3)]
+    out[np.ix_(np.arange(N), o[0][sel[0]], o[1][sel[1]], o[2][sel[2]], np.arange(plan.nc))] = acc[np.ix_(np.arange(N), qi[0][sel[0]], qi[1][sel[1]], qi[2][sel[2]], np.arange(plan.nc))]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# weight gradient
+# ---------------------------------------------------------------------------------------------------------------
+@dataclass
+class WgradPlan:
+    transposed: bool
+    q: Tuple[int, int, int]
+    hs: Tuple[int, int, int]
+    taps: List[Tuple[Tuple[int, int, int], int]]  # (halo offset, flat kernel index)
+    tile: Tuple[int, int, int]
+    ntp: int
+    cp_valid: int
+    ch_valid: int
+    stride_p: int
+    stride_h: int
+    stride_tap: int
+    lds: int
+    blocks: int
+
+
+def plan_wgrad(transposed: bool, wshape, kernel, stride, lattice_dims, es, cp_valid=None, ch_valid=None) -> WgradPlan:
+    """Conv3d: P = dY (co), H = X (ci), lattice = dY dims.  ConvTranspose3d: P = X (ci), H = dY (co), lattice = X dims."""
+    pad = same_pad(kernel)
+    K = int(np.prod(kernel))
+    taps = [((dx - pad[0], dy - pad[1], dz - pad[2]), (dx * kernel[1] + dy) * kernel[2] + dz) for dx in range(kernel[0]) for dy in range(kernel[1]) for dz in range(kernel[2])]
+    if not transposed:  # W[co][ci][K]
+        cp, chn = wshape[0], wshape[1]
+        stride_p, stride_h = wshape[1] * K, K
+    else:  # W[ci][co][K]
+        cp, chn = wshape[0], wshape[1]
+        stride_p, stride_h = wshape[1] * K, K
+    cp_valid = cp if cp_valid is None else cp_valid
+    ch_valid = chn if ch_valid is None else ch_valid
+    ntp = (cp_valid + 15) // 16
+    assert ntp <= 6, "P channels > 96 are not supported by the wgrad kernel"
+    q = tuple(lattice_dims)
+    nvox = q[0] * q[1] * q[2]
+    pseudo = [((t[0]), (0, 0, 0)) for t in taps]
+    for tv in (256, 128, 64, 32):
+        if tv > 32 and nvox < tv * 2:
+            continue
+        tile = choose_tile(q, pseudo, tv)
+        halo = 1
+        for a in range(3):
+            offs = [t[0][a] for t in taps]
+            halo *= (tile[a] - 1) * stride[a] + (max(offs) - min(offs) + 1)
+        lds = round_up(tv * 4, 16) + tv * ntp * 16 * es + halo * 16 * es
+        if lds <= LDS_LIMIT - 1024:
+            break
+    else:
+        raise ValueError("no LDS-feasible wgrad tile")
+    hchunks = (ch_valid + 15) // 16
+    blocks = max(1, min(1024 // hchunks, 512))
+    return WgradPlan(transposed, q, tuple(stride), taps, tile, ntp, cp_valid, ch_valid, stride_p, stride_h, 1, lds, blocks)
