@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE.json's metric on MI355X: training patches/s (fwd + Dice_spvPA + bwd + Adam) on synthetic
+384x128x128 bf16 patches, batch 4 per GPU, plus sliding-window volumes/s (512x512x120, roi 384x128x128, overlap 0.5).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task description): whole-job patches/s, the roofline of the dominant
+kernel (HIP-event timed inside the timed region) and, at N=1, the CPU baseline (oracle on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATCH = (384, 128, 128)
+HP = dict(channels=(16, 32, 48, 64, 80, 96), strides=((2, 2, 1), (2, 2, 1), (2, 2, 2), (2, 2, 2), (2, 2, 2)), kernel_sizes=((3, 3, 1), (3, 3, 1), (3, 3, 3), (3, 3, 3), (3, 3, 3), (3, 3, 3)),
+          sample_kernel_sizes=((3, 3, 1), (3, 3, 1), (3, 3, 3), (3, 3, 3), (3, 3, 3)))
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+FWD_BWD_GFLOP_PER_PATCH = 2053.9  # convolutions only, 2 FLOP/MAC
+
+
+def synth_batch(batch, patch, seed, device):
+    rng = np.random.default_rng(seed)
+    img = torch.from_numpy(rng.standard_normal((batch, 1, *patch), dtype=np.float32))
+    lab = np.zeros((batch, 1, *patch), np.float32)
+    for b in range(1, batch):  # sample 0 stays all-background; the others carry a small blob (tumour << 1 % of the voxels)
+        c = [int(rng.integers(s // 4, 3 * s // 4)) for s in patch]
+        r = [max(2, s // 12) for s in patch]
+        sl = tuple(slice(max(0, ci - ri), ci + ri) for ci, ri in zip(c, r))
+        gx, gy, gz = np.meshgrid(*[np.arange(s.start, s.stop) for s in sl], indexing="ij")
+        lab[b, 0][sl] = (((gx - c[0]) / r[0]) ** 2 + ((gy - c[1]) / r[1]) ** 2 + ((gz - c[2]) / r[2]) ** 2 <= 1.0).astype(np.float32)
+    return img.to(device), torch.from_numpy(lab).to(device)
+
+
+def build_model(dtype, device, attention=True):
+    import vs_seg_amd as V
+
+    torch.manual_seed(0)
+    m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, num_res_units=2, norm="batch", dropout=0.1, attention_module=attention, compute_dtype=dtype, **HP)
+    return m.to(device)
+
+
+def summarize_events(events):
+    torch.cuda.synchronize()
+    agg = {}
+    for name, meta, e0, e1 in events:
+        a = agg.setdefault(name, dict(ms=0.0, n=0, flops=0.0, bytes=0.0, kind=(meta or {}).get("kind", "hbm")))
+        a["ms"] += e0.elapsed_time(e1)
+        a["n"] += 1
+        if meta:
+            a["flops"] += meta.get("flops", 0.0)
+            a["bytes"] += meta.get("bytes", 0.0)
+    return agg
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle (CPU restatement, pinned to the reference's goldens) timed on the host cores: one fwd+loss+bwd+Adam step, batch 1."""
+    from oracle import vsseg_oracle as O
+
+    torch.set_num_threads(max(1, os.cpu_count() // 2 if (os.cpu_count() or 1) > 16 else (os.cpu_count() or 1)))
+    cores = torch.get_num_threads()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in O.seeded_state_dict(True, 0).items()}
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-7)
+
+    def step(shape):
+        rng = np.random.default_rng(0)
+        x = torch.from_numpy(rng.standard_normal((1, 1, *shape), dtype=np.float32))
+        y = torch.zeros(1, 1, *shape)
+        y[..., shape[0] // 3 : shape[0] // 2, shape[1] // 3 : shape[1] // 2, shape[2] // 3 : shape[2] // 2] = 1.0
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        logits, atts, _ = O.unet_forward(sd, x, train=True, attention_module=True, rng=torch.Generator().manual_seed(0))
+        loss = O.dice_spvpa(logits, atts, y)
+        loss.backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    step((64, 64, 32))  # warm the thread pool / allocator
+    t_small = step((128, 128, 32))
+    est_full = t_small * (PATCH[0] * PATCH[1] * PATCH[2]) / (128 * 128 * 32)
+    if est_full <= budget_s * 1.6:
+        shape = PATCH
+    elif est_full / 2 <= budget_s * 1.6:
+        shape = (PATCH[0] // 2, PATCH[1], PATCH[2])
+    else:
+        shape = (128, 128, 64)
+    t = step(shape)
+    frac = (shape[0] * shape[1] * shape[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
+    return dict(value=frac / t, unit="patches/s", cores=cores, kind="port",
+                sample=f"1 training step (fwd+Dice_spvPA+bwd+Adam, fp32, batch 1) of the oracle on a {shape[0]}x{shape[1]}x{shape[2]} patch = {frac:.3f} of a 384x128x128 patch in {t:.2f} s, scaled by voxels")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="patches per GPU (BASELINE config 2)")
+    ap.add_argument("--dtype", default=os.environ.get("VSSEG_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--swi-volumes", type=int, default=2, help="sliding-window volumes per GPU timed after the training steps (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print the per-kernel HIP-event breakdown of one step to stderr")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    import vs_seg_amd as V
+    from vs_seg_amd import parallel as DP
+
+    rank, world, local = DP.init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model = build_model(args.dtype, dev)
+    model.reuse_output_buffers = True
+    loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
+    opt = V.Adam(model.parameters(), lr=1e-4, weight_decay=1e-7)
+    trainer = DP.DataParallelTrainer(model.train(), loss_fn, opt)
+    img, lab = synth_batch(args.batch, PATCH, 1000 + rank, dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(1, args.warmup)):
+        trainer.step(img, lab)
+    plan = next(p for k, p in model._engine.plans.items() if k[2])
+    # one fully event-timed step: finds the dominant kernel (not part of the timed region)
+    plan.timer = dict(only=None, events=[])
+    trainer.step(img, lab)
+    full = summarize_events(plan.timer["events"])
+    dominant = max(full, key=lambda k: full[k]["ms"])
+    if args.profile and rank == 0:
+        tot = sum(a["ms"] for a in full.values())
+        print(f"--- per-kernel HIP-event time of one training step (sum {tot:.2f} ms) ---", file=sys.stderr)
+        for k, a in sorted(full.items(), key=lambda kv: -kv[1]["ms"]):
+            extra = f"{a['flops'] / a['ms'] / 1e9:9.1f} TFLOP/s" if a["flops"] else ""
+            extra += f" {a['bytes'] / a['ms'] / 1e6:9.1f} GB/s(alg)" if a["bytes"] else ""
+            print(f"{k:34s} n={a['n']:4d} {a['ms']:9.3f} ms {100 * a['ms'] / tot:5.1f}%  {extra}", file=sys.stderr)
+    plan.timer = dict(only={dominant}, events=[])
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(img, lab)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    dom = summarize_events(plan.timer["events"])[dominant]
+    plan.timer = None
+    loss_val = float(loss)
+    patches_per_s = args.steps * args.batch * world / dt
+
+    # ---- sliding-window inference (BASELINE configs 3/5): every rank blends its own volumes, no data-path collective
+    swi = None
+    if args.swi_volumes > 0:
+        model.eval()
+        vol = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal((1, 1, 512, 512, 120), dtype=np.float32)).to(dev)
+        pred = lambda w: model(w)[0]  # noqa: E731
+        with torch.no_grad():
+            V.sliding_window_inference(vol, PATCH, 1, pred, overlap=0.5, mode="gaussian")
+            barrier()
+            s0 = time.perf_counter()
+            for _ in range(args.swi_volumes):
+                out = V.sliding_window_inference(vol, PATCH, 1, pred, overlap=0.5, mode="gaussian")
+            barrier()
+            sdt = time.perf_counter() - s0
+        if world > 1:
+            t = torch.tensor([sdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sdt = float(t)
+        swi = dict(volumes_per_sec=args.swi_volumes * world / sdt, ms_per_volume=1e3 * sdt / args.swi_volumes, volume="512x512x120", roi="384x128x128", overlap=0.5, windows=14, sw_batch_size=1,
+                   mode="gaussian", sharding="volumes round-robin over ranks")
+        model.train()
+
+    if rank != 0:
+        return
+    peak = PEAK[args.dtype]
+    if dom["kind"] == "mfma" and dom["flops"] > 0:
+        ach = dom["flops"] / dom["ms"] / 1e9
+        roof = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None, launches=dom["n"], avg_launch_ms=dom["ms"] / dom["n"],
+                    alg_gflop_per_launch=dom["flops"] / dom["n"] / 1e9)
+    else:
+        ach = dom["bytes"] / dom["ms"] / 1e6
+        roof = dict(bound="hbm", kernel=dominant, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None, launches=dom["n"], avg_launch_ms=dom["ms"] / dom["n"])
+    tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            roof["traffic"] = json.load(open(tfile)).get(dominant)
+        except Exception:
+            pass
+    res = {
+        "metric": "train_patches_per_sec_fwd_bwd_384x128x128",
+        "value": patches_per_s,
+        "unit": "patches/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: 2.5D attention-UNet fwd + Dice_spvPA(attention+hardness) + bwd + Adam on random 384x128x128 patches, batch {args.batch} per GPU, dropout 0.1, random-init weights",
+                   "global_batch": args.batch * world, "patch": "384x128x128", "parallelism": f"dp{world}"},
+        "conv_stack_mfma_frac": FWD_BWD_GFLOP_PER_PATCH * patches_per_s / world / 1e3 / peak,
+        "loss": loss_val,
+        "roofline": roof,
+        "sliding_window": swi,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

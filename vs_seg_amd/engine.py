@@ -87,6 +87,7 @@ class Plan:
         self.bufs: Dict[str, torch.Tensor] = {}
         self.grads: Dict[str, torch.Tensor] = {}
         self.flat_ptr = eng.flat.data_ptr()
+        self.timer = None  # set to {'only': set|None, 'events': []} to time launches with HIP events
         self._plan_layers()
         self._lower()
         self._index_slots()
@@ -168,7 +169,7 @@ class Plan:
         self.wpack = torch.zeros(self._map_len, dtype=eng.tdtype, device=eng.device)
 
     def _igemm(self, lst, pl: P.IgemmPlan, woff: int, inp: L.Tensor, out: L.Tensor, *, bias=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
         d = L.IgemmDesc()
         d.inp, d.out = inp, out
         d.q, d.is_, d.os, d.oo = L.i3(pl.q), L.i3(pl.cls.is_), L.i3(pl.cls.os), L.i3(pl.cls.oo)
@@ -184,7 +185,13 @@ class Plan:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
         self.keep.append(d)
-        lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)]])
+        nvalid = self.n  # output voxels this lattice class writes
+        for a, oa in enumerate((out.x, out.y, out.z)):
+            nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
+        es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
+        meta = dict(name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+                    bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
+        lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
     # ------------------------------------------------------------------ lowering
     def _lower(self):
@@ -224,7 +231,7 @@ class Plan:
                 if self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
                     for pl, woff in cp.fwd:
-                        self._igemm(F, pl, woff, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre])
+                        self._igemm(F, pl, woff, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
@@ -232,7 +239,7 @@ class Plan:
                     F.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
                     for pl, woff in cp.fwd:
                         self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
-                                    res_mode=L.RES_ADD if res is not None else L.RES_NONE)
+                                    res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
                 xin, out = self._desc(op.x), self._desc(op.out)
@@ -295,14 +302,16 @@ class Plan:
             d.stride_p, d.stride_h, d.stride_tap = wg.stride_p, wg.stride_h, wg.stride_tap
             d.persistent_blocks = wg.blocks
             self.keep.append(d)
-            B.append([lib.vsseg_wgrad, [C.byref(d)]])
+            nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+                                                          bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad:
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
                 for pl, woff in cp.dgrad:
-                    self._igemm(B, pl, woff, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE)
+                    self._igemm(B, pl, woff, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         for op in reversed(ops):
@@ -356,10 +365,28 @@ class Plan:
         L.check(self.eng.lib.vsseg_gather_cast(self.eng.flat.data_ptr(), self.pack_map.data_ptr(), self.wpack.data_ptr(), self.pack_map.numel(), L.BF16 if self.eng.es == 2 else L.F32, stream), "gather_cast")
 
     def run(self, lst, stream):
-        for fn, args in lst:
-            rc = fn(*args, stream)
+        if self.timer is not None:
+            return self._run_timed(lst, stream)
+        for rec in lst:
+            rc = rec[0](*rec[1], stream)
             if rc:
-                L.check(rc, getattr(fn, "__name__", "launch"))
+                L.check(rc, getattr(rec[0], "__name__", "launch"))
+
+    def _run_timed(self, lst, stream):
+        """Per-launch HIP-event timing (events are recorded on the stream the kernels are launched on)."""
+        tm = self.timer
+        for rec in lst:
+            name = rec[2]["name"] if len(rec) > 2 else getattr(rec[0], "__name__", "memset")
+            if tm["only"] is not None and name not in tm["only"]:
+                rc = rec[0](*rec[1], stream)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = rec[0](*rec[1], stream)
+                e1.record()
+                tm["events"].append((name, rec[2] if len(rec) > 2 else None, e0, e1))
+            if rc:
+                L.check(rc, name)
 
     def memory_bytes(self) -> int:
         tot = sum(t.numel() * t.element_size() for t in self.bufs.values()) + sum(t.numel() * t.element_size() for t in self.grads.values())

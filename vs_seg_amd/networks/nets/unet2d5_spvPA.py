@@ -132,7 +132,12 @@ class UNet2d5_spvPA(nn.Module):
 
     def _ensure_flat(self):
         """(Re)establish the flat storage after `.to(device)` / `.cuda()` replaced the individual tensors."""
-        dev = next(iter(self._params.values())).device
+        first = next(self.parameters())
+        if first is not self._params[self._manifest[0][0]]:  # Module._apply may replace Parameter objects (e.g. cross-device .to())
+            self._params = dict(self.named_parameters())
+            for p in self._params.values():
+                p._vsseg_owner = self
+        dev = first.device
         ok = self._flat.device == dev
         if ok:
             base = self._flat.data_ptr()

@@ -1,0 +1,177 @@
+"""Single-node data parallelism over RCCL/xGMI: one process per GPU (`torch.distributed`, backend "nccl" == RCCL on ROCm).
+
+The reference is single-device (`"cuda:0"`, ref:params/VSparams.py:83); the semantics below are the build's:
+
+* training — pure data parallel.  Every rank steps on its own shard of the shuffled index list; ONE collective per step:
+  all-reduce(sum) of the flat 3.45 M-element fp32 gradient buffer (13.8 MB, a single bucket — xGMI links are
+  point-to-point, so one large transfer per step beats 178 per-tensor ones), folded into a mean by the fused Adam kernel
+  (`grad_scale = 1/world`).  BatchNorm uses per-rank batch statistics (PyTorch-DDP default); running statistics and
+  checkpoints come from rank 0.
+* inference — cases are sharded round-robin over ranks (`shard_indices`), Dice scalars all-gathered at the end; for a
+  single volume the windows are sharded (`sharded_sliding_window_inference`): window i -> rank i mod W, window logits
+  all-gathered, then every rank blends ALL windows in the reference's window order, which keeps the sequential fp32
+  accumulation bit-identical to the single-GPU result (an all-reduce of partial accumulators would not).
+
+All functions work with the gloo backend on CPU tensors too; that is how the world_size-2 tests run without GPUs.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+from .inferers import window_geometry
+
+
+def init_distributed(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*). Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
+def shard_indices(n: int, rank: int | None = None, world: int | None = None) -> List[int]:
+    """Round-robin shard of range(n): rank r owns r, r+W, r+2W, ..."""
+    rank = get_rank() if rank is None else rank
+    world = world_size() if world is None else world
+    return list(range(rank, n, world))
+
+
+def broadcast_parameters(flat: torch.Tensor, src: int = 0):
+    if world_size() > 1:
+        dist.broadcast(flat, src)
+
+
+def allreduce_gradients(gflat: torch.Tensor, async_op: bool = False):
+    """Sum the flat gradient buffer over ranks (single bucket).  The mean is applied by Adam's `grad_scale`."""
+    if world_size() > 1:
+        return dist.all_reduce(gflat, op=dist.ReduceOp.SUM, async_op=async_op)
+    return None
+
+
+def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
+    if world_size() > 1:
+        x = x.clone()
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        x /= world_size()
+    return x
+
+
+def all_gather_scalars(values: Sequence[float], total: int, device="cpu") -> List[float]:
+    """Each rank passes the scores of its `shard_indices(total)`; returns the `total` scores in case order on every rank."""
+    W, r = world_size(), get_rank()
+    if W == 1:
+        return list(values)
+    per = (total + W - 1) // W
+    buf = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
+    buf[: len(values)] = torch.tensor(list(values), dtype=torch.float64, device=device)
+    out = [torch.empty_like(buf) for _ in range(W)]
+    dist.all_gather(out, buf)
+    res = [float("nan")] * total
+    for rr in range(W):
+        for j, idx in enumerate(shard_indices(total, rr, W)):
+            res[idx] = float(out[rr][j])
+    return res
+
+
+def sharded_window_logits(inputs: torch.Tensor, roi_size, predictor: Callable, overlap: float, crop_fn: Callable) -> tuple:
+    """Runs this rank's windows (i mod W == rank) through `predictor` and all-gathers every window's logits.
+
+    Returns (windows [(b, start)], logits [n_windows, C, *roi] in reference window order).  `crop_fn(vol, [(b, start)], roi,
+    pad_before)` produces the window batch (HIP crop on GPU, a torch slice in the gloo tests).
+    """
+    W, r = world_size(), get_rank()
+    B = inputs.shape[0]
+    img = tuple(int(v) for v in inputs.shape[2:])
+    roi, padded, pad_before, _, starts = window_geometry(img, roi_size, overlap)
+    windows = [(b, s) for b in range(B) for s in starts]
+    mine = shard_indices(len(windows), r, W)
+    per = (len(windows) + W - 1) // W
+    local = None
+    for j, wi in enumerate(mine):
+        seg = predictor(crop_fn(inputs, [windows[wi]], roi, pad_before))
+        if local is None:
+            local = torch.zeros((per, *seg.shape[1:]), dtype=torch.float32, device=seg.device)
+        local[j] = seg[0]
+    if local is None:  # more ranks than windows: still take part in the collective
+        probe = predictor(crop_fn(inputs, [windows[0]], roi, pad_before))
+        local = torch.zeros((per, *probe.shape[1:]), dtype=torch.float32, device=probe.device)
+    local = local.contiguous()
+    if W == 1:
+        return windows, local[: len(windows)], (roi, padded, pad_before)
+    gathered = [torch.empty_like(local) for _ in range(W)]
+    dist.all_gather(gathered, local)
+    out = torch.empty((len(windows), *local.shape[1:]), dtype=torch.float32, device=local.device)
+    for rr in range(W):
+        idx = shard_indices(len(windows), rr, W)
+        if idx:
+            out[idx] = gathered[rr][: len(idx)]
+    return windows, out, (roi, padded, pad_before)
+
+
+def sharded_sliding_window_inference(inputs: torch.Tensor, roi_size, predictor: Callable, overlap: float = 0.25, mode: str = "constant") -> torch.Tensor:
+    """`sliding_window_inference` with the windows of each volume spread over the ranks (latency mode)."""
+    from . import _lib as L
+    from .inferers import _as_cl, crop_windows, importance_map
+
+    windows, logits, (roi, padded, pad_before) = sharded_window_logits(inputs, roi_size, predictor, overlap, crop_windows)
+    lib = L.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    B = inputs.shape[0]
+    img = tuple(int(v) for v in inputs.shape[2:])
+    seg = _as_cl(logits)
+    C = seg.shape[-1]
+    imap = importance_map(roi, mode, inputs.device)
+    out = torch.zeros((B, *padded, C), dtype=torch.float32, device=inputs.device)
+    cnt = torch.zeros((B, *padded), dtype=torch.float32, device=inputs.device)
+    per, pvox, ivox = roi[0] * roi[1] * roi[2], padded[0] * padded[1] * padded[2], img[0] * img[1] * img[2]
+    for i, (b, s) in enumerate(windows):  # reference window order on every rank
+        L.check(lib.vsseg_swi_accumulate(seg.data_ptr() + 4 * i * per * C, imap.data_ptr(), L.i3(roi), L.i3(s), C, out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr() + 4 * b * pvox, L.i3(padded), stream), "swi_accumulate")
+    final = torch.empty((B, *img, C), dtype=torch.float32, device=inputs.device)
+    for b in range(B):
+        L.check(lib.vsseg_swi_finalize(out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr() + 4 * b * pvox, L.i3(padded), L.i3(pad_before), L.i3(img), C, final.data_ptr() + 4 * b * ivox * C, stream), "swi_finalize")
+    return final.permute(0, 4, 1, 2, 3)
+
+
+class DataParallelTrainer:
+    """fwd + loss + bwd + gradient all-reduce + fused Adam for one rank (the train step of ref:params/VSparams.py:454-463 under DP)."""
+
+    def __init__(self, model, loss_fn, optimizer):
+        self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        self.world = world_size()
+        flat, _ = model.flat_parameters()
+        broadcast_parameters(flat, 0)
+        if hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0 / self.world
+
+    def step(self, inputs, labels):
+        self.opt.zero_grad()
+        outputs = self.model(inputs)
+        loss = self.loss_fn(outputs, labels)
+        loss.backward()
+        _, gflat = self.model.flat_parameters()
+        allreduce_gradients(gflat)
+        self.opt.step()
+        return loss

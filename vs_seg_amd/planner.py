@@ -101,6 +101,7 @@ class IgemmPlan:
     q: Tuple[int, int, int]
     kc: int  # padded K channels (multiple of 8) as laid out in the input tensor
     nc: int  # true N channels
+    kreal: int  # true K channels
     tile: Tuple[int, int, int]
     mtw: int
     nt: int
@@ -187,7 +188,7 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=6
     if best is None:
         raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} tile={tile}")
     ck, ksteps, lds = best
-    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds)
+    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds)
     plan.pack_map = pack_map(plan, wshape)
     return plan
 
