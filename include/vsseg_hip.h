@@ -119,13 +119,14 @@ int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, con
                      vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
 /* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, alpha_acc[shard] += dA*d(d<0). */
 int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                            const float* scale, const float* shift, /* the forward's folded affine: the PReLU/dropout branch is re-decided on the SAME fp32 value */
                             const float* alpha, float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream);
 /* finalize: dgamma, dbeta, dalpha (+= into flat grads) and the two per-channel means used by pass 2 */
 int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
                               float* mean_dz, float* mean_dzx, void* stream);
 /* pass 2: dy = gamma*invstd*(dz - mean_dz - xhat*mean_dzx) */
 int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream);
+                           const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream);
 /* debug/parity: write the keep-mask (0/1 as f32, [voxel][c]) the forward used */
 int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint64_t seed, uint32_t salt, void* stream);
 

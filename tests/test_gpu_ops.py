@@ -183,11 +183,11 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     ref.backward(H.from_cl(gcl).double())
     sums = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
     aacc = torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
-    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), S))
+    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), S))
     dg, db, da = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
     L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), S))
     dy = torch.zeros_like(ycl)
-    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), S))
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), S))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(dy).numpy(), yy.grad.float().numpy(), atol=_tol(dt, yy.grad))
     np.testing.assert_allclose(dg.cpu().numpy(), sd64["b.norm.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)

@@ -195,7 +195,7 @@ extern "C" int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_
 // backward of BN -> Dropout -> PReLU.  dz = d(loss)/d(BN output); pass 1 reduces, pass 2 applies.
 // ------------------------------------------------------------------------------------------------------------
 struct BnBwdArgs {
-  const float *mean, *invstd, *gamma, *beta, *alpha;
+  const float *mean, *invstd, *gamma, *beta, *scale, *shift, *alpha;
   float p_drop;
   uint64_t seed;
   uint32_t salt;
@@ -208,7 +208,7 @@ __device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     float xhat = (y.v[j] - a.mean[c + j]) * a.invstd[c + j];
-    float z = a.gamma[c + j] * xhat + a.beta[c + j];
+    float z = y.v[j] * a.scale[c + j] + a.shift[c + j];  // bit-identical to the forward's value: same side of the PReLU kink
     bool k = (keep >> j) & 1u;
     float d = k ? z * inv_keep : 0.f;
     float g = da.v[j];
@@ -246,13 +246,13 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const 
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&sums[(int64_t)shard * 2 * stride + (i / C) * stride + (i % C)], (double)red[i]);
   if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[2 * C]);
 }
-extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* alpha,
+extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream) {
   VSSEG_CHECK(y.ptr && dout.ptr && y.dtype == dout.dtype && y.c == dout.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && sums && alpha_acc && stride >= y.c, "vsseg_bn_act_bwd_reduce: bad arguments");
   int cgs = y.c / 8, blk = block_for_cgs(cgs);
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
   int64_t nv = tensor_voxels(y);
-  BnBwdArgs a{mean, invstd, gamma, beta, alpha, p_drop, seed, salt};
+  BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
   int grid = grid_for(nv * cgs, blk, 256 * 8);
   size_t lds = (2 * y.c + 1) * sizeof(float);
   DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
@@ -301,13 +301,13 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
     st8(dy + v * dyp + c, dz);
   }
 }
-extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* alpha,
+extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                       float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream) {
   VSSEG_CHECK(y.ptr && dout.ptr && dy.ptr && y.dtype == dout.dtype && y.dtype == dy.dtype && y.c == dout.c && y.c == dy.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && dy.pitch % 8 == 0,
               "vsseg_bn_act_bwd_apply: bad arguments");
   int cgs = y.c / 8;
   int64_t nv = tensor_voxels(y);
-  BnBwdArgs a{mean, invstd, gamma, beta, alpha, p_drop, seed, salt};
+  BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
   DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(nv * cgs, 256)), dim3(256), 0, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, mean_dz, mean_dzx, (T*)dy.ptr, dy.pitch, cgs, nv));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_apply");
   return VSSEG_OK;

@@ -320,11 +320,11 @@ class Plan:
                 yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
-                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)]])
+                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)]])
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre)]])
                 dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd]])
+                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd]])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
                     if contribution(op.res):
                         B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA]])
