@@ -90,6 +90,8 @@ typedef struct {
   int64_t stride_p, stride_h, stride_tap; /* element strides of dw along cP, cH, tap */
   int32_t cp_valid, ch_valid;
   int32_t persistent_blocks;
+  float* scratch;          /* partial-sum slabs: >= ceil(ch_valid/16) * ntaps * ntp*16 * 16 floats per workgroup */
+  int64_t scratch_elems;   /* capacity in floats; the number of persistent workgroups is clamped to what fits */
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);
@@ -117,13 +119,13 @@ int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, c
  * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables. */
 int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
                      vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
-/* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, alpha_acc[shard] += dA*d(d<0). */
+/* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, [2][c] += dout, alpha_acc[shard] += dA*d(d<0). */
 int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
                             const float* scale, const float* shift, /* the forward's folded affine: the PReLU/dropout branch is re-decided on the SAME fp32 value */
                             const float* alpha, float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream);
 /* finalize: dgamma, dbeta, dalpha (+= into flat grads) and the two per-channel means used by pass 2 */
 int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
-                              float* mean_dz, float* mean_dzx, void* stream);
+                              float* mean_dz, float* mean_dzx, float* dres_bias /* += sum(dout) or NULL */, void* stream);
 /* pass 2: dy = gamma*invstd*(dz - mean_dz - xhat*mean_dzx) */
 int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream);
@@ -133,7 +135,8 @@ int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint6
 /* AttentionBlock2: out = x * (1 + att)   (ref:params/networks/blocks/attentionblock.py:43-47); att is f32 [voxel]. */
 int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream);
 /* dx (+)= dout*(1+att);  dpre[voxel][0] = (sum_c dout*x + datt_ext) * att*(1-att)  (sigmoid backward), channels 1..7 zero. */
-int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, void* stream);
+int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre,
+                        float* dbias /* += sum(dpre): bias gradient of the sigmoid convolution, or NULL */, void* stream);
 
 /* generic helpers */
 int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);

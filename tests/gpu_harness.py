@@ -92,6 +92,8 @@ def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid
     d.dw = dw.data_ptr()
     d.stride_p, d.stride_h, d.stride_tap = wp.stride_p, wp.stride_h, wp.stride_tap
     d.persistent_blocks = wp.blocks
+    scr = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
     L.check(lib.vsseg_wgrad(C.byref(d), stream()), "wgrad")
     torch.cuda.synchronize()
     return dw.cpu().reshape(wshape)

@@ -181,11 +181,11 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     assert int(nb) == 1
     # backward
     ref.backward(H.from_cl(gcl).double())
-    sums = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
+    sums = torch.zeros(L.STAT_SHARDS, 3, c, dtype=torch.float64, device="cuda")
     aacc = torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
     L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), S))
-    dg, db, da = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
-    L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), S))
+    dg, db, da, drb = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(c, device="cuda")
+    L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), drb.data_ptr(), S))
     dy = torch.zeros_like(ycl)
     L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), S))
     torch.cuda.synchronize()
@@ -193,13 +193,15 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     np.testing.assert_allclose(dg.cpu().numpy(), sd64["b.norm.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(db.cpu().numpy(), sd64["b.norm.bias"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(da.cpu().numpy(), sd64["b.act.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(drb.cpu().numpy(), H.from_cl(gcl).double().sum((0, 2, 3, 4)).float().numpy(), rtol=1e-4, atol=1e-3)  # bias gradient of a residual conv
 
 
+@pytest.mark.parametrize("c", [32, 96, 160])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-def test_attention_gate_forward_backward(dt):
+def test_attention_gate_forward_backward(dt, c):
     lib = L.lib()
     torch.manual_seed(6)
-    c, dims, n = 32, (8, 8, 4), 2
+    dims, n = (8, 8, 4), 2
     x = _round(torch.randn(n, c, *dims), dt).double().requires_grad_(True)
     pre = torch.randn(n, 1, *dims, dtype=torch.float64, requires_grad=True)
     att = torch.sigmoid(pre)
@@ -215,12 +217,14 @@ def test_attention_gate_forward_backward(dt):
     dx = torch.zeros_like(xcl)
     dpre = torch.zeros(n, *dims, 8, dtype=H.DT[dt], device="cuda")
     ge = gatt_ext.reshape(n, *dims).contiguous().cuda()
-    L.check(lib.vsseg_att_apply_bwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(gcl), ge.data_ptr(), H.tdesc(dx), 0, H.tdesc(dpre), S))
+    dbias = torch.zeros(1, device="cuda")
+    L.check(lib.vsseg_att_apply_bwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(gcl), ge.data_ptr(), H.tdesc(dx), 0, H.tdesc(dpre), dbias.data_ptr(), S))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(o).numpy(), out.detach().float().numpy(), atol=_tol(dt, out))
     np.testing.assert_allclose(H.from_cl(dx).numpy(), x.grad.float().numpy(), atol=_tol(dt, x.grad))
     np.testing.assert_allclose(H.from_cl(dpre, 1).numpy(), pre.grad.float().numpy(), atol=_tol(dt, pre.grad))
     assert float(dpre[..., 1:].float().abs().max()) == 0.0
+    assert abs(float(dbias) - float(pre.grad.sum())) < 2e-2 * float(pre.grad.abs().sum()) ** 0.5 + 1e-3
 
 
 @pytest.mark.parametrize("att", [True, False])

@@ -1,0 +1,53 @@
+"""Turn rocprofv3 rocpd (.db) outputs into the small text summaries committed under profiles/.
+
+    python tools/rocprof_summary.py kernel <results.db>            -> per-kernel calls / total / average / share
+    python tools/rocprof_summary.py pmc <fetch.db> <write.db>      -> per-kernel HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
+
+FETCH_SIZE is doubled as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950 wide coalesced reads
+(the counter tallies 128-byte requests as 64 bytes); WRITE_SIZE is reported as is (uncalibrated there).  Both are in KiB.
+"""
+import glob
+import json
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.replace("unsigned short", "bf16").replace("void ", "")
+    return name.split("(")[0]
+
+
+def kernel_stats(db):
+    cur = sqlite3.connect(db).cursor()
+    rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc"))
+    print(f"{'kernel':60s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
+    for n, c, t, a, p in rows:
+        print(f"{short(n)[:60]:60s} {c:7d} {t:12.1f} {a:10.2f} {p:6.2f}")
+
+
+def pmc(fetch_db, write_db):
+    out = {}
+    for label, db in (("fetch", fetch_db), ("write", write_db)):
+        cur = sqlite3.connect(db).cursor()
+        q = "select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name"
+        for n, c, v in cur.execute(q, ("FETCH_SIZE" if label == "fetch" else "WRITE_SIZE",)):
+            d = out.setdefault(short(n), {})
+            d[label + "_kib_per_launch"] = v / c
+            d["launches"] = c
+    print(f"{'kernel':60s} {'launches':>8s} {'fetch MB/launch (x2 corrected)':>32s} {'write MB/launch':>16s}")
+    res = {}
+    for n, d in sorted(out.items(), key=lambda kv: -(kv[1].get("fetch_kib_per_launch", 0) * kv[1].get("launches", 0))):
+        f = 2.0 * d.get("fetch_kib_per_launch", 0.0) * 1024 / 1e6
+        w = d.get("write_kib_per_launch", 0.0) * 1024 / 1e6
+        print(f"{n[:60]:60s} {d.get('launches', 0):8d} {f:32.2f} {w:16.2f}")
+        res[n] = dict(fetch_mb=f, write_mb=w, launches=d.get("launches", 0))
+    return res
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "kernel":
+        kernel_stats(sys.argv[2])
+    else:
+        r = pmc(sys.argv[2], sys.argv[3])
+        if len(sys.argv) > 4:
+            json.dump(r, open(sys.argv[4], "w"), indent=1)

@@ -70,6 +70,8 @@ class WgradDesc(C.Structure):
         ("cp_valid", C.c_int32),
         ("ch_valid", C.c_int32),
         ("persistent_blocks", C.c_int32),
+        ("scratch", C.c_void_p),
+        ("scratch_elems", C.c_int64),
     ]
 
 
@@ -108,11 +110,11 @@ def lib():
         L.vsseg_bn_fold_eval.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
         L.vsseg_bn_act_fwd.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, Tensor, i32, Tensor, vp]
         L.vsseg_bn_act_bwd_reduce.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, i32, vp, vp]
-        L.vsseg_bn_act_bwd_finalize.argtypes = [vp, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp]
+        L.vsseg_bn_act_bwd_finalize.argtypes = [vp, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp, vp]
         L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp]
         L.vsseg_dropout_mask.argtypes = [vp, i64, i32, f32, u64, u32, vp]
         L.vsseg_att_apply_fwd.argtypes = [Tensor, vp, Tensor, vp]
-        L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp]
+        L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp, vp]
         L.vsseg_channel_sum.argtypes = [Tensor, vp, vp]
         L.vsseg_add_inplace.argtypes = [Tensor, Tensor, vp]
         L.vsseg_copy_cast.argtypes = [Tensor, Tensor, vp]

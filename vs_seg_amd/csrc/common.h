@@ -30,11 +30,14 @@ extern "C" void vsseg_set_error(const char* fmt, ...);
   } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even (NaN not expected on this path)
-  unsigned u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef __bf16 hbf16x2 __attribute__((ext_vector_type(2)));
+typedef float hf32x2 __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned f2bf2(float lo, float hi) {
+  hbf16x2 h = __builtin_convertvector(hf32x2{lo, hi}, hbf16x2);
+  return __builtin_bit_cast(unsigned, h);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(f2bf2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -55,8 +58,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   uint2 u;
-  u.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-  u.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+  u.x = f2bf2(v.x, v.y);
+  u.y = f2bf2(v.z, v.w);
   *reinterpret_cast<uint2*>(p) = u;
 }
 // 8 consecutive channels
@@ -76,10 +79,10 @@ __device__ __forceinline__ void st8(float* p, const f8& a) {
 }
 __device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
   uint4 u;
-  u.x = (unsigned)f2bf(a.v[0]) | ((unsigned)f2bf(a.v[1]) << 16);
-  u.y = (unsigned)f2bf(a.v[2]) | ((unsigned)f2bf(a.v[3]) << 16);
-  u.z = (unsigned)f2bf(a.v[4]) | ((unsigned)f2bf(a.v[5]) << 16);
-  u.w = (unsigned)f2bf(a.v[6]) | ((unsigned)f2bf(a.v[7]) << 16);
+  u.x = f2bf2(a.v[0], a.v[1]);
+  u.y = f2bf2(a.v[2], a.v[3]);
+  u.z = f2bf2(a.v[4], a.v[5]);
+  u.w = f2bf2(a.v[6], a.v[7]);
   *reinterpret_cast<uint4*>(p) = u;
 }
 
@@ -96,14 +99,16 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
   }
   return ctr;
 }
-// keep-mask for the 8 elements [8*i8, 8*i8+8) of a layer's activation tensor (logical [voxel][c] order, pitch-free)
+// keep-mask for the 8 elements [8*i8, 8*i8+8) of a layer's activation tensor (logical [voxel][c] order, pitch-free):
+// one Philox call = 128 random bits = eight 16-bit draws, keep iff draw >= round(p * 2^16)
 __device__ __forceinline__ unsigned dropout_keep8(uint64_t seed, uint32_t salt, uint64_t i8, float p) {
-  uint4 r0 = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-  uint4 r1 = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 1u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-  unsigned thr = (unsigned)(p * 4294967296.0f);  // keep iff r >= thr  (P[keep] = 1-p)
+  uint4 r = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+  const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
   unsigned m = 0;
-  m |= (r0.x >= thr) << 0; m |= (r0.y >= thr) << 1; m |= (r0.z >= thr) << 2; m |= (r0.w >= thr) << 3;
-  m |= (r1.x >= thr) << 4; m |= (r1.y >= thr) << 5; m |= (r1.z >= thr) << 6; m |= (r1.w >= thr) << 7;
+  m |= ((r.x & 0xffffu) >= thr) << 0; m |= ((r.x >> 16) >= thr) << 1;
+  m |= ((r.y & 0xffffu) >= thr) << 2; m |= ((r.y >> 16) >= thr) << 3;
+  m |= ((r.z & 0xffffu) >= thr) << 4; m |= ((r.z >> 16) >= thr) << 5;
+  m |= ((r.w & 0xffffu) >= thr) << 6; m |= ((r.w >> 16) >= thr) << 7;
   return m;
 }
 

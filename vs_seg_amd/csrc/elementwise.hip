@@ -222,29 +222,29 @@ __device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, 
 
 template <typename T>
 __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc) {
-  extern __shared__ float red[];  // [2][c] + [1]
+  extern __shared__ float red[];  // [3][c] + [1]
   const int C = cgs * 8;
-  for (int i = threadIdx.x; i < 2 * C + 1; i += blockDim.x) red[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * C + 1; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const float alpha = *a.alpha;
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs);
   const int c = cg * 8;
-  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
+  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
   for (int64_t v = gt / cgs; v < nvox; v += nthreads / cgs) {
     f8 yy = ld8(y + v * yp + c), da = ld8(dout + v * dp + c), dz, xh;
     dal += bn_bwd_elem8(yy, da, c, v * cgs + cg, a, alpha, dz, xh);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] += dz.v[j]; s2[j] += dz.v[j] * xh.v[j]; }
+    for (int j = 0; j < 8; ++j) { s1[j] += dz.v[j]; s2[j] += dz.v[j] * xh.v[j]; s3[j] += da.v[j]; }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); }
+  for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&red[2 * C], dal);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&red[3 * C], dal);
   __syncthreads();
   const int shard = blockIdx.x % VSSEG_STAT_SHARDS;
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&sums[(int64_t)shard * 2 * stride + (i / C) * stride + (i % C)], (double)red[i]);
-  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[2 * C]);
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) atomicAdd(&sums[(int64_t)shard * 3 * stride + (i / C) * stride + (i % C)], (double)red[i]);
+  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[3 * C]);
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream) {
@@ -254,13 +254,13 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   int64_t nv = tensor_voxels(y);
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
   int grid = grid_for(nv * cgs, blk, 256 * 8);
-  size_t lds = (2 * y.c + 1) * sizeof(float);
+  size_t lds = (3 * y.c + 1) * sizeof(float);
   DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }
 
-__global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int stride, const double* __restrict__ alpha_acc, int c, double count, float* dgamma, float* dbeta, float* dalpha, float* mean_dz, float* mean_dzx) {
+__global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int stride, const double* __restrict__ alpha_acc, int c, double count, float* dgamma, float* dbeta, float* dalpha, float* mean_dz, float* mean_dzx, float* dres_bias) {
   int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch == 0) {
     double a = 0;
@@ -268,20 +268,22 @@ __global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int 
     *dalpha += (float)a;
   }
   if (ch >= c) return;
-  double s = 0, q = 0;
+  double s = 0, q = 0, r = 0;
   for (int sh = 0; sh < VSSEG_STAT_SHARDS; ++sh) {
-    s += sums[(int64_t)sh * 2 * stride + ch];
-    q += sums[(int64_t)sh * 2 * stride + stride + ch];
+    s += sums[(int64_t)sh * 3 * stride + ch];
+    q += sums[(int64_t)sh * 3 * stride + stride + ch];
+    r += sums[(int64_t)sh * 3 * stride + 2 * stride + ch];
   }
+  if (dres_bias) dres_bias[ch] += (float)r;  // d(out)/d(residual) = 1: the residual convolution's bias gradient is sum(dout)
   dbeta[ch] += (float)s;
   dgamma[ch] += (float)q;
   mean_dz[ch] = (float)(s / count);
   mean_dzx[ch] = (float)(q / count);
 }
 extern "C" int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
-                                         float* mean_dz, float* mean_dzx, void* stream) {
+                                         float* mean_dz, float* mean_dzx, float* dres_bias, void* stream) {
   VSSEG_CHECK(sums && alpha_acc && dgamma && dbeta && dalpha && mean_dz && mean_dzx && c > 0, "vsseg_bn_act_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx);
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx, dres_bias);
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_finalize");
   return VSSEG_OK;
 }
@@ -338,65 +340,106 @@ extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tenso
   return VSSEG_OK;
 }
 
-// one thread per voxel: dx = dout*(1+att) (optionally += ), dpre = (sum_c dout*x + datt_ext)*att*(1-att) in channel 0 of an 8-wide row
-template <typename T, bool ACC>
+// G lanes per voxel (G = next power of two >= channel groups): dx = dout*(1+att) (optionally +=),
+// dpre = (sum_c dout*x + datt_ext) * att*(1-att) in channel 0 of an 8-wide row; sum(dpre) -> bias gradient of attention conv2
+template <typename T, bool ACC, int G>
 __global__ void att_apply_bwd_kernel(const T* __restrict__ x, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
-                                     T* __restrict__ dx, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox) {
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-    const float a = att[v], g = 1.f + a;
-    float dot = 0.f;
-    for (int cg = 0; cg < cgs; ++cg) {
-      f8 xx = ld8(x + v * xp + cg * 8), d = ld8(dout + v * dp + cg * 8);
-      f8 o;
-      if (ACC) o = ld8(dx + v * dxp + cg * 8);
+                                     T* __restrict__ dx, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias) {
+  const int sub = threadIdx.x % G;
+  const int64_t vstep = (int64_t)gridDim.x * (blockDim.x / G);
+  float bsum = 0.f;
+  for (int64_t v0 = blockIdx.x * (int64_t)(blockDim.x / G); v0 < nvox; v0 += vstep) {  // all lanes iterate together (shuffles need full groups)
+    const int64_t v = v0 + threadIdx.x / G;
+    const bool live = v < nvox;
+    float dot = 0.f, a = 0.f;
+    if (live) {
+      a = att[v];
+      if (sub < cgs) {
+        const float g = 1.f + a;
+        f8 xx = ld8(x + v * xp + sub * 8), d = ld8(dout + v * dp + sub * 8), o;
+        if (ACC) o = ld8(dx + v * dxp + sub * 8);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        dot += d.v[j] * xx.v[j];
-        o.v[j] = ACC ? o.v[j] + d.v[j] * g : d.v[j] * g;
+        for (int j = 0; j < 8; ++j) {
+          dot += d.v[j] * xx.v[j];
+          o.v[j] = ACC ? o.v[j] + d.v[j] * g : d.v[j] * g;
+        }
+        st8(dx + v * dxp + sub * 8, o);
       }
-      st8(dx + v * dxp + cg * 8, o);
     }
-    if (datt_ext) dot += datt_ext[v];
-    f8 r{{dot * a * (1.f - a), 0, 0, 0, 0, 0, 0, 0}};
-    st8(dpre + v * dprep, r);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    if (live && sub == 0) {
+      if (datt_ext) dot += datt_ext[v];
+      const float r = dot * a * (1.f - a);
+      st8(dpre + v * dprep, f8{{r, 0, 0, 0, 0, 0, 0, 0}});
+      bsum += r;
+    }
+  }
+  if (dbias) {
+    bsum = wave_sum(bsum);
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = bsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += part[w];
+      atomicAdd(dbias, t);
+    }
   }
 }
-extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, void* stream) {
+template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, const T* x, int xp, const float* att, const T* dout, int dp, const float* de, T* dx, int dxp, T* dpre, int dprep, int cgs, int64_t nv, float* dbias) {
+  switch (G) {
+    case 1: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 1>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    case 2: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 2>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    case 4: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 4>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    case 8: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 8>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    case 16: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 16>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    default: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 32>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+  }
+}
+extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, float* dbias, void* stream) {
   VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && dpre.ptr && x.dtype == dout.dtype && x.dtype == dx.dtype && x.dtype == dpre.dtype && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 && dpre.c == 8 &&
-                  x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && dpre.pitch % 8 == 0,
+                  x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && dpre.pitch % 8 == 0 && x.c <= 256,
               "vsseg_att_apply_bwd: bad arguments");
   int cgs = x.c / 8;
+  int G = 1;
+  while (G < cgs) G *= 2;
   int64_t nv = tensor_voxels(x);
-  dim3 g(grid_for(nv, 256)), b(256);
-  DISPATCH_T(x.dtype, if (accumulate_dx) hipLaunchKernelGGL((att_apply_bwd_kernel<T, true>), g, b, 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv);
-             else hipLaunchKernelGGL((att_apply_bwd_kernel<T, false>), g, b, 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv));
+  dim3 g(grid_for(nv * G, 256)), b(256);
+  hipStream_t s = as_stream(stream);
+  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias);
+             else att_bwd_launch<T, false>(G, g, b, s, (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias));
   VSSEG_LAUNCH_CHECK("vsseg_att_apply_bwd");
   return VSSEG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// per-channel sum (bias gradients of convolutions that are not followed by BatchNorm)
+// per-channel sum (bias gradients of convolutions that are not followed by BatchNorm): 8 channels per thread
 // ------------------------------------------------------------------------------------------------------------
-template <typename T> __global__ void channel_sum_kernel(const T* __restrict__ t, int pitch, int c, int64_t nvox, float* __restrict__ out) {
+template <typename T> __global__ void channel_sum_kernel(const T* __restrict__ t, int pitch, int c, int cgs, int64_t nvox, float* __restrict__ out) {
   extern __shared__ float red[];
-  for (int i = threadIdx.x; i < c; i += blockDim.x) red[i] = 0.f;
+  for (int i = threadIdx.x; i < cgs * 8; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
-  // thread keeps channel ch = gt % cpad fixed (cpad = c rounded to a divisor-friendly size handled by the host: blockDim % c == 0)
-  const int ch = (int)(gt % c);
-  float s = 0.f;
-  for (int64_t v = gt / c; v < nvox; v += nthreads / c) s += Elem<T>::ld(t + v * pitch + ch);
-  atomicAdd(&red[ch], s);
+  const int cg = (int)(gt % cgs);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t v = gt / cgs; v < nvox; v += nthreads / cgs) {
+    f8 a = ld8(t + v * pitch + cg * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += a.v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) atomicAdd(&red[cg * 8 + j], s[j]);
   __syncthreads();
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(&out[i], red[i]);
 }
 extern "C" int vsseg_channel_sum(vsseg_tensor t, float* out, void* stream) {
-  VSSEG_CHECK(t.ptr && out && t.c >= 1 && t.c <= 256, "vsseg_channel_sum: bad arguments");
-  int blk = t.c;
-  while (blk < 256) blk += t.c;  // multiple of c so that a thread's channel is loop-invariant
+  VSSEG_CHECK(t.ptr && out && t.c >= 1 && t.c <= 256 && t.pitch % 8 == 0 && (t.c + 7) / 8 * 8 <= t.pitch, "vsseg_channel_sum: bad arguments (the row must hold the channels rounded up to 8)");
+  int cgs = (t.c + 7) / 8, blk = block_for_cgs(cgs);
+  VSSEG_CHECK(blk > 0, "vsseg_channel_sum: unsupported channel count");
   int64_t nv = tensor_voxels(t);
-  int grid = grid_for(nv * t.c, blk, 1024);
-  DISPATCH_T(t.dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, dim3(grid), dim3(blk), t.c * sizeof(float), as_stream(stream), (const T*)t.ptr, t.pitch, t.c, nv, out));
+  int grid = grid_for(nv * cgs, blk, 2048);
+  DISPATCH_T(t.dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, dim3(grid), dim3(blk), cgs * 8 * sizeof(float), as_stream(stream), (const T*)t.ptr, t.pitch, t.c, cgs, nv, out));
   VSSEG_LAUNCH_CHECK("vsseg_channel_sum");
   return VSSEG_OK;
 }

@@ -11,17 +11,33 @@
 //   * K        <- (tap, input channel).  K is cut in groups of 8 channels; lane-group g = lane>>4 of a K-step owns
 //     group ks*4+g, i.e. one 16-byte (bf16) / 32-byte (f32) LDS read per lane per K-step.  bf16: one
 //     v_mfma_f32_16x16x32_bf16 per (voxel tile, channel tile); f32: eight v_mfma_f32_16x16x4_f32 (exact fp32).
-//   * the workgroup's input halo tile [hx][hy][hz][ck] and the chunk's packed weights are staged in LDS once per
-//     channel chunk; the 9/27 tap re-reads hit LDS, not L2/HBM.
+//
+// Structure: persistent workgroups walk (tile, channel-chunk) stages.  The input halo tile [hx][hy][hz][ck] of stage s+1
+// is fetched by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) into the second LDS buffer while stage s is
+// multiplied and stored, so every CU always has a whole tile of HBM reads in flight — most layers of this network are
+// HBM-bound, and a load->barrier->compute->store workgroup measured only ~1.6 TB/s.  Tiles are assigned
+// so that each XCD walks one contiguous eighth of the lattice (neighbouring tiles share halo rows through that XCD's L2).
+// Packed weights stay resident in LDS for single-chunk layers; per-channel epilogue constants live in LDS, so the hot
+// loop issues no ordinary global load that would make hipcc drain the DMA queue (cdna_hip_programming.md §5).
 #include "common.h"
+
+constexpr int PMAX = 8;  // 16-byte halo pieces per thread per stage (halo chunk <= 32 KiB)
+constexpr int AMAX = 8;  // 16-byte pieces per thread of the auxiliary (residual / accumulate) output tile
 
 struct IgemmK {
   vsseg_igemm_desc d;
   int halo[3];
   int off_min[3];
   int ntile[3];
-  int cgs;  // 8-channel groups per chunk
-  int lds_ktab, lds_vbase, lds_b, lds_halo;  // byte offsets
+  int cgs;      // 8-channel groups per chunk
+  int w_bytes;  // packed weights per chunk
+  int h_bytes;  // halo chunk
+  int lds_ktab, lds_epi, lds_w, lds_h, lds_aux;
+  int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask: the aux tile is prefetched by DMA like the halo
+  int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (0: aux handled by the slow path)
+  vsseg_tensor aux;
+  int64_t total_tiles;
+  const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
 };
 
 template <typename T> struct Frag;
@@ -50,30 +66,37 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.w, a.hi.w, acc, 0, 0, 0);
 }
 
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+// 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_wave_base, 16, 0, 0);
+}
+
 template <typename T, int NT, int MTW>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
-  constexpr int GB = 8 * ES;  // bytes of one 8-channel group
+  constexpr int GB = 8 * ES;   // bytes of one 8-channel group
+  constexpr int EPP = 16 / ES; // elements per 16-byte piece
   const vsseg_igemm_desc& d = k.d;
   int* ktab = reinterpret_cast<int*>(smem + k.lds_ktab);
-  int* vbase = reinterpret_cast<int*>(smem + k.lds_vbase);
-  char* Bl = smem + k.lds_b;
-  char* Hl = smem + k.lds_halo;
+  float* epi = reinterpret_cast<float*>(smem + k.lds_epi);  // bias | scale | shift, NT*16 each
+  char* Wl = smem + k.lds_w;
+  char* Hl = smem + k.lds_h;
+  char* Al = smem + k.lds_aux;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
-  // ---- decode workgroup -> (batch n, tile origin q0) ----
-  int b = blockIdx.x;
-  const int tz = b % k.ntile[2]; b /= k.ntile[2];
-  const int ty = b % k.ntile[1]; b /= k.ntile[1];
-  const int tx = b % k.ntile[0];
-  const int n = b / k.ntile[0];
-  const int q0[3] = {tx * d.tile[0], ty * d.tile[1], tz * d.tile[2]};
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int split = blockIdx.y;
   const int HY = k.halo[1], HZ = k.halo[2], CK = d.ck;
   const int hvox = k.halo[0] * HY * HZ;
+  const int ppv = CK / EPP;  // 16-byte pieces per halo voxel
+  const int pieces = hvox * ppv;
+  const int wpieces = k.w_bytes >> 4;
+  const int cout = d.out.c;
+  const int nch = d.nchunks;
 
-  // ---- per-workgroup lookup tables ----
+  // ---- per-workgroup tables ----
   for (int i = tid; i < d.ksteps * 4; i += 256) {
     int off = 0;
     if (i < d.ntaps * k.cgs) {
@@ -83,140 +106,330 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
     }
     ktab[i] = off;
   }
-  for (int v = tid; v < 64 * MTW; v += 256) {
+  for (int i = tid; i < NT * 16; i += 256) {
+    const int c = split * NT * 16 + i;
+    const bool ok = c < cout;
+    epi[i] = (ok && d.bias) ? d.bias[c] : 0.f;
+    epi[NT * 16 + i] = (ok && d.scale) ? d.scale[c] : 1.f;
+    epi[2 * NT * 16 + i] = (ok && d.scale) ? d.shift[c] : 0.f;
+  }
+  if (nch == 1) {  // packed weights stay resident for the whole kernel
+    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wpack) + (int64_t)split * k.w_bytes);
+    uint4* dst = reinterpret_cast<uint4*>(Wl);
+    for (int i = tid; i < wpieces; i += 256) dst[i] = src[i];
+  }
+  const float alpha = (d.act == VSSEG_ACT_PRELU && d.alpha) ? *d.alpha : 0.f;
+
+  // ---- per-thread constants: the halo pieces this thread fetches every stage, and the voxels it stores.
+  //      Everything that does not depend on the tile is computed once here: the per-tile work is then a handful of
+  //      32-bit adds (the unoptimised version spent ~1100 VALU+SALU instructions per tile and wave on index arithmetic
+  //      and was issue-bound at 1.7 TB/s on the HBM-bound layers).
+  const int X = d.in.x, Y = d.in.y, Z = d.in.z;
+  const unsigned in_vox_bytes = (unsigned)d.in.pitch * ES;
+  unsigned pinfo[PMAX];  // packed halo coordinates (slow path: bounds checks on boundary tiles)
+  unsigned prel[PMAX];   // byte offset relative to the halo origin voxel (fast path: interior tiles)
+#pragma unroll
+  for (int u = 0; u < PMAX; ++u) {
+    const int j = (u * 4 + wave) * 64 + lane;
+    unsigned info = 0xffffffffu, rel = 0;
+    if (j < pieces) {
+      int hv = j / ppv, c16 = j - hv * ppv;
+      int hz = hv % HZ, r = hv / HZ;
+      int hy = r % HY, hx = r / HY;
+      info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)c16 << 24);
+      rel = (unsigned)((hx * Y + hy) * Z + hz) * in_vox_bytes + (unsigned)c16 * 16u;
+    }
+    pinfo[u] = info;
+    prel[u] = rel;
+  }
+  const int OX = d.out.x, OY = d.out.y, OZ = d.out.z;
+  int vb[MTW];
+  unsigned vxyz[MTW];
+  unsigned ovrel[MTW];  // output voxel index relative to the tile's first output voxel
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const int v = (wave * MTW + m) * 16 + l15;
     int vz = v % d.tile[2], r = v / d.tile[2];
     int vy = r % d.tile[1], vx = r / d.tile[1];
-    vbase[v] = (((vx * d.is[0]) * HY + vy * d.is[1]) * HZ + vz * d.is[2]) * CK * ES;
+    vb[m] = (((vx * d.is[0]) * HY + vy * d.is[1]) * HZ + vz * d.is[2]) * CK * ES;
+    vxyz[m] = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16);
+    ovrel[m] = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]);
   }
-
-  f32x4 acc[MTW][NT];
+  const unsigned out_es = d.out.dtype == VSSEG_F32 ? 4u : 2u;
+  const unsigned out_vox_bytes = (unsigned)d.out.pitch * out_es;
+  // auxiliary tile (old output for accumulate / residual / ReLU mask): [tile voxel][NT*16] fetched by DMA one tile ahead
+  const bool aux_on = k.aux_bytes > 0;
+  const unsigned aux_es = k.aux.dtype == VSSEG_F32 ? 4u : 2u;
+  const unsigned aux_vox_bytes = (unsigned)k.aux.pitch * aux_es;
+  const int aux_row = NT * 16 * (int)aux_es;  // LDS bytes per voxel
+  const int ppa = aux_row >> 4;
+  const int apieces = aux_on ? 64 * MTW * ppa : 0;
+  unsigned arel[AMAX];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const T* inp = reinterpret_cast<const T*>(d.in.ptr);
-  const int X = d.in.x, Y = d.in.y, Z = d.in.z;
-  const int gx0 = q0[0] * d.is[0] + k.off_min[0], gy0 = q0[1] * d.is[1] + k.off_min[1], gz0 = q0[2] * d.is[2] + k.off_min[2];
-  const int64_t chunk_w_bytes = (int64_t)d.ksteps * NT * 64 * GB;
-
-  for (int ch = 0; ch < d.nchunks; ++ch) {
-    __syncthreads();  // previous chunk's fragment reads are done (also publishes ktab/vbase on the first pass)
-    {  // packed weights of this chunk: linear copy, 16 B per lane
-      const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * d.nchunks + ch) * chunk_w_bytes);
-      uint4* dst = reinterpret_cast<uint4*>(Bl);
-      const int n16 = (int)(chunk_w_bytes >> 4);
-      for (int i = tid; i < n16; i += 256) dst[i] = src[i];
+  for (int u = 0; u < AMAX; ++u) {
+    const int j = (u * 4 + wave) * 64 + lane;
+    unsigned rel = 0xffffffffu;
+    if (j < apieces) {
+      const int v = j / ppa, c16 = j - v * ppa;
+      int vz = v % d.tile[2], r = v / d.tile[2];
+      int vy = r % d.tile[1], vx = r / d.tile[1];
+      rel = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]) * aux_vox_bytes + (unsigned)(split * NT * 16) * aux_es + (unsigned)c16 * 16u;
     }
-    {  // input halo tile, zero-filled outside the tensor
-      const int c0 = ch * CK;
-      const int items = hvox * k.cgs;
-      for (int i = tid; i < items; i += 256) {
-        int hv = i / k.cgs, cg = i - hv * k.cgs;
-        int hz = hv % HZ, r = hv / HZ;
-        int hy = r % HY, hx = r / HY;
-        int gx = gx0 + hx, gy = gy0 + hy, gz = gz0 + hz;
-        char* dst = Hl + (int64_t)hv * CK * ES + cg * GB;
-        const bool ok = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && (c0 + cg * 8 + 8 <= d.in.c);
-        if (ES == 2) {
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (ok) v = *reinterpret_cast<const uint4*>(inp + ((((int64_t)n * X + gx) * Y + gy) * Z + gz) * d.in.pitch + c0 + cg * 8);
-          *reinterpret_cast<uint4*>(dst) = v;
-        } else {
-          uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-          if (ok) {
-            const uint4* s = reinterpret_cast<const uint4*>(inp + ((((int64_t)n * X + gx) * Y + gy) * Z + gz) * d.in.pitch + c0 + cg * 8);
-            v0 = s[0];
-            v1 = s[1];
-          }
-          reinterpret_cast<uint4*>(dst)[0] = v0;
-          reinterpret_cast<uint4*>(dst)[1] = v1;
+    arel[u] = rel;
+  }
+  const bool fast_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0 && ((d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on);
+  const int64_t aux_sample_bytes = (int64_t)OX * OY * OZ * aux_vox_bytes;
+
+  // ---- tile schedule: XCD x (= blockIdx % 8) owns tiles [x*tpx, (x+1)*tpx); its workgroups stride through them ----
+  const int G = gridDim.x;
+  const bool xcd_map = (G % 8) == 0;
+  const int tpx = xcd_map ? (int)((k.total_tiles + 7) / 8) : (int)k.total_tiles;
+  const int xcd = xcd_map ? (int)(blockIdx.x & 7) : 0;
+  const int slot = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int S = xcd_map ? G / 8 : G;
+  const int t_first = xcd * tpx;
+  int cnt = (int)k.total_tiles - t_first;
+  if (cnt > tpx) cnt = tpx;
+  const int my_tiles = cnt > slot ? (cnt - 1 - slot) / S + 1 : 0;
+  const int nstages = my_tiles * nch;
+
+  const char* in_base = reinterpret_cast<const char*>(d.in.ptr);
+  const int64_t in_sample_bytes = (int64_t)X * Y * Z * in_vox_bytes;
+  const int64_t out_sample_bytes = (int64_t)OX * OY * OZ * out_vox_bytes;
+
+  // tile coordinates advance by S tiles per step: add the precomputed (sz, sy, sx, sn) digits with carries, no division in the loop
+  struct TileIdx { int tz, ty, tx, n; };
+  auto tile_decode = [&](int b) {
+    TileIdx t;
+    t.tz = b % k.ntile[2]; b /= k.ntile[2];
+    t.ty = b % k.ntile[1]; b /= k.ntile[1];
+    t.tx = b % k.ntile[0];
+    t.n = b / k.ntile[0];
+    return t;
+  };
+  const TileIdx step = tile_decode(S);
+  auto tile_advance = [&](TileIdx& t) {
+    t.tz += step.tz; if (t.tz >= k.ntile[2]) { t.tz -= k.ntile[2]; ++t.ty; }
+    t.ty += step.ty; if (t.ty >= k.ntile[1]) { t.ty -= k.ntile[1]; ++t.tx; }
+    t.tx += step.tx; if (t.tx >= k.ntile[0]) { t.tx -= k.ntile[0]; ++t.n; }
+    t.n += step.n;
+  };
+  TileIdx t_issue = tile_decode(t_first + slot), t_cur = t_issue;
+  int ch_issue = 0, ch_cur = 0, par_issue = 0, par_cur = 0;
+  auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
+    const int ch = ch_issue, n = t_issue.n;
+    const int qx = t_issue.tx * d.tile[0], qy = t_issue.ty * d.tile[1], qz = t_issue.tz * d.tile[2];
+    if (++ch_issue == nch) { ch_issue = 0; tile_advance(t_issue); }
+    const int gx0 = qx * d.is[0] + k.off_min[0], gy0 = qy * d.is[1] + k.off_min[1], gz0 = qz * d.is[2] + k.off_min[2];
+    const int c0 = ch * CK;
+    char* Hdst = Hl + (s & 1) * k.h_bytes;
+    const char* sample = in_base + (int64_t)n * in_sample_bytes + (int64_t)c0 * ES;
+    const bool interior = gx0 >= 0 && gy0 >= 0 && gz0 >= 0 && gx0 + k.halo[0] <= X && gy0 + k.halo[1] <= Y && gz0 + k.halo[2] <= Z && c0 + CK <= d.in.c;
+    if (interior) {
+      const char* origin = sample + (int64_t)((gx0 * Y + gy0) * Z + gz0) * in_vox_bytes;
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u) {
+        if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
+        if (pinfo[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u) {
+        if ((u * 4 + wave) * 64 >= pieces) break;
+        const unsigned info = pinfo[u];
+        if (info != 0xffffffffu) {
+          const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
+          const int c = c0 + (int)(info >> 24) * EPP;
+          const bool ok = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
+          const void* src = ok ? (const void*)(sample + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
+          dma16(src, Hdst + (u * 4 + wave) * 1024);
         }
       }
     }
-    __syncthreads();
-
-    int vb[MTW];
+    if (aux_on && ch == 0) {
+      const int ox0 = qx * d.os[0] + d.oo[0], oy0 = qy * d.os[1] + d.oo[1], oz0 = qz * d.os[2] + d.oo[2];
+      const bool whole = qx + d.tile[0] <= d.q[0] && qy + d.tile[1] <= d.q[1] && qz + d.tile[2] <= d.q[2] && (qx + d.tile[0] - 1) * d.os[0] + d.oo[0] < OX &&
+                         (qy + d.tile[1] - 1) * d.os[1] + d.oo[1] < OY && (qz + d.tile[2] - 1) * d.os[2] + d.oo[2] < OZ;
+      if (whole) {  // partial tiles use the slow epilogue (ordinary loads)
+        const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + (int64_t)n * aux_sample_bytes + (int64_t)((ox0 * OY + oy0) * OZ + oz0) * aux_vox_bytes;
+        char* Adst = Al + par_issue * k.aux_bytes;
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) vb[m] = vbase[(wave * MTW + m) * 16 + l15];
-    for (int ks = 0; ks < d.ksteps; ++ks) {
-      const int koff = ktab[ks * 4 + g];
-      Frag<T> w[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) w[t] = Frag<T>::ld(Bl + ((int64_t)(ks * NT + t) * 64 + lane) * GB);
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        Frag<T> a = Frag<T>::ld(Hl + vb[m] + koff);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) mma(acc[m][t], w[t], a);
+        for (int u = 0; u < AMAX; ++u) {
+          if ((u * 4 + wave) * 64 >= apieces) break;
+          if (arel[u] != 0xffffffffu) dma16(aorigin + arel[u], Adst + (u * 4 + wave) * 1024);
+        }
       }
+      par_issue ^= 1;
     }
-  }
+    if (nch > 1) {
+      const char* wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
+      char* Wdst = Wl + (s & 1) * k.w_bytes;
+      for (int j0 = wave * 64; j0 < wpieces; j0 += 256)
+        if (j0 + lane < wpieces) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);
+    }
+  };
 
-  // ---- epilogue ----
-  const int cout = d.out.c;
-  const float alpha = (d.act == VSSEG_ACT_PRELU && d.alpha) ? *d.alpha : 0.f;
+  f32x4 acc[MTW][NT];
   float ssum[NT][4], ssq[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ssum[t][r] = ssq[t][r] = 0.f;
 
+  if (nstages > 0) issue(0);
+  for (int s = 0; s < nstages; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s has landed (this wave's pieces) ...
+    __syncthreads();                                  // ... and everybody's; everybody is also done with stage s-1's buffers
+    if (s + 1 < nstages) issue(s + 1);
+    const int ch = ch_cur;
+    if (ch == 0) {
 #pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    const int v = (wave * MTW + m) * 16 + l15;
-    int vz = v % d.tile[2], rr = v / d.tile[2];
-    int vy = rr % d.tile[1], vx = rr / d.tile[1];
-    const int qx = q0[0] + vx, qy = q0[1] + vy, qz = q0[2] + vz;
-    const int ox = qx * d.os[0] + d.oo[0], oy = qy * d.os[1] + d.oo[1], oz = qz * d.os[2] + d.oo[2];
-    const bool vok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && ox < d.out.x && oy < d.out.y && oz < d.out.z;
-    const int64_t ovox = (((int64_t)n * d.out.x + ox) * d.out.y + oy) * d.out.z + oz;
+      for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int c = (split * NT + t) * 16 + g * 4;
-      if (!vok || c >= cout) continue;
-      float val[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-      const int nc = min(4, cout - c);
+        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const char* Hs = Hl + (s & 1) * k.h_bytes;
+    const char* Ws = nch > 1 ? Wl + (s & 1) * k.w_bytes : Wl;
+    {  // K loop, software-pipelined by hand: the fragments of K-step ks+1 are read from LDS before the MFMAs of ks issue
+       // (with 1-2 waves per SIMD nothing else hides the ds_read -> MFMA latency; hipcc does not pipeline this loop itself)
+      Frag<T> wn[NT], an[MTW];
+      const char* Wlane = Ws + lane * GB;
+      {
+        const int koff = ktab[g];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (r >= nc) break;
-        float x = val[r];
-        if (d.bias) x += d.bias[c + r];
-        if (d.stats) { ssum[t][r] += x; ssq[t][r] += x * x; }
-        if (d.scale) x = x * d.scale[c + r] + d.shift[c + r];
-        if (d.act == VSSEG_ACT_PRELU) x = x > 0.f ? x : alpha * x;
-        else if (d.act == VSSEG_ACT_RELU) x = fmaxf(x, 0.f);
-        else if (d.act == VSSEG_ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
-        if (d.res_mode != VSSEG_RES_NONE) {
-          const int64_t ro = ovox * d.res.pitch + c + r;
-          float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(d.res.ptr)[ro] : bf2f(reinterpret_cast<const bf16_t*>(d.res.ptr)[ro]);
-          x = d.res_mode == VSSEG_RES_ADD ? x + rv : (rv > 0.f ? x : 0.f);
-        }
-        val[r] = x;
+        for (int t = 0; t < NT; ++t) wn[t] = Frag<T>::ld(Wlane + t * 64 * GB);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) an[m] = Frag<T>::ld(Hs + vb[m] + koff);
       }
-      const int64_t oo = ovox * d.out.pitch + c;
-      if (d.out.dtype == VSSEG_F32) {
-        float* op = reinterpret_cast<float*>(d.out.ptr) + oo;
-        if (nc == 4 && (d.out.pitch & 3) == 0 && !d.accumulate) st4(op, make_float4(val[0], val[1], val[2], val[3]));
-        else
-          for (int r = 0; r < nc; ++r) op[r] = d.accumulate ? op[r] + val[r] : val[r];
-      } else {
-        bf16_t* op = reinterpret_cast<bf16_t*>(d.out.ptr) + oo;
-        if (nc == 4 && (d.out.pitch & 3) == 0) {
-          if (d.accumulate) {
-            float4 o = ld4(op);
-            val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+      for (int ks = 0; ks < d.ksteps; ++ks) {
+        Frag<T> w[NT], a[MTW];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = wn[t];
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) a[m] = an[m];
+        if (ks + 1 < d.ksteps) {
+          const int koff = ktab[(ks + 1) * 4 + g];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) wn[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
+#pragma unroll
+          for (int m = 0; m < MTW; ++m) an[m] = Frag<T>::ld(Hs + vb[m] + koff);
+        }
+#pragma unroll
+        for (int m = 0; m < MTW; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mma(acc[m][t], w[t], a[m]);
+      }
+    }
+    if (++ch_cur != nch) continue;
+    ch_cur = 0;
+
+    // ---- epilogue of the current tile ----
+    const int n = t_cur.n, q0x = t_cur.tx * d.tile[0], q0y = t_cur.ty * d.tile[1], q0z = t_cur.tz * d.tile[2];
+    tile_advance(t_cur);
+    const int ox0 = q0x * d.os[0] + d.oo[0], oy0 = q0y * d.os[1] + d.oo[1], oz0 = q0z * d.os[2] + d.oo[2];
+    const unsigned tile_vox = (unsigned)((ox0 * OY + oy0) * OZ + oz0);  // first output voxel of the tile inside sample n
+    const bool whole = q0x + d.tile[0] <= d.q[0] && q0y + d.tile[1] <= d.q[1] && q0z + d.tile[2] <= d.q[2] && (q0x + d.tile[0] - 1) * d.os[0] + d.oo[0] < OX &&
+                       (q0y + d.tile[1] - 1) * d.os[1] + d.oo[1] < OY && (q0z + d.tile[2] - 1) * d.os[2] + d.oo[2] < OZ;
+    char* out_sample = reinterpret_cast<char*>(d.out.ptr) + (int64_t)n * out_sample_bytes;
+    const char* Aux = Al + par_cur * k.aux_bytes;
+    par_cur ^= 1;
+    if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) {
+        char* op = out_sample + (tile_vox + ovrel[m]) * out_vox_bytes;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int cl = t * 16 + g * 4;
+          const int c = split * NT * 16 + cl;
+          if (c >= cout) continue;
+          const float4 bi = *reinterpret_cast<const float4*>(epi + cl);
+          float val[4] = {acc[m][t][0] + bi.x, acc[m][t][1] + bi.y, acc[m][t][2] + bi.z, acc[m][t][3] + bi.w};
+          if (d.stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[t][r] += val[r]; ssq[t][r] += val[r] * val[r]; }
           }
-          st4(op, make_float4(val[0], val[1], val[2], val[3]));
-        } else
-          for (int r = 0; r < nc; ++r) op[r] = f2bf(d.accumulate ? bf2f(op[r]) + val[r] : val[r]);
+          if (d.scale) {
+            const float4 sc = *reinterpret_cast<const float4*>(epi + NT * 16 + cl), sh = *reinterpret_cast<const float4*>(epi + 2 * NT * 16 + cl);
+            val[0] = val[0] * sc.x + sh.x; val[1] = val[1] * sc.y + sh.y; val[2] = val[2] * sc.z + sh.z; val[3] = val[3] * sc.w + sh.w;
+          }
+          if (d.act == VSSEG_ACT_PRELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = val[r] > 0.f ? val[r] : alpha * val[r];
+          } else if (d.act == VSSEG_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = fmaxf(val[r], 0.f);
+          } else if (d.act == VSSEG_ACT_SIGMOID) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = 1.f / (1.f + __expf(-val[r]));
+          }
+          if (aux_on) {
+            const char* ap = Aux + ((wave * MTW + m) * 16 + l15) * aux_row + cl * (int)aux_es;
+            const float4 av = aux_es == 4 ? *reinterpret_cast<const float4*>(ap) : ld4(reinterpret_cast<const bf16_t*>(ap));
+            if (k.aux_mode == 3) {
+              val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
+            } else {
+              val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
+            }
+          }
+          if (out_es == 4) st4(reinterpret_cast<float*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+          else st4(reinterpret_cast<bf16_t*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) {
+      const int qx = q0x + (int)(vxyz[m] & 255u), qy = q0y + (int)((vxyz[m] >> 8) & 255u), qz = q0z + (int)(vxyz[m] >> 16);
+      const int ox = qx * d.os[0] + d.oo[0], oy = qy * d.os[1] + d.oo[1], oz = qz * d.os[2] + d.oo[2];
+      const bool vok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && ox < OX && oy < OY && oz < OZ;
+      const int64_t ovox = (((int64_t)n * OX + ox) * OY + oy) * OZ + oz;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int cl = t * 16 + g * 4;  // channel inside this workgroup's NT*16 slice
+        const int c = split * NT * 16 + cl;
+        if (!vok || c >= cout) continue;
+        float val[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
+        const int nc = min(4, cout - c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r >= nc) break;
+          float x = val[r] + epi[cl + r];
+          if (d.stats) { ssum[t][r] += x; ssq[t][r] += x * x; }
+          x = x * epi[NT * 16 + cl + r] + epi[2 * NT * 16 + cl + r];
+          if (d.act == VSSEG_ACT_PRELU) x = x > 0.f ? x : alpha * x;
+          else if (d.act == VSSEG_ACT_RELU) x = fmaxf(x, 0.f);
+          else if (d.act == VSSEG_ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
+          if (d.res_mode != VSSEG_RES_NONE) {
+            const int64_t ro = ovox * d.res.pitch + c + r;
+            float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(d.res.ptr)[ro] : bf2f(reinterpret_cast<const bf16_t*>(d.res.ptr)[ro]);
+            x = d.res_mode == VSSEG_RES_ADD ? x + rv : (rv > 0.f ? x : 0.f);
+          }
+          val[r] = x;
+        }
+        const int64_t oo = ovox * d.out.pitch + c;
+        if (d.out.dtype == VSSEG_F32) {
+          float* op = reinterpret_cast<float*>(d.out.ptr) + oo;
+          if (nc == 4 && (d.out.pitch & 3) == 0 && !d.accumulate) st4(op, make_float4(val[0], val[1], val[2], val[3]));
+          else
+            for (int r = 0; r < nc; ++r) op[r] = d.accumulate ? op[r] + val[r] : val[r];
+        } else {
+          bf16_t* op = reinterpret_cast<bf16_t*>(d.out.ptr) + oo;
+          if (nc == 4 && (d.out.pitch & 3) == 0) {
+            if (d.accumulate) {
+              float4 o = ld4(op);
+              val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
+            }
+            st4(op, make_float4(val[0], val[1], val[2], val[3]));
+          } else
+            for (int r = 0; r < nc; ++r) op[r] = f2bf(d.accumulate ? bf2f(op[r]) + val[r] : val[r]);
+        }
       }
     }
   }
 
-  if (d.stats) {  // per-channel sum / sum-of-squares: 16-lane shuffle tree -> LDS across waves -> sharded fp64 atomics
+  if (d.stats) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [2][NT*16]
+    float* red = epi;  // reuse [2][NT*16]
     for (int i = tid; i < 2 * NT * 16; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
@@ -247,6 +460,17 @@ template <typename T, int NT, int MTW> static int launch(const IgemmK& k, dim3 g
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, MTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  // persistent grid = resident workgroups only (registers AND LDS), otherwise the late workgroups form a tail
+  static int cached_lds = -1, cached_per_cu = 1;
+  if (cached_lds != lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW>, 256, lds) != hipSuccess || n < 1) n = 1;
+    cached_per_cu = n > 4 ? 4 : n;
+    cached_lds = lds;
+  }
+  int64_t gx = 256ll * cached_per_cu;
+  if (gx > k.total_tiles) gx = k.total_tiles;
+  grid.x = (unsigned)gx;
   hipLaunchKernelGGL((igemm_kernel<T, NT, MTW>), grid, dim3(256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_igemm");
   return VSSEG_OK;
@@ -273,6 +497,14 @@ template <typename T> static int launch_nt(const IgemmK& k, dim3 grid, int lds, 
   return VSSEG_EINVAL;
 }
 
+static const void* zero_page() {
+  static void* z = nullptr;
+  if (!z) {
+    if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) z = nullptr;
+  }
+  return z;
+}
+
 static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d && d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
   VSSEG_CHECK(d->in.dtype == VSSEG_F32 || d->in.dtype == VSSEG_BF16, "vsseg_igemm: bad input dtype");
@@ -285,18 +517,38 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   const int es = d->in.dtype == VSSEG_F32 ? 4 : 2;
   k.cgs = d->ck / 8;
   VSSEG_CHECK(d->ksteps * 4 >= d->ntaps * k.cgs, "vsseg_igemm: ksteps too small");
+  k.total_tiles = d->in.n;
   for (int a = 0; a < 3; ++a) {
     int lo = d->tap_off[0][a], hi = lo;
     for (int t = 1; t < d->ntaps; ++t) { lo = min(lo, d->tap_off[t][a]); hi = max(hi, d->tap_off[t][a]); }
     k.off_min[a] = lo;
     k.halo[a] = (d->tile[a] - 1) * d->is[a] + (hi - lo + 1);
     k.ntile[a] = (d->q[a] + d->tile[a] - 1) / d->tile[a];
+    k.total_tiles *= k.ntile[a];
+    VSSEG_CHECK(k.halo[a] <= 255 && d->tile[a] <= 255, "vsseg_igemm: tile/halo extent > 255");
   }
+  k.w_bytes = d->ksteps * d->nt * 64 * 8 * es;
+  k.h_bytes = k.halo[0] * k.halo[1] * k.halo[2] * d->ck * es;
+  k.aux_mode = 0;
+  k.aux_bytes = 0;
+  if (d->accumulate && d->res_mode == VSSEG_RES_NONE) { k.aux_mode = 1; k.aux = d->out; }
+  else if (!d->accumulate && d->res_mode == VSSEG_RES_ADD) { k.aux_mode = 2; k.aux = d->res; }
+  else if (!d->accumulate && d->res_mode == VSSEG_RES_RELUMASK) { k.aux_mode = 3; k.aux = d->res; }
+  if (k.aux_mode) {
+    const int aes = k.aux.dtype == VSSEG_F32 ? 4 : 2;
+    const int row = d->nt * 16 * aes;
+    const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && d->nsplit * d->nt * 16 <= k.aux.pitch && 64 * d->mtw * (row / 16) <= AMAX * 256 &&
+                    ((uintptr_t)k.aux.ptr % 16) == 0 && k.aux.c >= d->out.c;
+    if (ok) k.aux_bytes = 64 * d->mtw * row; else k.aux_mode = 0;
+  }
+  VSSEG_CHECK(k.h_bytes <= PMAX * 256 * 16, "vsseg_igemm: halo chunk of %d bytes exceeds %d; reduce ck or the tile", k.h_bytes, PMAX * 256 * 16);
+  VSSEG_CHECK(d->ck * es / 16 <= 255, "vsseg_igemm: ck too large");
   int off = 0;
   k.lds_ktab = off; off += ((d->ksteps * 4 * 4 + 15) / 16) * 16;
-  k.lds_vbase = off; off += 64 * d->mtw * 4;
-  k.lds_b = off; off += d->ksteps * d->nt * 64 * 8 * es;
-  k.lds_halo = off; off += k.halo[0] * k.halo[1] * k.halo[2] * d->ck * es;
+  k.lds_epi = off; off += 3 * d->nt * 16 * 4;
+  k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? 2 : 1);
+  k.lds_h = off; off += 2 * k.h_bytes;
+  k.lds_aux = off; off += 2 * k.aux_bytes;
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }
@@ -310,9 +562,10 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   IgemmK k;
   int lds = igemm_prepare(d, k);
   if (lds < 0) return lds;
-  int64_t blocks = (int64_t)d->in.n * k.ntile[0] * k.ntile[1] * k.ntile[2];
-  VSSEG_CHECK(blocks > 0 && blocks < (1ll << 31), "vsseg_igemm: bad grid");
-  dim3 grid((unsigned)blocks, (unsigned)d->nsplit);
+  k.zeros = zero_page();
+  VSSEG_CHECK(k.zeros, "vsseg_igemm: could not allocate the zero page");
+  VSSEG_CHECK(k.total_tiles > 0 && k.total_tiles < (1ll << 31), "vsseg_igemm: bad tile count");
+  dim3 grid(1, (unsigned)d->nsplit);  // grid.x is set to the resident workgroup count by launch<>()
   if (d->in.dtype == VSSEG_F32) return launch_nt<float>(k, grid, lds, as_stream(stream));
   return launch_nt<bf16_t>(k, grid, lds, as_stream(stream));
 }

@@ -10,7 +10,8 @@
 //
 // Work split: blockIdx.y = 16-channel chunk of H (only those channels of the halo tile are staged), blockIdx.x = persistent
 // workgroup striding over lattice tiles; accumulators live in registers across all tiles of a workgroup and are flushed
-// once with fp32 atomics.  The 4 waves of a workgroup split the taps (wave w owns taps t = w mod WT) and, for 1x1x1
+// once as a partial-sum slab (plain coalesced stores; fp32 atomics measured ~18 G/s and dominated the kernel); a tiny
+// second kernel sums the slabs of all workgroups into the weight gradient.  The 4 waves of a workgroup split the taps (wave w owns taps t = w mod WT) and, for 1x1x1
 // kernels, the K-steps.
 #include "common.h"
 
@@ -24,6 +25,8 @@ struct WgradK {
   int p_row;      // bytes per P row in LDS
   int lds_hbase, lds_p, lds_h;
   int64_t total_tiles;
+  float* slab;     // [gridDim.x][hchunks][ntaps][ntp*16][16] partial sums
+  int slab_chunk;  // ntaps * ntp*16 * 16
 };
 
 template <typename T, int MAXT, int NTP>
@@ -71,50 +74,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     const int n = (int)(b / k.ntile[0]);
     const int q0x = tx * d.tile[0], q0y = ty * d.tile[1], q0z = tz * d.tile[2];
     __syncthreads();
-    {  // P tile [tvox][NTP*16], zero outside the lattice / beyond the valid channels
+    {  // P tile [tvox][NTP*16], zero outside the lattice / beyond the valid channels.  Loads are issued in batches of U
+       // before any LDS store so that U global loads per thread are in flight (the staging is latency-, not bandwidth-bound).
+      constexpr int U = 4;
+      constexpr int V16 = ES == 2 ? 1 : 2;  // 16-byte pieces per 8-channel group
       const int cgs = PC / 8, items = k.tvox * cgs;
-      for (int i = tid; i < items; i += 256) {
-        int v = i / cgs, cg = i - v * cgs;
-        int vz = v % d.tile[2], r = v / d.tile[2];
-        int vy = r % d.tile[1], vx = r / d.tile[1];
-        int qx = q0x + vx, qy = q0y + vy, qz = q0z + vz;
-        const bool ok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && cg * 8 + 8 <= d.p.c;
-        char* dst = Pl + (int64_t)v * k.p_row + cg * 8 * ES;
-        const T* src = Pg + ((((int64_t)n * d.p.x + qx) * d.p.y + qy) * d.p.z + qz) * d.p.pitch + cg * 8;
-        if (ES == 2) {
-          uint4 val = make_uint4(0, 0, 0, 0);
-          if (ok) val = *reinterpret_cast<const uint4*>(src);
-          *reinterpret_cast<uint4*>(dst) = val;
-        } else {
-          uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-          if (ok) { v0 = reinterpret_cast<const uint4*>(src)[0]; v1 = reinterpret_cast<const uint4*>(src)[1]; }
-          reinterpret_cast<uint4*>(dst)[0] = v0;
-          reinterpret_cast<uint4*>(dst)[1] = v1;
+      for (int base = 0; base < items; base += 256 * U) {
+        uint4 val[U][V16];
+        int dsto[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = base + u * 256 + tid;
+          const int ii = min(i, items - 1);
+          int v = ii / cgs, cg = ii - v * cgs;
+          int vz = v % d.tile[2], r = v / d.tile[2];
+          int vy = r % d.tile[1], vx = r / d.tile[1];
+          int qx = q0x + vx, qy = q0y + vy, qz = q0z + vz;
+          const bool ok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && cg * 8 + 8 <= d.p.c;
+          dsto[u] = i < items ? v * k.p_row + cg * 8 * ES : -1;
+          const T* src = ok ? Pg + ((((int64_t)n * d.p.x + qx) * d.p.y + qy) * d.p.z + qz) * d.p.pitch + cg * 8 : Pg;
+#pragma unroll
+          for (int w = 0; w < V16; ++w) {
+            uint4 x = reinterpret_cast<const uint4*>(src)[w];
+            val[u][w] = ok ? x : make_uint4(0, 0, 0, 0);
+          }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dsto[u] >= 0) {
+#pragma unroll
+            for (int w = 0; w < V16; ++w) reinterpret_cast<uint4*>(Pl + dsto[u])[w] = val[u][w];
+          }
       }
     }
     {  // H halo tile [hvox][16] for this workgroup's channel chunk
+      constexpr int U = 4;
+      constexpr int V16 = ES == 2 ? 1 : 2;
       const int gx0 = q0x * d.hs[0] + k.off_min[0], gy0 = q0y * d.hs[1] + k.off_min[1], gz0 = q0z * d.hs[2] + k.off_min[2];
       const int items = hvox * 2;
-      for (int i = tid; i < items; i += 256) {
-        int hv = i >> 1, cg = i & 1;
-        int hz = hv % HZ, r = hv / HZ;
-        int hy = r % HY, hx = r / HY;
-        int gx = gx0 + hx, gy = gy0 + hy, gz = gz0 + hz;
-        const int c = chunk * 16 + cg * 8;
-        const bool ok = (unsigned)gx < (unsigned)d.h.x && (unsigned)gy < (unsigned)d.h.y && (unsigned)gz < (unsigned)d.h.z && c + 8 <= d.h.c;
-        char* dst = Hl + (int64_t)hv * HROW + cg * 8 * ES;
-        const T* src = Hg + ((((int64_t)n * d.h.x + gx) * d.h.y + gy) * d.h.z + gz) * d.h.pitch + c;
-        if (ES == 2) {
-          uint4 val = make_uint4(0, 0, 0, 0);
-          if (ok) val = *reinterpret_cast<const uint4*>(src);
-          *reinterpret_cast<uint4*>(dst) = val;
-        } else {
-          uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
-          if (ok) { v0 = reinterpret_cast<const uint4*>(src)[0]; v1 = reinterpret_cast<const uint4*>(src)[1]; }
-          reinterpret_cast<uint4*>(dst)[0] = v0;
-          reinterpret_cast<uint4*>(dst)[1] = v1;
+      for (int base = 0; base < items; base += 256 * U) {
+        uint4 val[U][V16];
+        int dsto[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = base + u * 256 + tid;
+          const int ii = min(i, items - 1);
+          int hv = ii >> 1, cg = ii & 1;
+          int hz = hv % HZ, r = hv / HZ;
+          int hy = r % HY, hx = r / HY;
+          int gx = gx0 + hx, gy = gy0 + hy, gz = gz0 + hz;
+          const int c = chunk * 16 + cg * 8;
+          const bool ok = (unsigned)gx < (unsigned)d.h.x && (unsigned)gy < (unsigned)d.h.y && (unsigned)gz < (unsigned)d.h.z && c + 8 <= d.h.c;
+          dsto[u] = i < items ? hv * HROW + cg * 8 * ES : -1;
+          const T* src = ok ? Hg + ((((int64_t)n * d.h.x + gx) * d.h.y + gy) * d.h.z + gz) * d.h.pitch + c : Hg;
+#pragma unroll
+          for (int w = 0; w < V16; ++w) {
+            uint4 x = reinterpret_cast<const uint4*>(src)[w];
+            val[u][w] = ok ? x : make_uint4(0, 0, 0, 0);
+          }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dsto[u] >= 0) {
+#pragma unroll
+            for (int w = 0; w < V16; ++w) reinterpret_cast<uint4*>(Hl + dsto[u])[w] = val[u][w];
+          }
       }
     }
     __syncthreads();
@@ -163,19 +187,35 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     }
   }
 
-  // flush: lane holds rows g*4+r (P channel) x col l15 (H channel)
-  const int ch = chunk * 16 + l15;
+  // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) -> this workgroup's slab [tap][cP][16]
+  float* slab = k.slab + ((int64_t)blockIdx.x * gridDim.y + chunk) * k.slab_chunk;
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     const int t = wt + i * k.wt;
-    if (t >= d.ntaps || ch >= d.ch_valid) continue;
+    if (t >= d.ntaps) continue;
 #pragma unroll
     for (int p = 0; p < NTP; ++p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cp = p * 16 + g * 4 + r;
-        if (cp < d.cp_valid) atomicAdd(d.dw + cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap, acc[i][p][r]);
+        float* dst = slab + ((int64_t)t * (NTP * 16) + cp) * 16 + l15;
+        if (k.wv == 1) *dst = acc[i][p][r];
+        else atomicAdd(dst, acc[i][p][r]);  // K-steps split over waves (1x1x1 kernels): slab pre-zeroed by the host wrapper
       }
+  }
+}
+
+// dw[cp][ch][tap] += sum over workgroups of their slabs
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
+  const int total = hchunks * slab_chunk;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int chunk = i / slab_chunk, r = i - chunk * slab_chunk;
+    const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
+    const int ch = chunk * 16 + l15;
+    if (cp >= d.cp_valid || ch >= d.ch_valid) continue;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += slab[((int64_t)b * hchunks + chunk) * slab_chunk + r];
+    d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap] += s;
   }
 }
 
@@ -239,9 +279,19 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   k.lds_h = off; off += k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_wgrad: needs %d bytes of LDS (> 160 KiB); reduce the tile", off);
   const int hchunks = (d->ch_valid + 15) / 16;
+  k.slab_chunk = d->ntaps * d->ntp * 16 * 16;
+  VSSEG_CHECK(d->scratch && d->scratch_elems >= (int64_t)hchunks * k.slab_chunk, "vsseg_wgrad: scratch too small (%lld < %lld floats)", (long long)d->scratch_elems, (long long)hchunks * k.slab_chunk);
   int64_t gx = d->persistent_blocks > 0 ? d->persistent_blocks : 256;
   if (gx > k.total_tiles) gx = k.total_tiles;
+  const int64_t cap = d->scratch_elems / ((int64_t)hchunks * k.slab_chunk);
+  if (gx > cap) gx = cap;
+  k.slab = d->scratch;
+  if (k.wv != 1) hipMemsetAsync(d->scratch, 0, sizeof(float) * gx * hchunks * k.slab_chunk, as_stream(stream));
   dim3 grid((unsigned)gx, (unsigned)hchunks);
-  if (d->p.dtype == VSSEG_F32) return wg_maxt<float>(k, maxt, grid, off, as_stream(stream));
-  return wg_maxt<bf16_t>(k, maxt, grid, off, as_stream(stream));
+  int rc = d->p.dtype == VSSEG_F32 ? wg_maxt<float>(k, maxt, grid, off, as_stream(stream)) : wg_maxt<bf16_t>(k, maxt, grid, off, as_stream(stream));
+  if (rc) return rc;
+  const int total = hchunks * k.slab_chunk;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)d->scratch, (int)gx, hchunks, d->ntaps, d->ntp * 16, k.slab_chunk, *d);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
+  return VSSEG_OK;
 }

@@ -154,14 +154,15 @@ class Plan:
             assert dims_out == self.lv[Lr.out_level]
             fwd, dgrad, wg = [], [], None
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
-                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c)
+                aux_es = 0 if op.res is None else (4 if op.res.kind == 'f32' else eng.es)
+                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c, aux_es=aux_es)
                 fwd.append((pl, add_map(pl.pack_map, woff)))
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
                     for cls in P.lattice_classes(dk, Lr.kernel, Lr.stride):
                         q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                        pl = P.plan_igemm(dk, Lr.wshape, cls, q, eng.es, kc_pad=P.round_up(Lr.cout, 8))
+                        pl = P.plan_igemm(dk, Lr.wshape, cls, q, eng.es, kc_pad=P.round_up(Lr.cout, 8), aux_es=eng.es)
                         dgrad.append((pl, add_map(pl.pack_map, woff)))
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg)
@@ -189,7 +190,7 @@ class Plan:
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
-        meta = dict(name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ks={pl.ksteps} lds={pl.lds}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
@@ -201,14 +202,14 @@ class Plan:
         cpad = {Lr.prefix: P.round_up(Lr.cout, 16) for Lr in bn_layers}
         tot_c = max(sum(cpad.values()), 1)
         nsh = L.STAT_SHARDS
-        # fp64 sharded statistics: row 0 forward (sum, sumsq), row 1 backward (sum dz, sum dz*xhat) + PReLU-slope accumulators
-        self.stats = torch.zeros(2, nsh * 2 * tot_c + nsh * max(len(bn_layers), 1), dtype=torch.float64, device=dev)
+        # fp64 sharded statistics: row 0 forward (sum, sumsq), row 1 backward (sum dz, sum dz*xhat, sum dout) + PReLU-slope accumulators
+        self.stats = torch.zeros(2, nsh * 3 * tot_c + nsh * max(len(bn_layers), 1), dtype=torch.float64, device=dev)
         self.vec = torch.zeros(6, tot_c, dtype=torch.float32, device=dev)  # mean, invstd, scale, shift, mean_dz, mean_dzx
         st_off, v_off, a_off = {}, {}, {}
         o = v = 0
         for i, Lr in enumerate(bn_layers):
-            st_off[Lr.prefix], v_off[Lr.prefix], a_off[Lr.prefix] = o, v, nsh * 2 * tot_c + nsh * i
-            o += nsh * 2 * cpad[Lr.prefix]
+            st_off[Lr.prefix], v_off[Lr.prefix], a_off[Lr.prefix] = o, v, nsh * 3 * tot_c + nsh * i
+            o += nsh * 3 * cpad[Lr.prefix]
             v += cpad[Lr.prefix]
         row = self.stats.shape[1]
         sptr = lambda which, pre: self.stats.data_ptr() + 8 * (which * row + st_off[pre])
@@ -300,10 +301,17 @@ class Plan:
             d.tile, d.ntp = L.i3(wg.tile), wg.ntp
             d.dw = self._gp(Lr.wkey)
             d.stride_p, d.stride_h, d.stride_tap = wg.stride_p, wg.stride_h, wg.stride_tap
-            d.persistent_blocks = wg.blocks
+            hch = (d.ch_valid + 15) // 16
+            tiles = self.n
+            for a in range(3):
+                tiles *= -(-wg.q[a] // wg.tile[a])
+            # few persistent workgroups with many tiles each: the per-workgroup flush is as large as the weight gradient itself
+            d.persistent_blocks = max(1, min(tiles // 4, 1024 // hch))
+            scr = self.eng.wgrad_scratch()
+            d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
             self.keep.append(d)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} lds={wg.lds}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad:
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -314,6 +322,8 @@ class Plan:
                     self._igemm(B, pl, woff, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
+        producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
+        folded_bias = set()  # plain convolutions whose bias gradient is produced by another kernel's reduction
         for op in reversed(ops):
             if isinstance(op, ConvBnAct):
                 Lr, pre = op.layer, op.layer.prefix
@@ -321,8 +331,12 @@ class Plan:
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)]])
+                dres_bias = None
+                if op.res is not None and op.res.name in producer:  # residual conv: d(out)/d(res) = 1, its bias gradient is sum(dA) (reduced above)
+                    dres_bias = self._gp(producer[op.res.name].layer.bkey)
+                    folded_bias.add(producer[op.res.name].layer.prefix)
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
-                                                          self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre)]])
+                                                          self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
                 dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
                 B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd]])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
@@ -335,12 +349,14 @@ class Plan:
                 Lr = op.layer
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
-                conv_backward(Lr, op.x, dy, bias_grad=True, relumask=relu_out.get(op.x.name))
+                conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name))
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
                 acc = contribution(op.x)
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level)]])
+                sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
+                folded_bias.add(sig.prefix)
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey)]])
 
     def _index_slots(self):
         self.seed_slots, self.ext_slots = [], []
@@ -408,6 +424,11 @@ class Engine:
         self.prog: Program = build_program(attention, hp)
         self.dropout_p = hp["dropout"] if dropout_p is None else dropout_p
         self.plans: Dict[tuple, Plan] = {}
+
+    def wgrad_scratch(self) -> torch.Tensor:
+        if getattr(self, "_wg_scratch", None) is None:
+            self._wg_scratch = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 192 MB of partial-sum slabs, shared by all layers
+        return self._wg_scratch
 
     def plan(self, n, dims, train) -> Plan:
         key = (int(n), tuple(int(d) for d in dims), bool(train))

@@ -117,12 +117,22 @@ class IgemmPlan:
         return len(self.cls.taps)
 
 
-def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es):
+HALO_MAX = 8 * 256 * 16  # bytes of one halo chunk the kernel can fetch per stage (PMAX pieces of 16 B per thread)
+
+
+def igemm_halo_bytes(tile, is_, taps, ck, es):
     halo = 1
     for a in range(3):
         offs = [t[0][a] for t in taps]
         halo *= (tile[a] - 1) * is_[a] + (max(offs) - min(offs) + 1)
-    return round_up(ksteps * 16, 16) + 64 * mtw * 4 + ksteps * nt * 64 * 8 * es + halo * ck * es
+    return halo * ck * es
+
+
+def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=4):
+    """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers."""
+    w = ksteps * nt * 64 * 8 * es
+    aux = 2 * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread), double-buffered
+    return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (2 if nchunks > 1 else 1) + 2 * igemm_halo_bytes(tile, is_, taps, ck, es) + aux
 
 
 def _pow2_floor(v):
@@ -150,44 +160,49 @@ def choose_tile(q, taps, voxels):
                 rem //= 2
                 grew = True
                 break
-        if not grew:  # lattice smaller than the tile: pad the last axis that still fits nothing
-            tile[2] *= rem
-            rem = 1
+        if not grew:  # lattice smaller than the tile: pad the smallest axis (keeps the halo of strided convs compact)
+            a = min(range(3), key=lambda a: (tile[a], -a))
+            tile[a] *= 2
+            rem //= 2
     return tuple(tile)
 
 
-def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=64 * 1024, mtw=None) -> IgemmPlan:
+def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=158 * 1024, mtw=None, aux_es=4) -> IgemmPlan:
     kreal, nreal = gemm_dims(kind, wshape)
     kc = round_up(kreal, 8) if kc_pad is None else kc_pad
     nt_total = (nreal + 15) // 16
-    nsplit = (nt_total + 5) // 6
-    nt = (nt_total + nsplit - 1) // nsplit
+    nsplit0 = (nt_total + 5) // 6
     nvox = q[0] * q[1] * q[2]
     if mtw is None:
-        mtw = 4 if nvox >= 2048 else (2 if nvox >= 512 else 1)
-        if nt >= 5 and mtw == 4:
-            mtw = 2
-    tile = choose_tile(q, cls.taps, 64 * mtw)
+        mtw0 = 4 if nvox >= 2048 else (2 if nvox >= 512 else 1)
+        mtws = [m for m in (4, 2, 1) if m <= mtw0]
+    else:
+        mtws = [mtw]
     ntaps = len(cls.taps)
+    cands = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}, reverse=True)
     best = None
-    for ck in sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}, reverse=True):
-        ksteps = (ntaps * (ck // 8) + 3) // 4
-        lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw, es)
-        if lds <= lds_budget:
-            best = (ck, ksteps, lds)
-            break
-        if lds <= LDS_LIMIT - 1024 and best is None:
-            pass
-    if best is None:  # nothing fits the soft budget: take the largest chunk that fits the hard limit, preferring small
-        for ck in sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}):
-            ksteps = (ntaps * (ck // 8) + 3) // 4
-            lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw, es)
-            if lds <= LDS_LIMIT - 1024:
-                best = (ck, ksteps, lds)
+    for budget in (lds_budget, LDS_LIMIT - 1024):  # soft budget first (more resident workgroups), then whatever fits
+        for nsplit in sorted({nsplit0, min(nt_total, 2 * nsplit0), min(nt_total, 3 * nsplit0)}):  # fewer channel tiles per workgroup when the weights do not fit
+            nt = (nt_total + nsplit - 1) // nsplit
+            for mtw_ in mtws:  # a smaller voxel tile when even the smallest channel chunk does not fit (stride-2 3x3x3 halos in fp32)
+                if nt >= 5 and mtw_ == 4:
+                    continue
+                tile = choose_tile(q, cls.taps, 64 * mtw_)
+                for ck in cands:
+                    ksteps = (ntaps * (ck // 8) + 3) // 4
+                    lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw_, es, kc // ck, aux_es)
+                    if lds <= budget and igemm_halo_bytes(tile, cls.is_, cls.taps, ck, es) <= HALO_MAX:
+                        best = (ck, ksteps, lds, tile, mtw_, nt, nsplit)
+                        break
+                if best:
+                    break
+            if best:
                 break
+        if best:
+            break
     if best is None:
-        raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} tile={tile}")
-    ck, ksteps, lds = best
+        raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} q={q}")
+    ck, ksteps, lds, tile, mtw, nt, nsplit = best
     plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds)
     plan.pack_map = pack_map(plan, wshape)
     return plan
