@@ -64,6 +64,7 @@ typedef struct {
   const void* wpack;       /* [nsplit][nchunks][ksteps][nt][64 lanes][8] in the compute dtype (== in.dtype) */
   /* epilogue: v = acc + bias; stats(v); v = v*scale+shift; v = act(v); residual; accumulate; store */
   const float* bias;       /* [cout] or NULL */
+  const float* bias2;      /* second bias added to the first (merged 1x1x1 residual convolution) or NULL */
   const float* scale;      /* [cout] or NULL (eval-mode BatchNorm folded) */
   const float* shift;
   const float* alpha;      /* device pointer to the PReLU slope (1 element) */
@@ -102,7 +103,10 @@ int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d);
 int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream);
 
 /* dst[i] = map[i] >= 0 ? cast(src[map[i]]) : 0 — (re)packs the fp32 master weights into MFMA fragment order. */
-int vsseg_gather_cast(const float* src, const int32_t* map, void* dst, int64_t n, int32_t dst_dtype, void* stream);
+int vsseg_gather_cast(const float* src, const int32_t* map, const int32_t* map2 /* optional second addend, or NULL */, void* dst, int64_t n, int32_t dst_dtype, void* stream);
+/* A 1x1x1 residual convolution merged into the centre tap of the k-tap convolution it is added to (last_conv_only ResidualUnit,
+ * ref:params/networks/blocks/convolutions.py:217-255): its gradients are the centre-tap slice / the bias gradient of the merged conv. */
+int vsseg_merge_residual_grads(const float* dw, const float* db, float* dwr, float* dbr, int32_t cout, int32_t cin, int32_t ktaps, int32_t centre, void* stream);
 
 /* dst[n][x][y][z][0..cpad) <- src window (crop + zero-pad outside + zero-extend channels + cast). src is [N][SX][SY][SZ] f32, 1 channel.
  * Used for the network input (ref:params/VSparams.py:456) and for sliding-window crops (MONAI sliding_window_inference step 6). */

@@ -40,7 +40,7 @@ def pack(plan: P.IgemmPlan, w: torch.Tensor, dtype) -> torch.Tensor:
     wf = w.detach().to(torch.float32).reshape(-1).contiguous().cuda()
     m = torch.from_numpy(plan.pack_map).cuda()
     out = torch.zeros(m.numel(), dtype=dtype, device="cuda")
-    L.check(lib.vsseg_gather_cast(wf.data_ptr(), m.data_ptr(), out.data_ptr(), m.numel(), L.F32 if dtype == torch.float32 else L.BF16, stream()), "gather_cast")
+    L.check(lib.vsseg_gather_cast(wf.data_ptr(), m.data_ptr(), None, out.data_ptr(), m.numel(), L.F32 if dtype == torch.float32 else L.BF16, stream()), "gather_cast")
     return out
 
 

@@ -4,6 +4,8 @@
 pack-map entry fails here, without a GPU.  The expected values come from the convolution definitions themselves
 (torch.nn.functional on CPU and its autograd, the same calls the oracle makes).
 """
+import dataclasses
+
 import numpy as np
 import pytest
 import torch
@@ -116,3 +118,30 @@ def test_every_network_layer_has_a_feasible_plan():
                     assert plan.lds <= P.LDS_LIMIT and 1 <= plan.nt <= 6 and plan.mtw in (1, 2, 4)
             wp = P.plan_wgrad(L.transposed, wshape, L.kernel, L.stride, dims if L.transposed else od, es)
             assert wp.lds <= P.LDS_LIMIT and wp.ntp <= 6 and (wp.tile[0] * wp.tile[1] * wp.tile[2]) % 32 == 0
+
+
+def test_merged_residual_pack_map():
+    """conv_3x3x1(x; W) + conv_1x1x1(x; Wr) == one convolution whose packed weights are pack_map(W) + pack_map_centre(Wr) (fwd and dgrad)."""
+    torch.manual_seed(5)
+    k, s, cin, cout, dims = (3, 3, 1), (1, 1, 1), 32, 2, (8, 8, 4)
+    x = torch.randn(2, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w, wr = torch.randn(cout, cin, *k, dtype=torch.float64), torch.randn(cout, cin, 1, 1, 1, dtype=torch.float64)
+    y = F.conv3d(x, w, padding=P.same_pad(k)) + F.conv3d(x, wr)
+    flat = torch.cat([w.reshape(-1), wr.reshape(-1)]).numpy()
+    off_r = w.numel()
+
+    def merged(kind, inp_cl, out_shape, kc):
+        cls = P.lattice_classes(kind, k, s)[0]
+        plan = P.plan_igemm(kind, tuple(w.shape), cls, out_shape, es=2, kc_pad=kc)
+        m1, m2 = plan.pack_map, P.pack_map_centre(plan, tuple(wr.shape))
+        wpack = np.where(m1 >= 0, flat[np.clip(m1, 0, None)], 0.0) + np.where(m2 >= 0, flat[np.clip(m2 + off_r, 0, None)], 0.0)
+        ident = dataclasses.replace(plan)
+        ident.pack_map = np.arange(wpack.size, dtype=np.int32)
+        return P.simulate_igemm(ident, inp_cl, wpack, out_shape)
+
+    np.testing.assert_allclose(merged("conv_fwd", _cl(x.detach()), dims, cin), _cl(y.detach()), atol=1e-9)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gy_cl = np.zeros((2, *dims, 8))
+    gy_cl[..., :cout] = _cl(gy)
+    np.testing.assert_allclose(merged("conv_dgrad", gy_cl, dims, 8), _cl(x.grad), atol=1e-9)

@@ -40,6 +40,7 @@ class IgemmDesc(C.Structure):
         ("ksteps", C.c_int32),
         ("wpack", C.c_void_p),
         ("bias", C.c_void_p),
+        ("bias2", C.c_void_p),
         ("scale", C.c_void_p),
         ("shift", C.c_void_p),
         ("alpha", C.c_void_p),
@@ -77,7 +78,7 @@ class WgradDesc(C.Structure):
 
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -104,7 +105,8 @@ def lib():
         L.vsseg_igemm.argtypes = [C.POINTER(IgemmDesc), vp]
         L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
         L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
-        L.vsseg_gather_cast.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.vsseg_gather_cast.argtypes = [vp, vp, vp, vp, i64, i32, vp]
+        L.vsseg_merge_residual_grads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.vsseg_stage_input.argtypes = [vp, i32, I3, I3, Tensor, vp]
         L.vsseg_bn_finalize.argtypes = [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.vsseg_bn_fold_eval.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]

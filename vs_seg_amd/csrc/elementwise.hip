@@ -20,16 +20,21 @@ static inline int block_for_cgs(int cgs) {
 // ------------------------------------------------------------------------------------------------------------
 // gather-cast (weight packing), input staging, copies
 // ------------------------------------------------------------------------------------------------------------
-template <typename T> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ map, T* __restrict__ dst, int64_t n) {
+template <typename T> __global__ void gather_cast_kernel(const float* __restrict__ src, const int32_t* __restrict__ map, const int32_t* __restrict__ map2, T* __restrict__ dst, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int m = map[i];
-    Elem<T>::st(dst + i, m >= 0 ? src[m] : 0.f);
+    float v = m >= 0 ? src[m] : 0.f;
+    if (map2) {
+      int m2 = map2[i];
+      if (m2 >= 0) v += src[m2];
+    }
+    Elem<T>::st(dst + i, v);
   }
 }
-extern "C" int vsseg_gather_cast(const float* src, const int32_t* map, void* dst, int64_t n, int32_t dst_dtype, void* stream) {
+extern "C" int vsseg_gather_cast(const float* src, const int32_t* map, const int32_t* map2, void* dst, int64_t n, int32_t dst_dtype, void* stream) {
   VSSEG_CHECK(src && map && dst && n >= 0, "vsseg_gather_cast: bad arguments");
   if (n == 0) return VSSEG_OK;
-  DISPATCH_T(dst_dtype, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), src, map, (T*)dst, n));
+  DISPATCH_T(dst_dtype, hipLaunchKernelGGL(gather_cast_kernel<T>, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), src, map, map2, (T*)dst, n));
   VSSEG_LAUNCH_CHECK("vsseg_gather_cast");
   return VSSEG_OK;
 }
@@ -441,6 +446,18 @@ extern "C" int vsseg_channel_sum(vsseg_tensor t, float* out, void* stream) {
   int grid = grid_for(nv * cgs, blk, 2048);
   DISPATCH_T(t.dtype, hipLaunchKernelGGL(channel_sum_kernel<T>, dim3(grid), dim3(blk), cgs * 8 * sizeof(float), as_stream(stream), (const T*)t.ptr, t.pitch, t.c, cgs, nv, out));
   VSSEG_LAUNCH_CHECK("vsseg_channel_sum");
+  return VSSEG_OK;
+}
+
+__global__ void merge_residual_grads_kernel(const float* dw, const float* db, float* dwr, float* dbr, int cout, int cin, int ktaps, int centre) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cout * cin) dwr[i] += dw[(int64_t)i * ktaps + centre];
+  if (i < cout) dbr[i] += db[i];
+}
+extern "C" int vsseg_merge_residual_grads(const float* dw, const float* db, float* dwr, float* dbr, int32_t cout, int32_t cin, int32_t ktaps, int32_t centre, void* stream) {
+  VSSEG_CHECK(dw && db && dwr && dbr && cout > 0 && cin > 0 && centre >= 0 && centre < ktaps, "vsseg_merge_residual_grads: bad arguments");
+  hipLaunchKernelGGL(merge_residual_grads_kernel, dim3((cout * cin + 255) / 256), dim3(256), 0, as_stream(stream), dw, db, dwr, dbr, cout, cin, ktaps, centre);
+  VSSEG_LAUNCH_CHECK("vsseg_merge_residual_grads");
   return VSSEG_OK;
 }
 

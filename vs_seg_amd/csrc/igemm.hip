@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
   for (int i = tid; i < NT * 16; i += 256) {
     const int c = split * NT * 16 + i;
     const bool ok = c < cout;
-    epi[i] = (ok && d.bias) ? d.bias[c] : 0.f;
+    epi[i] = ((ok && d.bias) ? d.bias[c] : 0.f) + ((ok && d.bias2) ? d.bias2[c] : 0.f);
     epi[NT * 16 + i] = (ok && d.scale) ? d.scale[c] : 1.f;
     epi[2 * NT * 16 + i] = (ok && d.scale) ? d.shift[c] : 0.f;
   }
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
     }
     arel[u] = rel;
   }
-  const bool fast_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0 && ((d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on);
+  const bool fast_store = (d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on;
+  const bool vec_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0;
   const int64_t aux_sample_bytes = (int64_t)OX * OY * OZ * aux_vox_bytes;
 
   // ---- tile schedule: XCD x (= blockIdx % 8) owns tiles [x*tpx, (x+1)*tpx); its workgroups stride through them ----
@@ -371,8 +372,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             }
           }
-          if (out_es == 4) st4(reinterpret_cast<float*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
-          else st4(reinterpret_cast<bf16_t*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+          if (vec_store) {
+            if (out_es == 4) st4(reinterpret_cast<float*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+            else st4(reinterpret_cast<bf16_t*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+          } else {  // 1- and 2-channel outputs (attention map, logits): scalar stores of the valid channels
+            const int nc = min(4, cout - c);
+            for (int r = 0; r < nc; ++r) {
+              if (out_es == 4) reinterpret_cast<float*>(op)[c + r] = val[r];
+              else reinterpret_cast<bf16_t*>(op)[c + r] = f2bf(val[r]);
+            }
+          }
         }
       }
       continue;

@@ -25,14 +25,24 @@ struct WgradK {
   int p_row;      // bytes per P row in LDS
   int lds_hbase, lds_p, lds_h;
   int64_t total_tiles;
+  const void* zeros;  // >= 16 zero bytes in global memory (source of out-of-bounds pieces)
   float* slab;     // [gridDim.x][hchunks][ntaps][ntp*16][16] partial sums
   int slab_chunk;  // ntaps * ntp*16 * 16
 };
+
+typedef __attribute__((address_space(1))) const void wg_gvoid_t;
+typedef __attribute__((address_space(3))) void wg_lvoid_t;
+__device__ __forceinline__ void wg_dma16(const void* gsrc, char* lds_wave_base) {  // LDS address = wave-uniform base + lane*16
+  __builtin_amdgcn_global_load_lds((wg_gvoid_t*)gsrc, (wg_lvoid_t*)lds_wave_base, 16, 0, 0);
+}
+constexpr int WPP = 12;  // 16-byte pieces of the P tile per thread  (P tile <= 48 KiB)
+constexpr int WPH = 8;   // ... of the H halo tile per thread         (halo    <= 32 KiB)
 
 template <typename T, int MAXT, int NTP>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
+  constexpr int EPP = 16 / ES;
   constexpr int HROW = 16 * ES;  // bytes per halo row (16 channels)
   const vsseg_wgrad_desc& d = k.d;
   int* hbase = reinterpret_cast<int*>(smem + k.lds_hbase);
@@ -40,9 +50,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   char* Hl = smem + k.lds_h;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int wt = wave % k.wt, wv = wave / k.wt;
-  const int HY = k.halo[1], HZ = k.halo[2];
-  const int hvox = k.halo[0] * HY * HZ;
+  const int HX = k.halo[0], HY = k.halo[1], HZ = k.halo[2];
+  const int hvox = HX * HY * HZ;
   const int chunk = blockIdx.y;
+  const int p_bytes = k.tvox * k.p_row, h_bytes = hvox * HROW;
 
   for (int v = tid; v < k.tvox; v += 256) {
     int vz = v % d.tile[2], r = v / d.tile[2];
@@ -61,88 +72,134 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
     for (int p = 0; p < NTP; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const T* Pg = reinterpret_cast<const T*>(d.p.ptr);
-  const T* Hg = reinterpret_cast<const T*>(d.h.ptr);
-  const int PC = NTP * 16;
-  const int ksteps = k.tvox / 32;
+  // ---- per-thread constants of the two DMA tiles (same scheme as igemm.hip: tile-independent part precomputed once) ----
+  const int PX = d.p.x, PY = d.p.y, PZ = d.p.z, QX = d.h.x, QY = d.h.y, QZ = d.h.z;
+  const unsigned p_vox_bytes = (unsigned)d.p.pitch * ES, h_vox_bytes = (unsigned)d.h.pitch * ES;
+  const int ppp = k.p_row >> 4;   // 16-byte pieces per P voxel row (NTP*16 channels)
+  const int ppieces = k.tvox * ppp;
+  const int hpieces = hvox * ES;  // 16 channels = ES pieces of 16 B
+  unsigned pinfo[WPP], prel[WPP], hinfo[WPH], hrel[WPH];
+#pragma unroll
+  for (int u = 0; u < WPP; ++u) {
+    const int j = (u * 4 + wave) * 64 + lane;
+    unsigned info = 0xffffffffu, rel = 0;
+    if (j < ppieces) {
+      const int v = j / ppp, c16 = j - v * ppp;
+      int vz = v % d.tile[2], r = v / d.tile[2];
+      int vy = r % d.tile[1], vx = r / d.tile[1];
+      const bool cok = c16 * EPP + EPP <= d.p.c;  // channels beyond the tensor are zero-filled
+      info = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
+      rel = (unsigned)((vx * PY + vy) * PZ + vz) * p_vox_bytes + (unsigned)c16 * 16u;
+    }
+    pinfo[u] = info;
+    prel[u] = rel;
+  }
+#pragma unroll
+  for (int u = 0; u < WPH; ++u) {
+    const int j = (u * 4 + wave) * 64 + lane;
+    unsigned info = 0xffffffffu, rel = 0;
+    if (j < hpieces) {
+      const int hv = j / ES, c16 = j - hv * ES;
+      int hz = hv % HZ, r = hv / HZ;
+      int hy = r % HY, hx = r / HY;
+      const bool cok = chunk * 16 + c16 * EPP + EPP <= d.h.c;
+      info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
+      rel = (unsigned)((hx * QY + hy) * QZ + hz) * h_vox_bytes + (unsigned)c16 * 16u;
+    }
+    hinfo[u] = info;
+    hrel[u] = rel;
+  }
+  const bool p_chan_ok = NTP * 16 <= d.p.c, h_chan_ok = chunk * 16 + 16 <= d.h.c;  // every piece has real channels (fast path)
+  const char* p_base = reinterpret_cast<const char*>(d.p.ptr);
+  const char* h_base = reinterpret_cast<const char*>(d.h.ptr) + (int64_t)chunk * 16 * ES;
+  const int64_t p_sample = (int64_t)PX * PY * PZ * p_vox_bytes, h_sample = (int64_t)QX * QY * QZ * h_vox_bytes;
 
-  for (int64_t tile = blockIdx.x; tile < k.total_tiles; tile += gridDim.x) {
-    int64_t b = tile;
-    const int tz = (int)(b % k.ntile[2]); b /= k.ntile[2];
-    const int ty = (int)(b % k.ntile[1]); b /= k.ntile[1];
-    const int tx = (int)(b % k.ntile[0]);
-    const int n = (int)(b / k.ntile[0]);
-    const int q0x = tx * d.tile[0], q0y = ty * d.tile[1], q0z = tz * d.tile[2];
-    __syncthreads();
-    {  // P tile [tvox][NTP*16], zero outside the lattice / beyond the valid channels.  Loads are issued in batches of U
-       // before any LDS store so that U global loads per thread are in flight (the staging is latency-, not bandwidth-bound).
-      constexpr int U = 4;
-      constexpr int V16 = ES == 2 ? 1 : 2;  // 16-byte pieces per 8-channel group
-      const int cgs = PC / 8, items = k.tvox * cgs;
-      for (int base = 0; base < items; base += 256 * U) {
-        uint4 val[U][V16];
-        int dsto[U];
+  struct TileIdx { int tz, ty, tx, n; };
+  auto tile_decode = [&](int b) {
+    TileIdx t;
+    t.tz = b % k.ntile[2]; b /= k.ntile[2];
+    t.ty = b % k.ntile[1]; b /= k.ntile[1];
+    t.tx = b % k.ntile[0];
+    t.n = b / k.ntile[0];
+    return t;
+  };
+  const int G = gridDim.x;
+  const TileIdx step = tile_decode(G);
+  auto tile_advance = [&](TileIdx& t) {
+    t.tz += step.tz; if (t.tz >= k.ntile[2]) { t.tz -= k.ntile[2]; ++t.ty; }
+    t.ty += step.ty; if (t.ty >= k.ntile[1]) { t.ty -= k.ntile[1]; ++t.tx; }
+    t.tx += step.tx; if (t.tx >= k.ntile[0]) { t.tx -= k.ntile[0]; ++t.n; }
+    t.n += step.n;
+  };
+  TileIdx t_issue = tile_decode((int)blockIdx.x);
+  const int my_tiles = (int)blockIdx.x < (int)k.total_tiles ? ((int)k.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+
+  auto issue = [&](int s) {  // LDS-DMA of tile s into buffer s&1
+    const int n = t_issue.n, q0x = t_issue.tx * d.tile[0], q0y = t_issue.ty * d.tile[1], q0z = t_issue.tz * d.tile[2];
+    tile_advance(t_issue);
+    char* Pdst = Pl + (s & 1) * p_bytes;
+    char* Hdst = Hl + (s & 1) * h_bytes;
+    {
+      const char* sample = p_base + (int64_t)n * p_sample;
+      const bool interior = q0x + d.tile[0] <= d.q[0] && q0y + d.tile[1] <= d.q[1] && q0z + d.tile[2] <= d.q[2] && p_chan_ok;
+      if (interior) {
+        const char* origin = sample + (int64_t)((q0x * PY + q0y) * PZ + q0z) * p_vox_bytes;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = base + u * 256 + tid;
-          const int ii = min(i, items - 1);
-          int v = ii / cgs, cg = ii - v * cgs;
-          int vz = v % d.tile[2], r = v / d.tile[2];
-          int vy = r % d.tile[1], vx = r / d.tile[1];
-          int qx = q0x + vx, qy = q0y + vy, qz = q0z + vz;
-          const bool ok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && cg * 8 + 8 <= d.p.c;
-          dsto[u] = i < items ? v * k.p_row + cg * 8 * ES : -1;
-          const T* src = ok ? Pg + ((((int64_t)n * d.p.x + qx) * d.p.y + qy) * d.p.z + qz) * d.p.pitch + cg * 8 : Pg;
+        for (int u = 0; u < WPP; ++u) {
+          if ((u * 4 + wave) * 64 >= ppieces) break;
+          if (pinfo[u] != 0xffffffffu) wg_dma16(origin + prel[u], Pdst + (u * 4 + wave) * 1024);
+        }
+      } else {
 #pragma unroll
-          for (int w = 0; w < V16; ++w) {
-            uint4 x = reinterpret_cast<const uint4*>(src)[w];
-            val[u][w] = ok ? x : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < WPP; ++u) {
+          if ((u * 4 + wave) * 64 >= ppieces) break;
+          const unsigned info = pinfo[u];
+          if (info != 0xffffffffu) {
+            const int qx = q0x + (int)(info & 255u), qy = q0y + (int)((info >> 8) & 255u), qz = q0z + (int)((info >> 16) & 255u);
+            const unsigned c16 = info >> 24;
+            const bool ok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && c16 != 255u;
+            const void* src = ok ? (const void*)(sample + (int64_t)((qx * PY + qy) * PZ + qz) * p_vox_bytes + c16 * 16u) : k.zeros;
+            wg_dma16(src, Pdst + (u * 4 + wave) * 1024);
           }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (dsto[u] >= 0) {
-#pragma unroll
-            for (int w = 0; w < V16; ++w) reinterpret_cast<uint4*>(Pl + dsto[u])[w] = val[u][w];
-          }
       }
     }
-    {  // H halo tile [hvox][16] for this workgroup's channel chunk
-      constexpr int U = 4;
-      constexpr int V16 = ES == 2 ? 1 : 2;
+    {
+      const char* sample = h_base + (int64_t)n * h_sample;
       const int gx0 = q0x * d.hs[0] + k.off_min[0], gy0 = q0y * d.hs[1] + k.off_min[1], gz0 = q0z * d.hs[2] + k.off_min[2];
-      const int items = hvox * 2;
-      for (int base = 0; base < items; base += 256 * U) {
-        uint4 val[U][V16];
-        int dsto[U];
+      const bool interior = gx0 >= 0 && gy0 >= 0 && gz0 >= 0 && gx0 + HX <= QX && gy0 + HY <= QY && gz0 + HZ <= QZ && h_chan_ok;
+      if (interior) {
+        const char* origin = sample + (int64_t)((gx0 * QY + gy0) * QZ + gz0) * h_vox_bytes;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int i = base + u * 256 + tid;
-          const int ii = min(i, items - 1);
-          int hv = ii >> 1, cg = ii & 1;
-          int hz = hv % HZ, r = hv / HZ;
-          int hy = r % HY, hx = r / HY;
-          int gx = gx0 + hx, gy = gy0 + hy, gz = gz0 + hz;
-          const int c = chunk * 16 + cg * 8;
-          const bool ok = (unsigned)gx < (unsigned)d.h.x && (unsigned)gy < (unsigned)d.h.y && (unsigned)gz < (unsigned)d.h.z && c + 8 <= d.h.c;
-          dsto[u] = i < items ? hv * HROW + cg * 8 * ES : -1;
-          const T* src = ok ? Hg + ((((int64_t)n * d.h.x + gx) * d.h.y + gy) * d.h.z + gz) * d.h.pitch + c : Hg;
+        for (int u = 0; u < WPH; ++u) {
+          if ((u * 4 + wave) * 64 >= hpieces) break;
+          if (hinfo[u] != 0xffffffffu) wg_dma16(origin + hrel[u], Hdst + (u * 4 + wave) * 1024);
+        }
+      } else {
 #pragma unroll
-          for (int w = 0; w < V16; ++w) {
-            uint4 x = reinterpret_cast<const uint4*>(src)[w];
-            val[u][w] = ok ? x : make_uint4(0, 0, 0, 0);
+        for (int u = 0; u < WPH; ++u) {
+          if ((u * 4 + wave) * 64 >= hpieces) break;
+          const unsigned info = hinfo[u];
+          if (info != 0xffffffffu) {
+            const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
+            const unsigned c16 = info >> 24;
+            const bool ok = (unsigned)gx < (unsigned)QX && (unsigned)gy < (unsigned)QY && (unsigned)gz < (unsigned)QZ && c16 != 255u;
+            const void* src = ok ? (const void*)(sample + (int64_t)((gx * QY + gy) * QZ + gz) * h_vox_bytes + c16 * 16u) : k.zeros;
+            wg_dma16(src, Hdst + (u * 4 + wave) * 1024);
           }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (dsto[u] >= 0) {
-#pragma unroll
-            for (int w = 0; w < V16; ++w) reinterpret_cast<uint4*>(Hl + dsto[u])[w] = val[u][w];
-          }
       }
     }
-    __syncthreads();
+  };
 
+  const int ksteps = k.tvox / 32;
+  if (my_tiles > 0) issue(0);
+  for (int s = 0; s < my_tiles; ++s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile s landed for every wave; every wave is done reading tile s-1's buffers
+    if (s + 1 < my_tiles) issue(s + 1);
+    const char* Ps = Pl + (s & 1) * p_bytes;
+    const char* Hs = Hl + (s & 1) * h_bytes;
     for (int ks = wv; ks < ksteps; ks += k.wv) {
       if constexpr (ES == 2) {
         // lane (g, i=l15): rows r=i>>2 of two 4-voxel blocks, 4-channel column chunk q=i&3
@@ -153,32 +210,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
         for (int p = 0; p < NTP; ++p) {
           typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Pl + v0 * k.p_row + p * 32 + qc));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Pl + v1 * k.p_row + p * 32 + qc));
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Ps + v0 * k.p_row + p * 32 + qc));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Ps + v1 * k.p_row + p * 32 + qc));
           pa[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
           if (toff[i] < 0) continue;
           typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hl + h0 + toff[i]));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hl + h1 + toff[i]));
+          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h0 + toff[i]));
+          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h1 + toff[i]));
           bf16x8 hb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
           for (int p = 0; p < NTP; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[p], hb, acc[i][p], 0, 0, 0);
         }
       } else {
 #pragma unroll 2
-        for (int s = 0; s < 8; ++s) {
-          const int v = ks * 32 + s * 4 + g;
+        for (int ss = 0; ss < 8; ++ss) {
+          const int v = ks * 32 + ss * 4 + g;
           const int hb0 = hbase[v] * HROW + l15 * 4;
           float pa[NTP];
 #pragma unroll
-          for (int p = 0; p < NTP; ++p) pa[p] = *reinterpret_cast<const float*>(Pl + v * k.p_row + (p * 16 + l15) * 4);
+          for (int p = 0; p < NTP; ++p) pa[p] = *reinterpret_cast<const float*>(Ps + v * k.p_row + (p * 16 + l15) * 4);
 #pragma unroll
           for (int i = 0; i < MAXT; ++i) {
             if (toff[i] < 0) continue;
-            const float hb = *reinterpret_cast<const float*>(Hl + hb0 + toff[i]);
+            const float hb = *reinterpret_cast<const float*>(Hs + hb0 + toff[i]);
 #pragma unroll
             for (int p = 0; p < NTP; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[p], hb, acc[i][p], 0, 0, 0);
           }
@@ -219,17 +276,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, in
   }
 }
 
-template <typename T, int MAXT, int NTP> static int wg_launch(const WgradK& k, dim3 grid, int lds, hipStream_t s) {
+template <typename T, int MAXT, int NTP> static int wg_launch(WgradK& k, dim3& grid, int lds, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, MAXT, NTP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  // persistent grid: never more workgroups than are resident at once (a late workgroup would be a serial tail)
+  static int cached_lds = -1, cached_per_cu = 1;
+  if (cached_lds != lds) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<T, MAXT, NTP>, 256, lds) != hipSuccess || n < 1) n = 1;
+    cached_per_cu = n > 4 ? 4 : n;
+    cached_lds = lds;
+  }
+  unsigned cap = (unsigned)(256 * cached_per_cu) / grid.y;
+  if (cap < 1) cap = 1;
+  if (grid.x > cap) grid.x = cap;
   hipLaunchKernelGGL((wgrad_kernel<T, MAXT, NTP>), grid, dim3(256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad");
   return VSSEG_OK;
 }
-template <typename T, int MAXT> static int wg_ntp(const WgradK& k, dim3 grid, int lds, hipStream_t s) {
+template <typename T, int MAXT> static int wg_ntp(WgradK& k, dim3& grid, int lds, hipStream_t s) {
   switch (k.d.ntp) {
     case 1: return wg_launch<T, MAXT, 1>(k, grid, lds, s);
     case 2: return wg_launch<T, MAXT, 2>(k, grid, lds, s);
@@ -241,7 +309,7 @@ template <typename T, int MAXT> static int wg_ntp(const WgradK& k, dim3 grid, in
   vsseg_set_error("vsseg_wgrad: ntp must be 1..6 (got %d)", k.d.ntp);
   return VSSEG_EINVAL;
 }
-template <typename T> static int wg_maxt(const WgradK& k, int maxt, dim3 grid, int lds, hipStream_t s) {
+template <typename T> static int wg_maxt(WgradK& k, int maxt, dim3& grid, int lds, hipStream_t s) {
   if (maxt <= 1) return wg_ntp<T, 1>(k, grid, lds, s);
   if (maxt <= 3) return wg_ntp<T, 3>(k, grid, lds, s);
   if (maxt <= 7) return wg_ntp<T, 7>(k, grid, lds, s);
@@ -275,8 +343,17 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   k.p_row = d->ntp * 16 * es;
   int off = 0;
   k.lds_hbase = off; off += ((k.tvox * 4 + 15) / 16) * 16;
-  k.lds_p = off; off += k.tvox * k.p_row;
-  k.lds_h = off; off += k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
+  k.lds_p = off; off += 2 * k.tvox * k.p_row;                          // double-buffered: tile s+1 streams in by LDS-DMA while tile s is multiplied
+  k.lds_h = off; off += 2 * k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
+  VSSEG_CHECK(k.tvox * k.p_row <= WPP * 256 * 16 && k.halo[0] * k.halo[1] * k.halo[2] * 16 * es <= WPH * 256 * 16, "vsseg_wgrad: tile too large for the DMA piece budget");
+  for (int a = 0; a < 3; ++a) VSSEG_CHECK(k.halo[a] <= 255 && d->tile[a] <= 255, "vsseg_wgrad: tile/halo extent > 255");
+  {
+    static void* z = nullptr;
+    if (!z && (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess)) z = nullptr;
+    VSSEG_CHECK(z, "vsseg_wgrad: could not allocate the zero page");
+    k.zeros = z;
+  }
+  VSSEG_CHECK(k.total_tiles < (1ll << 31), "vsseg_wgrad: too many tiles");
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_wgrad: needs %d bytes of LDS (> 160 KiB); reduce the tile", off);
   const int hchunks = (d->ch_valid + 15) / 16;
   k.slab_chunk = d->ntaps * d->ntp * 16 * 16;
@@ -291,7 +368,7 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   int rc = d->p.dtype == VSSEG_F32 ? wg_maxt<float>(k, maxt, grid, off, as_stream(stream)) : wg_maxt<bf16_t>(k, maxt, grid, off, as_stream(stream));
   if (rc) return rc;
   const int total = hchunks * k.slab_chunk;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)d->scratch, (int)gx, hchunks, d->ntaps, d->ntp * 16, k.slab_chunk, *d);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)d->scratch, (int)grid.x, hchunks, d->ntaps, d->ntp * 16, k.slab_chunk, *d);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
   return VSSEG_OK;
 }

@@ -142,11 +142,31 @@ class Plan:
             self._map_len += m.size
             return off
 
+        # a 1x1x1 residual conv added to a plain (no BatchNorm) conv of the same input merges into that conv's centre tap
+        plain = {op.out.name: op for op in eng.prog.ops if isinstance(op, ConvPlain)}
+        self.merged: Dict[str, ConvPlain] = {}  # residual-conv prefix -> the convolution that absorbed it
+        self.absorbs: Dict[str, ConvPlain] = {}  # absorbing conv prefix -> the residual conv op
+        for op in eng.prog.ops:
+            if isinstance(op, ConvPlain) and op.res is not None and op.act == "none" and op.res.name in plain:
+                a = plain[op.res.name]
+                if a.x is op.x and a.act == "none" and a.layer.kernel == (1, 1, 1) and all(k % 2 == 1 for k in op.layer.kernel):
+                    self.merged[a.layer.prefix] = op
+                    self.absorbs[op.layer.prefix] = a
+        maps2: List[np.ndarray] = []
+
+        def add_map2(m2, param_off2, n):
+            maps2.append(np.full(n, -1, np.int32) if m2 is None else np.where(m2 >= 0, m2 + param_off2, -1).astype(np.int32))
+
         self.cplans: Dict[str, _ConvPlans] = {}
         for op in eng.prog.ops:
             if not isinstance(op, (ConvBnAct, ConvPlain)):
                 continue
             Lr = op.layer
+            if Lr.prefix in self.merged:
+                self.cplans[Lr.prefix] = _ConvPlans([], [], None)
+                continue
+            absorbed = self.absorbs.get(Lr.prefix)
+            woff2 = eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0
             woff = eng.layout.param_off[Lr.wkey][0]
             dims_in = self.lv[Lr.level]
             kind = "convT_fwd" if Lr.transposed else "conv_fwd"
@@ -154,9 +174,10 @@ class Plan:
             assert dims_out == self.lv[Lr.out_level]
             fwd, dgrad, wg = [], [], None
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
-                aux_es = 0 if op.res is None else (4 if op.res.kind == 'f32' else eng.es)
+                aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
                 pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c, aux_es=aux_es)
                 fwd.append((pl, add_map(pl.pack_map, woff)))
+                add_map2(P.pack_map_centre(pl, absorbed.layer.wshape) if absorbed is not None else None, woff2, pl.pack_map.size)
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
@@ -164,12 +185,15 @@ class Plan:
                         q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
                         pl = P.plan_igemm(dk, Lr.wshape, cls, q, eng.es, kc_pad=P.round_up(Lr.cout, 8), aux_es=eng.es)
                         dgrad.append((pl, add_map(pl.pack_map, woff)))
+                        add_map2(P.pack_map_centre(pl, absorbed.layer.wshape) if absorbed is not None else None, woff2, pl.pack_map.size)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg)
         self.pack_map = torch.from_numpy(np.concatenate(maps)).to(eng.device)
+        self.pack_map2 = torch.from_numpy(np.concatenate(maps2)).to(eng.device) if self.absorbs else None
+        assert self.pack_map2 is None or self.pack_map2.numel() == self.pack_map.numel()
         self.wpack = torch.zeros(self._map_len, dtype=eng.tdtype, device=eng.device)
 
-    def _igemm(self, lst, pl: P.IgemmPlan, woff: int, inp: L.Tensor, out: L.Tensor, *, bias=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
+    def _igemm(self, lst, pl: P.IgemmPlan, woff: int, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
                res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
         d = L.IgemmDesc()
         d.inp, d.out = inp, out
@@ -180,7 +204,7 @@ class Plan:
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps
         d.wpack = self.wpack.data_ptr() + self.eng.es * woff
-        d.bias, d.scale, d.shift, d.alpha = bias or None, scale or None, shift or None, alpha or None
+        d.bias, d.bias2, d.scale, d.shift, d.alpha = bias or None, bias2 or None, scale or None, shift or None, alpha or None
         d.act, d.res_mode, d.accumulate = act, res_mode, accumulate
         if res is not None:
             d.res = res
@@ -243,10 +267,14 @@ class Plan:
                                     res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
+                if Lr.prefix in self.merged:  # computed inside the convolution it is added to
+                    continue
+                absorbed = self.absorbs.get(Lr.prefix)
                 xin, out = self._desc(op.x), self._desc(op.out)
-                res = self._desc(op.res) if op.res is not None else None
+                res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for pl, woff in cp.fwd:
-                    self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), act=ACT_CODE[op.act], res=res, res_mode=L.RES_ADD if res is not None else L.RES_NONE)
+                    self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
+                                res_mode=L.RES_ADD if res is not None else L.RES_NONE)
             elif isinstance(op, AttGate):
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
@@ -347,6 +375,12 @@ class Plan:
                 conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
             elif isinstance(op, ConvPlain):
                 Lr = op.layer
+                if Lr.prefix in self.merged:  # gradients of a merged residual conv = centre-tap slice / bias gradient of the absorbing conv
+                    big = self.merged[Lr.prefix].layer
+                    kx, ky, kz = big.kernel
+                    centre = ((kx // 2) * ky + ky // 2) * kz + kz // 2
+                    B.append([lib.vsseg_merge_residual_grads, [self._gp(big.wkey), self._gp(big.bkey), self._gp(Lr.wkey), self._gp(Lr.bkey), Lr.cout, Lr.cin, kx * ky * kz, centre]])
+                    continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
                 conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name))
@@ -378,7 +412,8 @@ class Plan:
             args[i] = glogits if slot.kind == "glogits" else gatt.get(slot.name)
 
     def pack_weights(self, stream):
-        L.check(self.eng.lib.vsseg_gather_cast(self.eng.flat.data_ptr(), self.pack_map.data_ptr(), self.wpack.data_ptr(), self.pack_map.numel(), L.BF16 if self.eng.es == 2 else L.F32, stream), "gather_cast")
+        m2 = self.pack_map2.data_ptr() if self.pack_map2 is not None else None
+        L.check(self.eng.lib.vsseg_gather_cast(self.eng.flat.data_ptr(), self.pack_map.data_ptr(), m2, self.wpack.data_ptr(), self.pack_map.numel(), L.BF16 if self.eng.es == 2 else L.F32, stream), "gather_cast")
 
     def run(self, lst, stream):
         if self.timer is not None:

@@ -230,6 +230,24 @@ def pack_map(plan: IgemmPlan, wshape) -> np.ndarray:
     return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
 
 
+def pack_map_centre(plan: IgemmPlan, wshape_1x1) -> np.ndarray:
+    """Gather map (same layout as `pack_map`) that places a 1x1x1 convolution's weights on the zero-offset tap of `plan`
+    and -1 elsewhere: adding it to the plan's own map merges `conv_k(x) + conv_1x1(x)` into one convolution."""
+    kreal, nreal = gemm_dims(plan.kind, wshape_1x1)
+    cgs = plan.ck // 8
+    S, CH, KS, NT = plan.nsplit, plan.nchunks, plan.ksteps, plan.nt
+    split, ch, ks, t, lane, j = np.meshgrid(np.arange(S), np.arange(CH), np.arange(KS), np.arange(NT), np.arange(64), np.arange(8), indexing="ij")
+    p = ks * 4 + (lane >> 4)
+    tap = p // cgs
+    c = ch * plan.ck + (p % cgs) * 8 + j
+    n = (split * NT + t) * 16 + (lane & 15)
+    centre = [i for i, (off, _) in enumerate(plan.cls.taps) if tuple(off) == (0, 0, 0)]
+    assert len(centre) == 1, "the merged residual needs exactly one zero-offset tap"
+    valid = (tap == centre[0]) & (c < kreal) & (n < nreal)
+    flat = weight_flat_index(plan.kind, wshape_1x1, np.where(valid, c, 0), np.where(valid, n, 0), 0)
+    return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
+
+
 def out_dims(kind, in_dims, kernel, stride):
     pad = same_pad(kernel)
     if kind == "conv_fwd":
@@ -320,8 +338,9 @@ def plan_wgrad(transposed: bool, wshape, kernel, stride, lattice_dims, es, cp_va
         for a in range(3):
             offs = [t[0][a] for t in taps]
             halo *= (tile[a] - 1) * stride[a] + (max(offs) - min(offs) + 1)
-        lds = round_up(tv * 4, 16) + tv * ntp * 16 * es + halo * 16 * es
-        if lds <= LDS_LIMIT - 1024:
+        p_bytes, h_bytes = tv * ntp * 16 * es, halo * 16 * es
+        lds = round_up(tv * 4, 16) + 2 * p_bytes + 2 * h_bytes  # double-buffered tiles (LDS-DMA pipeline), mirrors vsseg_wgrad()
+        if lds <= LDS_LIMIT - 1024 and p_bytes <= 12 * 256 * 16 and h_bytes <= 8 * 256 * 16:
             break
     else:
         raise ValueError("no LDS-feasible wgrad tile")
