@@ -210,7 +210,7 @@ def main():
     tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tfile):
         try:
-            roof["traffic"] = json.load(open(tfile)).get(dominant)
+            roof["traffic"] = (json.load(open(tfile)).get(dominant) or {}).get("hbm_bytes_per_launch")  # PMC FETCH_SIZE(x2)+WRITE_SIZE, see profiles/
         except Exception:
             pass
     res = {

@@ -17,6 +17,18 @@ def short(name):
     return name.split("(")[0]
 
 
+def bench_name(short_name):
+    """rocprof kernel name -> the name bench.py uses for its roofline block (igemm<bf16,NT,MTW>, wgrad<bf16,NTP>)."""
+    import re
+    m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+)>", short_name)
+    if m:
+        return f"igemm<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(2)},{m.group(3)}>"
+    m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)>", short_name)
+    if m:
+        return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
+    return short_name
+
+
 def kernel_stats(db):
     cur = sqlite3.connect(db).cursor()
     rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc"))
@@ -40,7 +52,17 @@ def pmc(fetch_db, write_db):
         f = 2.0 * d.get("fetch_kib_per_launch", 0.0) * 1024 / 1e6
         w = d.get("write_kib_per_launch", 0.0) * 1024 / 1e6
         print(f"{n[:60]:60s} {d.get('launches', 0):8d} {f:32.2f} {w:16.2f}")
-        res[n] = dict(fetch_mb=f, write_mb=w, launches=d.get("launches", 0))
+        key = bench_name(n)
+        if key in res:  # several rocprof instantiations map to one bench name (wgrad MAXT variants): launch-weighted mean
+            o = res[key]
+            tot = o["launches"] + d.get("launches", 0)
+            o["fetch_mb"] = (o["fetch_mb"] * o["launches"] + f * d.get("launches", 0)) / max(tot, 1)
+            o["write_mb"] = (o["write_mb"] * o["launches"] + w * d.get("launches", 0)) / max(tot, 1)
+            o["launches"] = tot
+        else:
+            res[key] = dict(fetch_mb=f, write_mb=w, launches=d.get("launches", 0))
+    for v in res.values():
+        v["hbm_bytes_per_launch"] = (v["fetch_mb"] + v["write_mb"]) * 1e6
     return res
 
 

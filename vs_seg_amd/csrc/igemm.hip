@@ -38,7 +38,47 @@ struct IgemmK {
   vsseg_tensor aux;
   int64_t total_tiles;
   const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
+  const struct TileDesc* tiles;
 };
+
+// Per-tile descriptor, computed once per (geometry) by a setup kernel and cached: the main kernel fetches it with one scalar
+// load per stage instead of re-deriving tile coordinates, origins and boundary flags from ~40 uniform values (which made
+// hipcc spill ~500 SGPRs per kernel and left the HBM-bound layers instruction-issue-bound).
+struct __attribute__((aligned(64))) TileDesc {
+  int64_t in_vox;   // voxel index (incl. batch) of the halo origin inside the input tensor (meaningful when interior)
+  int64_t out_vox;  // voxel index (incl. batch) of the tile's first output voxel
+  int32_t g0[3];    // halo origin coordinates (may be negative)
+  int32_t q0[3];    // lattice origin of the tile
+  int32_t n;
+  int32_t flags;    // bit 0: halo entirely inside the input; bit 1: tile entirely inside lattice and output
+};
+
+__global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab) {
+  const vsseg_igemm_desc& d = k.d;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < k.total_tiles; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = t;
+    const int tz = (int)(b % k.ntile[2]); b /= k.ntile[2];
+    const int ty = (int)(b % k.ntile[1]); b /= k.ntile[1];
+    const int tx = (int)(b % k.ntile[0]);
+    const int n = (int)(b / k.ntile[0]);
+    TileDesc td;
+    td.n = n;
+    td.q0[0] = tx * d.tile[0]; td.q0[1] = ty * d.tile[1]; td.q0[2] = tz * d.tile[2];
+    bool interior = true, whole = true;
+    const int dims_in[3] = {d.in.x, d.in.y, d.in.z}, dims_out[3] = {d.out.x, d.out.y, d.out.z};
+    int o0[3];
+    for (int a = 0; a < 3; ++a) {
+      td.g0[a] = td.q0[a] * d.is[a] + k.off_min[a];
+      interior = interior && td.g0[a] >= 0 && td.g0[a] + k.halo[a] <= dims_in[a];
+      o0[a] = td.q0[a] * d.os[a] + d.oo[a];
+      whole = whole && td.q0[a] + d.tile[a] <= d.q[a] && (td.q0[a] + d.tile[a] - 1) * d.os[a] + d.oo[a] < dims_out[a];
+    }
+    td.in_vox = (((int64_t)n * d.in.x + td.g0[0]) * d.in.y + td.g0[1]) * d.in.z + td.g0[2];
+    td.out_vox = (((int64_t)n * d.out.x + o0[0]) * d.out.y + o0[1]) * d.out.z + o0[2];
+    td.flags = (interior ? 1 : 0) | (whole ? 2 : 0);
+    tab[t] = td;
+  }
+}
 
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
@@ -74,7 +114,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
 }
 
 template <typename T, int NT, int MTW>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
+__global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const IgemmK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int GB = 8 * ES;   // bytes of one 8-channel group
@@ -179,7 +219,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
   }
   const bool fast_store = (d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on;
   const bool vec_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0;
-  const int64_t aux_sample_bytes = (int64_t)OX * OY * OZ * aux_vox_bytes;
 
   // ---- tile schedule: XCD x (= blockIdx % 8) owns tiles [x*tpx, (x+1)*tpx); its workgroups stride through them ----
   const int G = gridDim.x;
@@ -196,44 +235,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
 
   const char* in_base = reinterpret_cast<const char*>(d.in.ptr);
   const int64_t in_sample_bytes = (int64_t)X * Y * Z * in_vox_bytes;
-  const int64_t out_sample_bytes = (int64_t)OX * OY * OZ * out_vox_bytes;
 
-  // tile coordinates advance by S tiles per step: add the precomputed (sz, sy, sx, sn) digits with carries, no division in the loop
-  struct TileIdx { int tz, ty, tx, n; };
-  auto tile_decode = [&](int b) {
-    TileIdx t;
-    t.tz = b % k.ntile[2]; b /= k.ntile[2];
-    t.ty = b % k.ntile[1]; b /= k.ntile[1];
-    t.tx = b % k.ntile[0];
-    t.n = b / k.ntile[0];
-    return t;
-  };
-  const TileIdx step = tile_decode(S);
-  auto tile_advance = [&](TileIdx& t) {
-    t.tz += step.tz; if (t.tz >= k.ntile[2]) { t.tz -= k.ntile[2]; ++t.ty; }
-    t.ty += step.ty; if (t.ty >= k.ntile[1]) { t.ty -= k.ntile[1]; ++t.tx; }
-    t.tx += step.tx; if (t.tx >= k.ntile[0]) { t.tx -= k.ntile[0]; ++t.n; }
-    t.n += step.n;
-  };
-  TileIdx t_issue = tile_decode(t_first + slot), t_cur = t_issue;
+  const TileDesc* tiles = k.tiles + (t_first + slot);  // this workgroup's tiles: tiles[i * S]
+  // descriptors are fetched (scalar loads) one tile ahead of their first use, so their latency never sits in front of a DMA issue
+  TileDesc td_next = tiles[0];  // descriptor of the next tile to be issued
+  TileDesc td_cur = td_next;    // descriptor of the tile whose epilogue comes next
+  TileDesc td_pre = td_next;    // descriptor of the most recently issued tile
+  int ti_issue = 0;
   int ch_issue = 0, ch_cur = 0, par_issue = 0, par_cur = 0;
   auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
-    const int ch = ch_issue, n = t_issue.n;
-    const int qx = t_issue.tx * d.tile[0], qy = t_issue.ty * d.tile[1], qz = t_issue.tz * d.tile[2];
-    if (++ch_issue == nch) { ch_issue = 0; tile_advance(t_issue); }
-    const int gx0 = qx * d.is[0] + k.off_min[0], gy0 = qy * d.is[1] + k.off_min[1], gz0 = qz * d.is[2] + k.off_min[2];
+    const int ch = ch_issue;
+    const TileDesc td = td_next;
+    if (ch == 0) td_pre = td;
+    if (++ch_issue == nch) {
+      ch_issue = 0;
+      ++ti_issue;
+      if (ti_issue < my_tiles) td_next = tiles[(int64_t)ti_issue * S];  // uniform address: scalar loads, consumed a whole stage later
+    }
     const int c0 = ch * CK;
     char* Hdst = Hl + (s & 1) * k.h_bytes;
-    const char* sample = in_base + (int64_t)n * in_sample_bytes + (int64_t)c0 * ES;
-    const bool interior = gx0 >= 0 && gy0 >= 0 && gz0 >= 0 && gx0 + k.halo[0] <= X && gy0 + k.halo[1] <= Y && gz0 + k.halo[2] <= Z && c0 + CK <= d.in.c;
+    const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
     if (interior) {
-      const char* origin = sample + (int64_t)((gx0 * Y + gy0) * Z + gz0) * in_vox_bytes;
+      const char* origin = in_base + td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
 #pragma unroll
       for (int u = 0; u < PMAX; ++u) {
         if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
         if (pinfo[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
       }
     } else {
+      const int gx0 = td.g0[0], gy0 = td.g0[1], gz0 = td.g0[2];
+      const char* sample = in_base + (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
 #pragma unroll
       for (int u = 0; u < PMAX; ++u) {
         if ((u * 4 + wave) * 64 >= pieces) break;
@@ -248,11 +279,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
       }
     }
     if (aux_on && ch == 0) {
-      const int ox0 = qx * d.os[0] + d.oo[0], oy0 = qy * d.os[1] + d.oo[1], oz0 = qz * d.os[2] + d.oo[2];
-      const bool whole = qx + d.tile[0] <= d.q[0] && qy + d.tile[1] <= d.q[1] && qz + d.tile[2] <= d.q[2] && (qx + d.tile[0] - 1) * d.os[0] + d.oo[0] < OX &&
-                         (qy + d.tile[1] - 1) * d.os[1] + d.oo[1] < OY && (qz + d.tile[2] - 1) * d.os[2] + d.oo[2] < OZ;
-      if (whole) {  // partial tiles use the slow epilogue (ordinary loads)
-        const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + (int64_t)n * aux_sample_bytes + (int64_t)((ox0 * OY + oy0) * OZ + oz0) * aux_vox_bytes;
+      if (td.flags & 2) {  // partial tiles use the slow epilogue (ordinary loads)
+        const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + td.out_vox * aux_vox_bytes;
         char* Adst = Al + par_issue * k.aux_bytes;
 #pragma unroll
         for (int u = 0; u < AMAX; ++u) {
@@ -291,53 +319,77 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
     }
     const char* Hs = Hl + (s & 1) * k.h_bytes;
     const char* Ws = nch > 1 ? Wl + (s & 1) * k.w_bytes : Wl;
-    {  // K loop, software-pipelined by hand: the fragments of K-step ks+1 are read from LDS before the MFMAs of ks issue
-       // (with 1-2 waves per SIMD nothing else hides the ds_read -> MFMA latency; hipcc does not pipeline this loop itself)
-      Frag<T> wn[NT], an[MTW];
+    if constexpr (NT <= 2) {
+      // HBM-bound configurations (<= 32 output channels per workgroup): plain K loop — two resident workgroups per CU hide the
+      // LDS latency, and the registers of a second fragment set would cost that second workgroup
       const char* Wlane = Ws + lane * GB;
+      for (int ks = 0; ks < d.ksteps; ++ks) {
+        const int koff = ktab[ks * 4 + g];
+        Frag<T> w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = Frag<T>::ld(Wlane + (ks * NT + t) * 64 * GB);
+#pragma unroll
+        for (int m = 0; m < MTW; ++m) {
+          Frag<T> a = Frag<T>::ld(Hs + vb[m] + koff);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) mma(acc[m][t], w[t], a);
+        }
+      }
+    } else
+    {  // K loop, software-pipelined by hand with two fragment sets (no register moves): the fragments of K-step ks+1 are
+       // read from LDS before the MFMAs of ks issue (with 1-2 waves per SIMD nothing else hides the ds_read -> MFMA latency)
+      Frag<T> w0[NT], a0[MTW], w1[NT], a1[MTW];
+      const char* Wlane = Ws + lane * GB;
+      const int nks = d.ksteps;
       {
         const int koff = ktab[g];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wn[t] = Frag<T>::ld(Wlane + t * 64 * GB);
+        for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + t * 64 * GB);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) an[m] = Frag<T>::ld(Hs + vb[m] + koff);
+        for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
       }
-      for (int ks = 0; ks < d.ksteps; ++ks) {
-        Frag<T> w[NT], a[MTW];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) w[t] = wn[t];
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) a[m] = an[m];
-        if (ks + 1 < d.ksteps) {
+      for (int ks = 0; ks < nks; ks += 2) {
+        const bool has1 = ks + 1 < nks;
+        if (has1) {
           const int koff = ktab[(ks + 1) * 4 + g];
 #pragma unroll
-          for (int t = 0; t < NT; ++t) wn[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
+          for (int t = 0; t < NT; ++t) w1[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) an[m] = Frag<T>::ld(Hs + vb[m] + koff);
+          for (int m = 0; m < MTW; ++m) a1[m] = Frag<T>::ld(Hs + vb[m] + koff);
         }
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) mma(acc[m][t], w[t], a[m]);
+          for (int t = 0; t < NT; ++t) mma(acc[m][t], w0[t], a0[m]);
+        if (has1) {
+          if (ks + 2 < nks) {
+            const int koff = ktab[(ks + 2) * 4 + g];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + ((ks + 2) * NT + t) * 64 * GB);
+#pragma unroll
+            for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
+          }
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) mma(acc[m][t], w1[t], a1[m]);
+        }
       }
     }
     if (++ch_cur != nch) continue;
     ch_cur = 0;
 
     // ---- epilogue of the current tile ----
-    const int n = t_cur.n, q0x = t_cur.tx * d.tile[0], q0y = t_cur.ty * d.tile[1], q0z = t_cur.tz * d.tile[2];
-    tile_advance(t_cur);
-    const int ox0 = q0x * d.os[0] + d.oo[0], oy0 = q0y * d.os[1] + d.oo[1], oz0 = q0z * d.os[2] + d.oo[2];
-    const unsigned tile_vox = (unsigned)((ox0 * OY + oy0) * OZ + oz0);  // first output voxel of the tile inside sample n
-    const bool whole = q0x + d.tile[0] <= d.q[0] && q0y + d.tile[1] <= d.q[1] && q0z + d.tile[2] <= d.q[2] && (q0x + d.tile[0] - 1) * d.os[0] + d.oo[0] < OX &&
-                       (q0y + d.tile[1] - 1) * d.os[1] + d.oo[1] < OY && (q0z + d.tile[2] - 1) * d.os[2] + d.oo[2] < OZ;
-    char* out_sample = reinterpret_cast<char*>(d.out.ptr) + (int64_t)n * out_sample_bytes;
+    const TileDesc tc = td_cur;
+    td_cur = td_pre;  // the tile being prefetched (if any) is the next one to finish
+    const bool whole = (tc.flags & 2) != 0;
+    char* out_tile = reinterpret_cast<char*>(d.out.ptr) + tc.out_vox * out_vox_bytes;
     const char* Aux = Al + par_cur * k.aux_bytes;
     par_cur ^= 1;
     if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
-        char* op = out_sample + (tile_vox + ovrel[m]) * out_vox_bytes;
+        char* op = out_tile + ovrel[m] * out_vox_bytes;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int cl = t * 16 + g * 4;
@@ -386,6 +438,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmK k) {
       }
       continue;
     }
+    const int n = tc.n, q0x = tc.q0[0], q0y = tc.q0[1], q0z = tc.q0[2];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
       const int qx = q0x + (int)(vxyz[m] & 255u), qy = q0y + (int)((vxyz[m] >> 8) & 255u), qz = q0z + (int)(vxyz[m] >> 16);
@@ -506,6 +559,22 @@ template <typename T> static int launch_nt(const IgemmK& k, dim3 grid, int lds, 
   return VSSEG_EINVAL;
 }
 
+#include <map>
+#include <vector>
+static const TileDesc* tile_table(const IgemmK& k, hipStream_t stream) {
+  static std::map<std::vector<int64_t>, TileDesc*> cache;
+  const vsseg_igemm_desc& d = k.d;
+  std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles};
+  for (int a = 0; a < 3; ++a) { key.push_back(d.q[a]); key.push_back(d.tile[a]); key.push_back(d.is[a]); key.push_back(d.os[a]); key.push_back(d.oo[a]); key.push_back(k.off_min[a]); key.push_back(k.halo[a]); }
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  TileDesc* tab = nullptr;
+  if (hipMalloc(&tab, sizeof(TileDesc) * k.total_tiles) != hipSuccess) return nullptr;
+  hipLaunchKernelGGL(igemm_tile_setup_kernel, dim3((unsigned)((k.total_tiles + 255) / 256 > 1024 ? 1024 : (k.total_tiles + 255) / 256)), dim3(256), 0, stream, k, tab);
+  cache[key] = tab;
+  return tab;
+}
+
 static const void* zero_page() {
   static void* z = nullptr;
   if (!z) {
@@ -574,6 +643,8 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   k.zeros = zero_page();
   VSSEG_CHECK(k.zeros, "vsseg_igemm: could not allocate the zero page");
   VSSEG_CHECK(k.total_tiles > 0 && k.total_tiles < (1ll << 31), "vsseg_igemm: bad tile count");
+  k.tiles = tile_table(k, as_stream(stream));
+  VSSEG_CHECK(k.tiles, "vsseg_igemm: could not allocate the tile table");
   dim3 grid(1, (unsigned)d->nsplit);  // grid.x is set to the resident workgroup count by launch<>()
   if (d->in.dtype == VSSEG_F32) return launch_nt<float>(k, grid, lds, as_stream(stream));
   return launch_nt<bf16_t>(k, grid, lds, as_stream(stream));
