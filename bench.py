@@ -66,8 +66,7 @@ def cpu_baseline(budget_s=25.0):
     """The oracle (CPU restatement, pinned to the reference's goldens) timed on the host cores: one fwd+loss+bwd+Adam step, batch 1."""
     from oracle import vsseg_oracle as O
 
-    torch.set_num_threads(max(1, os.cpu_count() // 2 if (os.cpu_count() or 1) > 16 else (os.cpu_count() or 1)))
-    cores = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
     sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in O.seeded_state_dict(True, 0).items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-4, weight_decay=1e-7)
@@ -85,8 +84,19 @@ def cpu_baseline(budget_s=25.0):
         opt.step()
         return time.perf_counter() - t0
 
-    step((64, 64, 32))  # warm the thread pool / allocator
-    t_small = step((128, 128, 32))
+    # "all host cores" is not the fastest setting for this oracle on a 2-socket box (thread oversubscription of small convolutions):
+    # calibrate a few thread counts on a 128x128x32 patch and keep the fastest — the baseline should be the CPU's best effort
+    best = None
+    for nt in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu // 2, ncpu)}):
+        if nt < 1:
+            continue
+        torch.set_num_threads(nt)
+        step((64, 64, 32))
+        ts = step((128, 128, 32))
+        if best is None or ts < best[0]:
+            best = (ts, nt)
+    t_small, cores = best
+    torch.set_num_threads(cores)
     est_full = t_small * (PATCH[0] * PATCH[1] * PATCH[2]) / (128 * 128 * 32)
     if est_full <= budget_s * 1.6:
         shape = PATCH
@@ -200,13 +210,16 @@ def main():
     if rank != 0:
         return
     peak = PEAK[args.dtype]
-    if dom["kind"] == "mfma" and dom["flops"] > 0:
+    ridge = peak * 1e12 / 8e12  # FLOP per byte at which the MFMA roof meets the 8 TB/s HBM roof
+    ai = dom["flops"] / dom["bytes"] if dom["bytes"] else float("inf")
+    if dom["kind"] == "mfma" and dom["flops"] > 0 and ai >= ridge:
         ach = dom["flops"] / dom["ms"] / 1e9
         roof = dict(bound="mfma", kernel=dominant, achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, traffic=None, launches=dom["n"], avg_launch_ms=dom["ms"] / dom["n"],
-                    alg_gflop_per_launch=dom["flops"] / dom["n"] / 1e9)
-    else:
+                    alg_gflop_per_launch=dom["flops"] / dom["n"] / 1e9, alg_flop_per_byte=ai)
+    else:  # the dominant kernel's launches sit left of the ridge (16/32-channel full-resolution layers): HBM is the roof
         ach = dom["bytes"] / dom["ms"] / 1e6
-        roof = dict(bound="hbm", kernel=dominant, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None, launches=dom["n"], avg_launch_ms=dom["ms"] / dom["n"])
+        roof = dict(bound="hbm", kernel=dominant, achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0, traffic=None, launches=dom["n"], avg_launch_ms=dom["ms"] / dom["n"],
+                    alg_bytes_per_launch=dom["bytes"] / dom["n"], alg_gflop_per_launch=dom["flops"] / dom["n"] / 1e9, alg_flop_per_byte=ai if ai != float("inf") else None)
     tfile = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     if os.path.exists(tfile):
         try:

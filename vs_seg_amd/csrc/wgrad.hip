@@ -270,8 +270,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, in
     const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
     const int ch = chunk * 16 + l15;
     if (cp >= d.cp_valid || ch >= d.ch_valid) continue;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += slab[((int64_t)b * hchunks + chunk) * slab_chunk + r];
+    // 8 independent partial sums keep 8 loads in flight (a single dependent chain made this kernel cost as much as a wgrad tile pass)
+    float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float* p = slab + (int64_t)chunk * slab_chunk + r;
+    const int64_t bstride = (int64_t)hchunks * slab_chunk;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8[j] += p[(b + j) * bstride];
+    }
+    for (; b < nblk; ++b) s8[0] += p[b * bstride];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap] += s;
   }
 }
