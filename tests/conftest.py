@@ -16,3 +16,22 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def poison_device_memory():
+    """On a GPU box, fill the caching allocator's pools with NaN bit patterns before any test runs: a kernel that reads a
+    buffer nobody initialised (torch.empty, padded channels, scratch) then fails on every box, not only on one whose HBM
+    happens to hold a previous job's data."""
+    try:
+        import torch
+    except ImportError:
+        yield
+        return
+    if torch.cuda.is_available() and os.environ.get("VSSEG_NO_POISON") != "1":
+        big = [torch.full((1 << 28,), float("nan"), device="cuda") for _ in range(8)]   # 8 x 1 GiB (large pool)
+        mid = [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(256)]  # 1 MiB blocks
+        small = [torch.full((1 << 12,), float("nan"), device="cuda") for _ in range(2048)]  # small pool
+        torch.cuda.synchronize()
+        del big, mid, small
+    yield

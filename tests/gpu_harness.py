@@ -52,7 +52,7 @@ def igemm_desc(plan: P.IgemmPlan, wpack: torch.Tensor, inp: L.Tensor, out: L.Ten
     for t, (off, _) in enumerate(plan.cls.taps):
         d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
     d.tile = L.i3(plan.tile)
-    d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps = plan.mtw, plan.nt, plan.nsplit, plan.ck, plan.nchunks, plan.ksteps
+    d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = plan.mtw, plan.nt, plan.nsplit, plan.ck, plan.nchunks, plan.ksteps, plan.depth
     d.wpack = wpack.data_ptr()
     for k, v in kw.items():
         setattr(d, k, v)

@@ -108,7 +108,10 @@ def _check_grads(m, sd, rel, robust=False):
             err = float((got - ref).norm() / (ref.norm() + 1e-30))
         else:
             err = float((got - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
-        if err > (5 * rel if (robust and got.numel() == 1) else rel):  # PReLU slopes: one heavily cancelling scalar sum each
+        # PReLU slopes: one heavily cancelling scalar sum over a whole activation tensor each.  They are the worst entries of
+        # the fp32-vs-fp64 comparison of the CPU oracle with itself too (2-3e-4 there, everything else <= 3e-5), and the
+        # summation order of the HIP reductions moves them around 1-2e-3 from box to box -> 5x allowance for scalars.
+        if err > (5 * rel if got.numel() == 1 else rel):
             bad.append((k, err))
     assert not bad, f"{len(bad)} parameter gradients off: {sorted(bad, key=lambda t: -t[1])[:8]}"
     gf, rf = torch.cat(gf), torch.cat(rf)

@@ -32,7 +32,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--stats", action="store_true")
-    ap.add_argument("--lds-budget", type=int, default=64 * 1024)
+    ap.add_argument("--lds-budget", type=int, default=158 * 1024)
+    ap.add_argument("--depth", type=int, default=0)
     a = ap.parse_args()
     dt = H.DT[a.dtype]
     es = 2 if a.dtype == "bf16" else 4
@@ -51,6 +52,9 @@ def main():
         plan = dataclasses.replace(plan, tile=tile, ck=ck, nchunks=plan.kc // ck, ksteps=ksteps, mtw=tile[0] * tile[1] * tile[2] // 64)
         plan.pack_map = P.pack_map(plan, tuple(w.shape))
         plan.lds = P.igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, plan.nt, plan.mtw, es, plan.kc // ck)
+    if a.depth:
+        plan.depth = a.depth
+        plan.lds = P.igemm_lds_bytes(plan.tile, cls.is_, cls.taps, plan.ck, plan.ksteps, plan.nt, plan.mtw, es, plan.nchunks, 0, a.depth)
     x = torch.randn(a.batch, *a.dims, P.round_up(a.cin, 8), device="cuda").to(dt)
     out = torch.zeros(a.batch, *odims, a.cout, dtype=dt, device="cuda")
     wp = H.pack(plan, w, dt)
@@ -73,7 +77,7 @@ def main():
     nvox = a.batch * odims[0] * odims[1] * odims[2]
     flops = 2.0 * nvox * plan.ntaps * a.cin * a.cout
     byts = es * (x.numel() / x.shape[-1] * a.cin + nvox * a.cout)
-    print(f"tile={plan.tile} mtw={plan.mtw} nt={plan.nt} ck={plan.ck} ks={plan.ksteps} lds={plan.lds}  {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s  {byts / ms / 1e6:.0f} GB/s(alg)")
+    print(f"tile={plan.tile} mtw={plan.mtw} nt={plan.nt} ck={plan.ck} ks={plan.ksteps} D={plan.depth} lds={plan.lds}  {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s  {byts / ms / 1e6:.0f} GB/s(alg)")
 
 
 if __name__ == "__main__":

@@ -38,6 +38,7 @@ class IgemmDesc(C.Structure):
         ("ck", C.c_int32),
         ("nchunks", C.c_int32),
         ("ksteps", C.c_int32),
+        ("depth", C.c_int32),
         ("wpack", C.c_void_p),
         ("bias", C.c_void_p),
         ("bias2", C.c_void_p),

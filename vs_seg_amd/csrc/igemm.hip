@@ -35,6 +35,7 @@ struct IgemmK {
   int lds_ktab, lds_epi, lds_w, lds_h, lds_aux;
   int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask: the aux tile is prefetched by DMA like the halo
   int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (0: aux handled by the slow path)
+  int depth;      // prefetch distance in stages (1..3); the LDS rings hold depth+1 buffers
   vsseg_tensor aux;
   int64_t total_tiles;
   const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
@@ -111,6 +112,20 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 // 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_wave_base, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the immediate must be a literal.  Waiting for a SMALLER count than
+// necessary is always safe (it only waits longer), so n is clamped to the largest literal provided.
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define VSSEG_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n < 0 ? 0 : (n > 40 ? 40 : n)) {
+    VSSEG_VM_CASE(0) VSSEG_VM_CASE(1) VSSEG_VM_CASE(2) VSSEG_VM_CASE(3) VSSEG_VM_CASE(4) VSSEG_VM_CASE(5) VSSEG_VM_CASE(6) VSSEG_VM_CASE(7) VSSEG_VM_CASE(8) VSSEG_VM_CASE(9)
+    VSSEG_VM_CASE(10) VSSEG_VM_CASE(11) VSSEG_VM_CASE(12) VSSEG_VM_CASE(13) VSSEG_VM_CASE(14) VSSEG_VM_CASE(15) VSSEG_VM_CASE(16) VSSEG_VM_CASE(17) VSSEG_VM_CASE(18) VSSEG_VM_CASE(19)
+    VSSEG_VM_CASE(20) VSSEG_VM_CASE(21) VSSEG_VM_CASE(22) VSSEG_VM_CASE(23) VSSEG_VM_CASE(24) VSSEG_VM_CASE(25) VSSEG_VM_CASE(26) VSSEG_VM_CASE(27) VSSEG_VM_CASE(28) VSSEG_VM_CASE(29)
+    VSSEG_VM_CASE(30) VSSEG_VM_CASE(31) VSSEG_VM_CASE(32) VSSEG_VM_CASE(33) VSSEG_VM_CASE(34) VSSEG_VM_CASE(35) VSSEG_VM_CASE(36) VSSEG_VM_CASE(37) VSSEG_VM_CASE(38) VSSEG_VM_CASE(39)
+    VSSEG_VM_CASE(40)
+  }
+#undef VSSEG_VM_CASE
 }
 
 template <typename T, int NT, int MTW>
@@ -239,21 +254,28 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   const TileDesc* tiles = k.tiles + (t_first + slot);  // this workgroup's tiles: tiles[i * S]
   // descriptors are fetched (scalar loads) one tile ahead of their first use, so their latency never sits in front of a DMA issue
   TileDesc td_next = tiles[0];  // descriptor of the next tile to be issued
-  TileDesc td_cur = td_next;    // descriptor of the tile whose epilogue comes next
-  TileDesc td_pre = td_next;    // descriptor of the most recently issued tile
-  int ti_issue = 0;
-  int ch_issue = 0, ch_cur = 0, par_issue = 0, par_cur = 0;
+  int ti_issue = 0, ti_cur = 0;
+  int ch_issue = 0, ch_cur = 0;
+  const int D = k.depth, nbuf = D + 1;
+  int buf_issue = 0, buf_cur = 0, abuf_issue = 0, abuf_cur = 0;  // ring positions (stage ring / per-tile auxiliary ring)
+  // VMEM instructions this wave issues per stage: the counted waits below rely on these being exact and wave-uniform
+  int nh = 0, na = 0, nw = 0;
+#pragma unroll
+  for (int u = 0; u < PMAX; ++u) nh += ((u * 4 + wave) * 64 < pieces) ? 1 : 0;
+#pragma unroll
+  for (int u = 0; u < AMAX; ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
+  if (nch > 1)
+    for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
   auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
     const int ch = ch_issue;
     const TileDesc td = td_next;
-    if (ch == 0) td_pre = td;
     if (++ch_issue == nch) {
       ch_issue = 0;
       ++ti_issue;
       if (ti_issue < my_tiles) td_next = tiles[(int64_t)ti_issue * S];  // uniform address: scalar loads, consumed a whole stage later
     }
     const int c0 = ch * CK;
-    char* Hdst = Hl + (s & 1) * k.h_bytes;
+    char* Hdst = Hl + buf_issue * k.h_bytes;
     const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
     if (interior) {
       const char* origin = in_base + td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
@@ -279,23 +301,25 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
       }
     }
     if (aux_on && ch == 0) {
-      if (td.flags & 2) {  // partial tiles use the slow epilogue (ordinary loads)
-        const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + td.out_vox * aux_vox_bytes;
-        char* Adst = Al + par_issue * k.aux_bytes;
+      // partial tiles use the slow epilogue (ordinary loads) but still issue the same number of DMAs (from the zero page),
+      // so that the per-stage instruction count the vmcnt arithmetic relies on stays exact
+      const bool whole = (td.flags & 2) != 0;
+      const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + td.out_vox * aux_vox_bytes;
+      char* Adst = Al + abuf_issue * k.aux_bytes;
 #pragma unroll
-        for (int u = 0; u < AMAX; ++u) {
-          if ((u * 4 + wave) * 64 >= apieces) break;
-          if (arel[u] != 0xffffffffu) dma16(aorigin + arel[u], Adst + (u * 4 + wave) * 1024);
-        }
+      for (int u = 0; u < AMAX; ++u) {
+        if ((u * 4 + wave) * 64 >= apieces) break;
+        if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(aorigin + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
       }
-      par_issue ^= 1;
+      if (++abuf_issue == nbuf) abuf_issue = 0;
     }
     if (nch > 1) {
       const char* wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
-      char* Wdst = Wl + (s & 1) * k.w_bytes;
+      char* Wdst = Wl + buf_issue * k.w_bytes;
       for (int j0 = wave * 64; j0 < wpieces; j0 += 256)
         if (j0 + lane < wpieces) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);
     }
+    if (++buf_issue == nbuf) buf_issue = 0;
   };
 
   f32x4 acc[MTW][NT];
@@ -305,11 +329,25 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
 #pragma unroll
     for (int r = 0; r < 4; ++r) ssum[t][r] = ssq[t][r] = 0.f;
 
-  if (nstages > 0) issue(0);
+  __syncthreads();  // tables / resident weights / epilogue constants written above are visible before the pipeline starts
+  for (int j = 0; j < D && j < nstages; ++j) issue(j);  // stages 0..D-1 in flight
   for (int s = 0; s < nstages; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage s has landed (this wave's pieces) ...
-    __syncthreads();                                  // ... and everybody's; everybody is also done with stage s-1's buffers
-    if (s + 1 < nstages) issue(s + 1);
+    // Stage s has landed once at most the DMAs of the younger stages s+1..s+D-1 remain (VMEM ops complete in issue order).  The
+    // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
+    if (D == 1) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      int younger = 0, chj = ch_cur;
+      for (int j = 1; j < D && s + j < nstages; ++j) {
+        if (++chj == nch) chj = 0;
+        younger += nh + nw + (chj == 0 ? na : 0);
+      }
+      wait_vmcnt(younger);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring
+    if (s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
+    const TileDesc tc = tiles[(int64_t)ti_cur * S];  // this stage's tile (scalar load, consumed in the epilogue)
     const int ch = ch_cur;
     if (ch == 0) {
 #pragma unroll
@@ -317,8 +355,9 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const char* Hs = Hl + (s & 1) * k.h_bytes;
-    const char* Ws = nch > 1 ? Wl + (s & 1) * k.w_bytes : Wl;
+    const char* Hs = Hl + buf_cur * k.h_bytes;
+    const char* Ws = nch > 1 ? Wl + buf_cur * k.w_bytes : Wl;
+    if (++buf_cur == nbuf) buf_cur = 0;
     if constexpr (NT <= 2) {
       // HBM-bound configurations (<= 32 output channels per workgroup): plain K loop — two resident workgroups per CU hide the
       // LDS latency, and the registers of a second fragment set would cost that second workgroup
@@ -380,12 +419,11 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     ch_cur = 0;
 
     // ---- epilogue of the current tile ----
-    const TileDesc tc = td_cur;
-    td_cur = td_pre;  // the tile being prefetched (if any) is the next one to finish
+    ++ti_cur;
     const bool whole = (tc.flags & 2) != 0;
     char* out_tile = reinterpret_cast<char*>(d.out.ptr) + tc.out_vox * out_vox_bytes;
-    const char* Aux = Al + par_cur * k.aux_bytes;
-    par_cur ^= 1;
+    const char* Aux = Al + abuf_cur * k.aux_bytes;
+    if (++abuf_cur == nbuf) abuf_cur = 0;
     if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
@@ -436,8 +474,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
           }
         }
       }
-      continue;
-    }
+    } else {
     const int n = tc.n, q0x = tc.q0[0], q0y = tc.q0[1], q0z = tc.q0[2];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
@@ -487,6 +524,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
         }
       }
     }
+    }  // slow epilogue
   }
 
   if (d.stats) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics
@@ -624,9 +662,11 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   int off = 0;
   k.lds_ktab = off; off += ((d->ksteps * 4 * 4 + 15) / 16) * 16;
   k.lds_epi = off; off += 3 * d->nt * 16 * 4;
-  k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? 2 : 1);
-  k.lds_h = off; off += 2 * k.h_bytes;
-  k.lds_aux = off; off += 2 * k.aux_bytes;
+  k.depth = d->depth < 1 ? 1 : (d->depth > 3 ? 3 : d->depth);
+  const int nbuf = k.depth + 1;
+  k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? nbuf : 1);
+  k.lds_h = off; off += nbuf * k.h_bytes;
+  k.lds_aux = off; off += nbuf * k.aux_bytes;
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }

@@ -202,7 +202,7 @@ class Plan:
         for t, (off, _) in enumerate(pl.cls.taps):
             d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
         d.tile = L.i3(pl.tile)
-        d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps
+        d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
         d.wpack = self.wpack.data_ptr() + self.eng.es * woff
         d.bias, d.bias2, d.scale, d.shift, d.alpha = bias or None, bias2 or None, scale or None, shift or None, alpha or None
         d.act, d.res_mode, d.accumulate = act, res_mode, accumulate
@@ -214,7 +214,7 @@ class Plan:
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
-        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ks={pl.ksteps} lds={pl.lds}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ks={pl.ksteps} D={pl.depth} lds={pl.lds}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 

@@ -110,6 +110,7 @@ class IgemmPlan:
     nchunks: int
     ksteps: int
     lds: int
+    depth: int = 1
     pack_map: np.ndarray = field(repr=False, default=None)  # int32, -1 = zero
 
     @property
@@ -128,11 +129,12 @@ def igemm_halo_bytes(tile, is_, taps, ck, es):
     return halo * ck * es
 
 
-def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=4):
+def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=4, depth=1):
     """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers."""
     w = ksteps * nt * 64 * 8 * es
-    aux = 2 * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread), double-buffered
-    return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (2 if nchunks > 1 else 1) + 2 * igemm_halo_bytes(tile, is_, taps, ck, es) + aux
+    nbuf = depth + 1
+    aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
+    return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * igemm_halo_bytes(tile, is_, taps, ck, es) + aux
 
 
 def _pow2_floor(v):
@@ -203,7 +205,9 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
     if best is None:
         raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} q={q}")
     ck, ksteps, lds, tile, mtw, nt, nsplit = best
-    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds)
+    depth = 1  # deeper rings (2-3 stages ahead) measured slower: they cost the second resident workgroup, and two workgroups per CU
+    #            overlapping each other's compute/epilogue chain matter more than extra bytes in flight (tools/bench_igemm.py --depth)
+    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds, depth)
     plan.pack_map = pack_map(plan, wshape)
     return plan
 
