@@ -7,9 +7,9 @@
  * and return 0 or a negative VSSEG_E* code (text via vsseg_last_error()).
  *
  * Data layout: activations are channels-last [N][X][Y][Z][C] ("NDHWC", identical to torch.channels_last_3d strides
- * of a [N,C,X,Y,Z] tensor) described by vsseg_tensor; `pitch` lets a tensor be a channel slice of a wider buffer so
- * that the skip-connection concat (MONAI SkipConnection, ref:params/networks/nets/unet2d5_spvPA.py:89) is never
- * materialised by a copy.
+ * of a [N,C,X,Y,Z] tensor) described by vsseg_tensor; `pitch` lets a tensor be a channel slice of a wider buffer, and
+ * `ptr2/csplit` let it be the concatenation of two dense tensors, so that the skip-connection concat (MONAI
+ * SkipConnection, ref:params/networks/nets/unet2d5_spvPA.py:89) is never materialised by a copy.
  */
 #ifndef VSSEG_HIP_H
 #define VSSEG_HIP_H
@@ -41,8 +41,16 @@ typedef struct {
   void* ptr;     /* first element of the view (channel offset already applied) */
   int32_t dtype; /* VSSEG_F32 | VSSEG_BF16 */
   int32_t c;     /* channels in the view */
-  int32_t pitch; /* elements between consecutive voxels (>= c) */
+  int32_t pitch; /* elements between consecutive voxels (>= c, or >= max(csplit, c - csplit) for a two-part tensor) */
   int32_t n, x, y, z;
+  /* Two-part tensors (the skip-connection concat, ref:params/networks/nets/unet2d5_spvPA.py:89 / MONAI SkipConnection):
+   * channels [0, csplit) live at ptr, channels [csplit, c) at ptr2, both with the same pitch — the concat is the pair of
+   * its (dense) operands and is never materialised.  ptr2 == NULL: ordinary tensor.  csplit must be a multiple of 16.
+   * Accepted by vsseg_igemm (in, out, res), vsseg_wgrad (h) and vsseg_att_apply_fwd/bwd (x, dx); every other entry point
+   * rejects it with VSSEG_EINVAL. */
+  void* ptr2;
+  int32_t csplit;
+  int32_t reserved;
 } vsseg_tensor;
 
 /* One implicit-GEMM launch over an output lattice q in [0,q): out[q*os+oo][n] = epi( sum_t sum_c in[q*is+off_t][c] * W[t][c][n] ).

@@ -59,18 +59,27 @@ def igemm_desc(plan: P.IgemmPlan, wpack: torch.Tensor, inp: L.Tensor, out: L.Ten
     return d
 
 
-def run_lattice_op(kind, w, x_cl: torch.Tensor, out_cl: torch.Tensor, stride, **epi):
-    """Run every lattice class of a conv-like op; x_cl/out_cl are channels-last device tensors."""
+def two_part(a: torch.Tensor, b: torch.Tensor) -> L.Tensor:
+    """Descriptor of the channel concatenation [a | b] of two dense channels-last tensors (nothing is copied)."""
+    return L.Tensor.two_part(tdesc(a), tdesc(b))
+
+
+def run_lattice_op(kind, w, x_cl, out_cl, stride, **epi):
+    """Run every lattice class of a conv-like op; x_cl/out_cl are channels-last device tensors, or (a, b) pairs of them
+    for a two-part tensor."""
     lib = L.lib()
     kernel = tuple(w.shape[2:])
-    es = x_cl.element_size()
-    odims = tuple(out_cl.shape[1:4])
+    xin = two_part(*x_cl) if isinstance(x_cl, tuple) else tdesc(x_cl)
+    xout = two_part(*out_cl) if isinstance(out_cl, tuple) else tdesc(out_cl)
+    x0 = x_cl[0] if isinstance(x_cl, tuple) else x_cl
+    es = x0.element_size()
+    odims = (xout.x, xout.y, xout.z)
     keep = []
     for cls in P.lattice_classes(kind, kernel, stride):
         q = odims if kind in ("conv_fwd", "convT_dgrad") else tuple((o + s - 1) // s for o, s in zip(odims, stride))
-        plan = P.plan_igemm(kind, tuple(w.shape), cls, q, es, kc_pad=x_cl.shape[-1], **({"lds_budget": epi.pop("lds_budget")} if "lds_budget" in epi else {}))
-        wp = pack(plan, w, x_cl.dtype)
-        d = igemm_desc(plan, wp, tdesc(x_cl), tdesc(out_cl), **epi)
+        plan = P.plan_igemm(kind, tuple(w.shape), cls, q, es, kc_pad=xin.c, in_split=xin.csplit if xin.ptr2 else 0, **({"lds_budget": epi.pop("lds_budget")} if "lds_budget" in epi else {}))
+        wp = pack(plan, w, x0.dtype)
+        d = igemm_desc(plan, wp, xin, xout, **epi)
         keep.append((wp, d))
         L.check(lib.vsseg_igemm(C.byref(d), stream()), "igemm")
     torch.cuda.synchronize()
@@ -83,7 +92,7 @@ def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid
     wp = P.plan_wgrad(transposed, wshape, kernel, stride, tuple(p_cl.shape[1:4]), es)
     dw = torch.zeros(int(np.prod(wshape)), dtype=torch.float32, device="cuda")
     d = L.WgradDesc()
-    d.p, d.h, d.cp_valid, d.ch_valid = tdesc(p_cl), tdesc(h_cl), cp_valid, ch_valid
+    d.p, d.h, d.cp_valid, d.ch_valid = tdesc(p_cl), (two_part(*h_cl) if isinstance(h_cl, tuple) else tdesc(h_cl)), cp_valid, ch_valid
     d.q, d.hs, d.ntaps = L.i3(wp.q), L.i3(wp.hs), len(wp.taps)
     for t, (off, widx) in enumerate(wp.taps):
         d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off

@@ -227,6 +227,110 @@ def test_attention_gate_forward_backward(dt, c):
     assert abs(float(dbias) - float(pre.grad.sum())) < 2e-2 * float(pre.grad.abs().sum()) ** 0.5 + 1e-3
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# two-part tensors: the skip-connection concat cat([skip, up], 1) (MONAI SkipConnection) addressed as a pair of dense
+# tensors.  Every kernel that accepts one must give exactly what it gives on the materialised concatenation.
+# ---------------------------------------------------------------------------------------------------------------
+def _split_cl(t_cl, c0):
+    return t_cl[..., :c0].contiguous(), t_cl[..., c0:].contiguous()
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,c0,c1,cout,dims,budget", [((3, 3, 1), 16, 16, 16, (16, 16, 8), None), ((3, 3, 3), 48, 48, 48, (8, 8, 8), None), ((3, 3, 3), 48, 48, 48, (8, 8, 8), 40 * 1024),
+                                                      ((3, 3, 3), 80, 80, 80, (6, 2, 8), None), ((1, 1, 1), 32, 32, 32, (8, 8, 8), None)])
+def test_two_part_input_forward_and_wgrad(k, c0, c1, cout, dims, budget, dt):
+    torch.manual_seed(11)
+    cin = c0 + c1
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k)) ** 0.5, dt).double().requires_grad_(True)
+    y = F.conv3d(x.double(), w, padding=P.same_pad(k))
+    xa, xb = _split_cl(H.to_cl(x, H.DT[dt]), c0)
+    out = torch.zeros(2, *dims, cout, dtype=H.DT[dt], device="cuda")
+    kw = {"lds_budget": budget} if budget else {}
+    keep = H.run_lattice_op("conv_fwd", w.detach().float(), (xa, xb), out, (1, 1, 1), **kw)
+    if budget:
+        assert keep[0][1].nchunks > 1 and c0 % keep[0][1].ck == 0  # several chunks, none straddling the split
+    np.testing.assert_allclose(H.from_cl(out).numpy(), y.detach().float().numpy(), atol=_tol(dt, y))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    dw = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), H.to_cl(gy, H.DT[dt]), (xa, xb), cout, cin)
+    ref = w.grad.float()
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=(5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,c0,c1,cout,dims", [((3, 3, 1), 16, 16, 16, (16, 16, 8)), ((3, 3, 3), 48, 48, 48, (8, 8, 8)), ((3, 3, 3), 80, 80, 80, (6, 2, 8)), ((3, 3, 1), 32, 32, 2, (9, 8, 4))])
+def test_two_part_output_dgrad_fresh_accumulate_and_relu_mask(k, c0, c1, cout, dims, dt):
+    """The data gradient of a convolution whose input is the concat is written into the two operands' gradient tensors:
+    fresh, then accumulated on top of earlier contributions, with the attention-ReLU mask as the residual operand."""
+    torch.manual_seed(12)
+    cin = c0 + c1
+    w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k)) ** 0.5, dt)
+    x = torch.zeros(2, cin, *dims, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x, w.double(), padding=P.same_pad(k))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    want = x.grad
+    gcl = H.to_cl(gy, H.DT[dt], P.round_up(cout, 8))
+    da, db = torch.zeros(2, *dims, c0, dtype=H.DT[dt], device="cuda"), torch.zeros(2, *dims, c1, dtype=H.DT[dt], device="cuda")
+    H.run_lattice_op("conv_dgrad", w, gcl, (da, db), (1, 1, 1))
+    got = torch.cat([H.from_cl(da), H.from_cl(db)], 1)
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), atol=_tol(dt, want))
+    # accumulate + mask: operands pre-filled, result = old + dgrad * (mask > 0)
+    old = _round(torch.randn(2, cin, *dims), dt)
+    mask = _round(torch.randn(2, cin, *dims), dt)
+    oa, ob = _split_cl(H.to_cl(old, H.DT[dt]), c0)
+    ma, mb = _split_cl(H.to_cl(mask, H.DT[dt]), c0)
+    H.run_lattice_op("conv_dgrad", w, gcl, (oa, ob), (1, 1, 1), accumulate=1)
+    got = torch.cat([H.from_cl(oa), H.from_cl(ob)], 1)
+    ref = old.double() + want
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), atol=_tol(dt, ref))
+    fa, fb = torch.zeros_like(da), torch.zeros_like(db)
+    H.run_lattice_op("conv_dgrad", w, gcl, (fa, fb), (1, 1, 1), res_mode=L.RES_RELUMASK, res=H.two_part(ma, mb))
+    got = torch.cat([H.from_cl(fa), H.from_cl(fb)], 1)
+    ref = want * (mask.double() > 0)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), atol=_tol(dt, want))
+
+
+@pytest.mark.parametrize("c0", [16, 48, 80])
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_two_part_attention_gate(dt, c0):
+    lib = L.lib()
+    torch.manual_seed(13)
+    dims, n, c = (8, 8, 4), 2, 2 * c0
+    x = _round(torch.randn(n, c, *dims), dt).double().requires_grad_(True)
+    pre = torch.randn(n, 1, *dims, dtype=torch.float64, requires_grad=True)
+    att = torch.sigmoid(pre)
+    out = att * x + x
+    gout = _round(torch.randn(n, c, *dims), dt)
+    (out * gout.double()).sum().backward()
+    xa, xb = _split_cl(H.to_cl(x, H.DT[dt]), c0)
+    gcl = H.to_cl(gout, H.DT[dt])
+    attd = att.detach().float().reshape(n, *dims).contiguous().cuda()
+    o = torch.zeros(n, *dims, c, dtype=H.DT[dt], device="cuda")
+    S = H.stream()
+    L.check(lib.vsseg_att_apply_fwd(H.two_part(xa, xb), attd.data_ptr(), H.tdesc(o), S))
+    old = _round(torch.randn(n, c, *dims), dt)
+    da, db = _split_cl(H.to_cl(old, H.DT[dt]), c0)
+    dpre = torch.zeros(n, *dims, 8, dtype=H.DT[dt], device="cuda")
+    L.check(lib.vsseg_att_apply_bwd(H.two_part(xa, xb), attd.data_ptr(), H.tdesc(gcl), None, H.two_part(da, db), 1, H.tdesc(dpre), None, S))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(H.from_cl(o).numpy(), out.detach().float().numpy(), atol=_tol(dt, out))
+    ref = old.double() + x.grad
+    np.testing.assert_allclose(torch.cat([H.from_cl(da), H.from_cl(db)], 1).numpy(), ref.float().numpy(), atol=_tol(dt, ref))
+    np.testing.assert_allclose(H.from_cl(dpre, 1).numpy(), pre.grad.float().numpy(), atol=_tol(dt, pre.grad))
+
+
+def test_two_part_tensors_are_rejected_where_unsupported():
+    lib = L.lib()
+    a = torch.zeros(1, 4, 4, 4, 16, device="cuda")
+    t2 = H.two_part(a, a.clone())
+    vec = torch.zeros(32, device="cuda")
+    assert lib.vsseg_channel_sum(t2, vec.data_ptr(), H.stream()) == L.EINVAL
+    assert lib.vsseg_copy_cast(t2, t2, H.stream()) == L.EINVAL
+    assert b"two-part" in lib.vsseg_last_error()
+
+
 @pytest.mark.parametrize("att", [True, False])
 @pytest.mark.parametrize("hard", [True, False])
 def test_dice_spvpa_loss_matches_reference_golden(att, hard):

@@ -15,10 +15,19 @@ ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELUMASK = 0, 1, 2
 MAX_TAPS = 27
 STAT_SHARDS = 256
+EINVAL, ELAUNCH = -1, -2
 
 
 class Tensor(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("c", C.c_int32), ("pitch", C.c_int32), ("n", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32)]
+    # positional construction Tensor(ptr, dtype, c, pitch, n, x, y, z) leaves ptr2/csplit zero = an ordinary tensor
+    _fields_ = [("ptr", C.c_void_p), ("dtype", C.c_int32), ("c", C.c_int32), ("pitch", C.c_int32), ("n", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("z", C.c_int32),
+                ("ptr2", C.c_void_p), ("csplit", C.c_int32), ("reserved", C.c_int32)]
+
+    @classmethod
+    def two_part(cls, a: "Tensor", b: "Tensor") -> "Tensor":
+        """The channel concatenation [a | b] of two tensors of the same geometry, dtype and pitch (nothing is copied)."""
+        assert (a.dtype, a.pitch, a.n, a.x, a.y, a.z) == (b.dtype, b.pitch, b.n, b.x, b.y, b.z) and not a.ptr2 and not b.ptr2 and a.c % 16 == 0
+        return cls(a.ptr, a.dtype, a.c + b.c, a.pitch, a.n, a.x, a.y, a.z, b.ptr, a.c, 0)
 
 
 class IgemmDesc(C.Structure):

@@ -8,6 +8,17 @@
     else { typedef bf16_t T; __VA_ARGS__; }            \
   } while (0)
 
+// two-part tensors (vsseg_hip.h): channels >= csplit live at ptr2
+static inline int split_of(const vsseg_tensor& t) { return t.ptr2 ? t.csplit : 0x7fffffff; }
+static inline bool two_part_ok(const vsseg_tensor& t) {
+  return !t.ptr2 || (t.csplit > 0 && t.csplit < t.c && t.csplit % 16 == 0 && t.pitch >= t.csplit && t.pitch >= t.c - t.csplit);
+}
+#define VSSEG_ONE_PART(name, ...)                                                                     \
+  do {                                                                                                \
+    const vsseg_tensor* ts_[] = {__VA_ARGS__};                                                        \
+    for (const vsseg_tensor* t_ : ts_) VSSEG_CHECK(!t_->ptr2, name ": two-part tensors are not supported here"); \
+  } while (0)
+
 // block size such that every thread keeps one fixed 8-channel group while striding over voxels
 static inline int block_for_cgs(int cgs) {
   int a = cgs, b = 64;
@@ -61,6 +72,7 @@ template <typename T> __global__ void stage_input_kernel(const float* __restrict
   }
 }
 extern "C" int vsseg_stage_input(const float* src, int32_t n, const int32_t sdims[3], const int32_t origin[3], vsseg_tensor dst, void* stream) {
+  VSSEG_ONE_PART("vsseg_stage_input", &dst);
   VSSEG_CHECK(src && dst.ptr && dst.c >= 1 && dst.pitch >= dst.c && dst.n == n, "vsseg_stage_input: bad arguments");
   VSSEG_CHECK(dst.c % 8 != 0 || dst.pitch % 8 == 0, "vsseg_stage_input: vectorised path needs pitch %% 8 == 0");
   int64_t total = tensor_voxels(dst);
@@ -80,6 +92,7 @@ template <typename S, typename D, bool ADD> __global__ void copy_kernel(const S*
   }
 }
 template <bool ADD> static int copy_impl(vsseg_tensor src, vsseg_tensor dst, void* stream, const char* name) {
+  VSSEG_ONE_PART("vsseg_copy_cast/add_inplace", &src, &dst);
   VSSEG_CHECK(src.ptr && dst.ptr && src.c == dst.c && tensor_voxels(src) == tensor_voxels(dst), "%s: shape mismatch", name);
   int64_t nv = tensor_voxels(src), total = nv * src.c;
   dim3 g(grid_for(total, 256)), b(256);
@@ -170,6 +183,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
 }
 extern "C" int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
                                 vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream) {
+  VSSEG_ONE_PART("vsseg_bn_act_fwd", &y, &res, &out);
   VSSEG_CHECK(y.ptr && out.ptr && scale && shift && alpha && y.c % 8 == 0 && y.pitch % 8 == 0 && out.pitch % 8 == 0 && out.c == y.c && out.dtype == y.dtype, "vsseg_bn_act_fwd: bad arguments");
   VSSEG_CHECK(!has_res || (res.ptr && res.dtype == y.dtype && res.c == y.c && res.pitch % 8 == 0), "vsseg_bn_act_fwd: bad residual");
   VSSEG_CHECK(p_drop >= 0.f && p_drop < 1.f, "vsseg_bn_act_fwd: dropout p out of range");
@@ -253,6 +267,7 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const 
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream) {
+  VSSEG_ONE_PART("vsseg_bn_act_bwd_reduce", &y, &dout);
   VSSEG_CHECK(y.ptr && dout.ptr && y.dtype == dout.dtype && y.c == dout.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && sums && alpha_acc && stride >= y.c, "vsseg_bn_act_bwd_reduce: bad arguments");
   int cgs = y.c / 8, blk = block_for_cgs(cgs);
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
@@ -310,6 +325,7 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
 }
 extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                       float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream) {
+  VSSEG_ONE_PART("vsseg_bn_act_bwd_apply", &y, &dout, &dy);
   VSSEG_CHECK(y.ptr && dout.ptr && dy.ptr && y.dtype == dout.dtype && y.dtype == dy.dtype && y.c == dout.c && y.c == dy.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && dy.pitch % 8 == 0,
               "vsseg_bn_act_bwd_apply: bad arguments");
   int cgs = y.c / 8;
@@ -324,23 +340,24 @@ extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const f
 // attention gate  out = x*(1+att)                       ref:params/networks/blocks/attentionblock.py:43-47
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void att_apply_fwd_kernel(const T* __restrict__ x, int xp, const float* __restrict__ att, T* __restrict__ out, int op, int cgs, int64_t nvox) {
+__global__ void att_apply_fwd_kernel(const T* __restrict__ x, const T* __restrict__ x2, int xsplit, int xp, const float* __restrict__ att, T* __restrict__ out, int op, int cgs, int64_t nvox) {
   const int64_t total = nvox * cgs;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t v = i / cgs;
     int c = (int)(i - v * cgs) * 8;
     const float g = 1.f + att[v];
-    f8 a = ld8(x + v * xp + c);
+    f8 a = c >= xsplit ? ld8(x2 + v * xp + (c - xsplit)) : ld8(x + v * xp + c);  // two-part x: the concat of the skip and upsample tensors
 #pragma unroll
     for (int j = 0; j < 8; ++j) a.v[j] *= g;
     st8(out + v * op + c, a);
   }
 }
 extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream) {
-  VSSEG_CHECK(x.ptr && att && out.ptr && x.dtype == out.dtype && x.c == out.c && x.c % 8 == 0 && x.pitch % 8 == 0 && out.pitch % 8 == 0, "vsseg_att_apply_fwd: bad arguments");
+  VSSEG_CHECK(x.ptr && att && out.ptr && x.dtype == out.dtype && x.c == out.c && x.c % 8 == 0 && x.pitch % 8 == 0 && out.pitch % 8 == 0 && !out.ptr2, "vsseg_att_apply_fwd: bad arguments");
+  VSSEG_CHECK(two_part_ok(x), "vsseg_att_apply_fwd: bad two-part x");
   int cgs = x.c / 8;
   int64_t nv = tensor_voxels(x);
-  DISPATCH_T(x.dtype, hipLaunchKernelGGL(att_apply_fwd_kernel<T>, dim3(grid_for(nv * cgs, 256)), dim3(256), 0, as_stream(stream), (const T*)x.ptr, x.pitch, att, (T*)out.ptr, out.pitch, cgs, nv));
+  DISPATCH_T(x.dtype, hipLaunchKernelGGL(att_apply_fwd_kernel<T>, dim3(grid_for(nv * cgs, 256)), dim3(256), 0, as_stream(stream), (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, (T*)out.ptr, out.pitch, cgs, nv));
   VSSEG_LAUNCH_CHECK("vsseg_att_apply_fwd");
   return VSSEG_OK;
 }
@@ -348,9 +365,12 @@ extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tenso
 // G lanes per voxel (G = next power of two >= channel groups): dx = dout*(1+att) (optionally +=),
 // dpre = (sum_c dout*x + datt_ext) * att*(1-att) in channel 0 of an 8-wide row; sum(dpre) -> bias gradient of attention conv2
 template <typename T, bool ACC, int G>
-__global__ void att_apply_bwd_kernel(const T* __restrict__ x, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
-                                     T* __restrict__ dx, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias) {
+__global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int xsplit, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
+                                     T* __restrict__ dx0, T* __restrict__ dx1, int dxsplit, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias) {
   const int sub = threadIdx.x % G;
+  // two-part x / dx (skip-connection concat and its gradient): this lane's 8-channel group lies in one part
+  const T* x = sub * 8 >= xsplit ? x1 - xsplit : x0;
+  T* dx = sub * 8 >= dxsplit ? dx1 - dxsplit : dx0;
   const int64_t vstep = (int64_t)gridDim.x * (blockDim.x / G);
   float bsum = 0.f;
   for (int64_t v0 = blockIdx.x * (int64_t)(blockDim.x / G); v0 < nvox; v0 += vstep) {  // all lanes iterate together (shuffles need full groups)
@@ -392,15 +412,17 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x, int xp, const floa
     }
   }
 }
-template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, const T* x, int xp, const float* att, const T* dout, int dp, const float* de, T* dx, int dxp, T* dpre, int dprep, int cgs, int64_t nv, float* dbias) {
+template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, vsseg_tensor x, const float* att, const T* dout, int dp, const float* de, vsseg_tensor dx, T* dpre, int dprep, int cgs, int64_t nv, float* dbias) {
+#define VSSEG_ATT_BWD(GG) hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, GG>), g, b, 0, s, (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, dout, dp, de, (T*)dx.ptr, (T*)dx.ptr2, split_of(dx), dx.pitch, dpre, dprep, cgs, nv, dbias)
   switch (G) {
-    case 1: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 1>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
-    case 2: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 2>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
-    case 4: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 4>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
-    case 8: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 8>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
-    case 16: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 16>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
-    default: hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, 32>), g, b, 0, s, x, xp, att, dout, dp, de, dx, dxp, dpre, dprep, cgs, nv, dbias); break;
+    case 1: VSSEG_ATT_BWD(1); break;
+    case 2: VSSEG_ATT_BWD(2); break;
+    case 4: VSSEG_ATT_BWD(4); break;
+    case 8: VSSEG_ATT_BWD(8); break;
+    case 16: VSSEG_ATT_BWD(16); break;
+    default: VSSEG_ATT_BWD(32); break;
   }
+#undef VSSEG_ATT_BWD
 }
 extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, float* dbias, void* stream) {
   VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && dpre.ptr && x.dtype == dout.dtype && x.dtype == dx.dtype && x.dtype == dpre.dtype && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 && dpre.c == 8 &&
@@ -412,8 +434,9 @@ extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tenso
   int64_t nv = tensor_voxels(x);
   dim3 g(grid_for(nv * G, 256)), b(256);
   hipStream_t s = as_stream(stream);
-  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias);
-             else att_bwd_launch<T, false>(G, g, b, s, (const T*)x.ptr, x.pitch, att, (const T*)dout.ptr, dout.pitch, datt_ext, (T*)dx.ptr, dx.pitch, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias));
+  VSSEG_CHECK(two_part_ok(x) && two_part_ok(dx) && !dout.ptr2 && !dpre.ptr2, "vsseg_att_apply_bwd: bad two-part tensor");
+  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias);
+             else att_bwd_launch<T, false>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias));
   VSSEG_LAUNCH_CHECK("vsseg_att_apply_bwd");
   return VSSEG_OK;
 }
@@ -439,6 +462,7 @@ template <typename T> __global__ void channel_sum_kernel(const T* __restrict__ t
   for (int i = threadIdx.x; i < c; i += blockDim.x) atomicAdd(&out[i], red[i]);
 }
 extern "C" int vsseg_channel_sum(vsseg_tensor t, float* out, void* stream) {
+  VSSEG_ONE_PART("vsseg_channel_sum", &t);
   VSSEG_CHECK(t.ptr && out && t.c >= 1 && t.c <= 256 && t.pitch % 8 == 0 && (t.c + 7) / 8 * 8 <= t.pitch, "vsseg_channel_sum: bad arguments (the row must hold the channels rounded up to 8)");
   int cgs = (t.c + 7) / 8, blk = block_for_cgs(cgs);
   VSSEG_CHECK(blk > 0, "vsseg_channel_sum: unsupported channel count");

@@ -20,6 +20,7 @@
 // Packed weights stay resident in LDS for single-chunk layers; per-channel epilogue constants live in LDS, so the hot
 // loop issues no ordinary global load that would make hipcc drain the DMA queue (cdna_hip_programming.md §5).
 #include "common.h"
+#include <stdlib.h>
 
 constexpr int PMAX = 8;  // 16-byte halo pieces per thread per stage (halo chunk <= 32 KiB)
 constexpr int AMAX = 8;  // 16-byte pieces per thread of the auxiliary (residual / accumulate) output tile
@@ -54,14 +55,24 @@ struct __attribute__((aligned(64))) TileDesc {
   int32_t flags;    // bit 0: halo entirely inside the input; bit 1: tile entirely inside lattice and output
 };
 
-__global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab) {
+// Table order = execution order (an XCD's workgroups walk a contiguous range of the table, ~64 tiles at a time).  Tiles are
+// ordered (sample, x-band of `xb` tiles, y, x inside the band, z): the tiles in flight on one XCD then form a compact
+// xb x 1..2 x nz brick whose x- and y-neighbours were fetched at most a few steps earlier, so the halo overlap between
+// neighbouring tiles is served by that XCD's L2 instead of being fetched from HBM again.
+__global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
+  const int64_t per_sample = (int64_t)k.ntile[0] * k.ntile[1] * k.ntile[2];
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < k.total_tiles; t += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = t;
+    const int n = (int)(t / per_sample);
+    int64_t b = t - n * per_sample;
+    const int64_t band_tiles = (int64_t)xb * k.ntile[1] * k.ntile[2];
+    const int band = (int)(b / band_tiles);
+    b -= band * band_tiles;
+    const int bw = min(xb, k.ntile[0] - band * xb);  // the last band may be narrower
     const int tz = (int)(b % k.ntile[2]); b /= k.ntile[2];
-    const int ty = (int)(b % k.ntile[1]); b /= k.ntile[1];
-    const int tx = (int)(b % k.ntile[0]);
-    const int n = (int)(b / k.ntile[0]);
+    const int txl = (int)(b % bw);
+    const int ty = (int)(b / bw);
+    const int tx = band * xb + txl;
     TileDesc td;
     td.n = n;
     td.q0[0] = tx * d.tile[0]; td.q0[1] = ty * d.tile[1]; td.q0[2] = tz * d.tile[2];
@@ -197,6 +208,17 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     pinfo[u] = info;
     prel[u] = rel;
   }
+  // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  prel/pinfo keep the channel offset of the
+  // virtual concatenated row; part 1's base is biased by -csplit channels so the same offsets address it.  A chunk never
+  // straddles the split unless it is the only chunk (checked on the host), so the per-piece choice is static per thread.
+  const bool in_two = d.in.ptr2 != nullptr;
+  const int in_csplit = in_two ? d.in.csplit : 0x7fffffff;
+  unsigned p2mask = 0;  // bit u: piece u of this thread lies in part 1 (single-chunk case)
+  if (in_two && nch == 1) {
+#pragma unroll
+    for (int u = 0; u < PMAX; ++u)
+      if (pinfo[u] != 0xffffffffu && (int)(pinfo[u] >> 24) * EPP >= in_csplit) p2mask |= 1u << u;
+  }
   const int OX = d.out.x, OY = d.out.y, OZ = d.out.z;
   int vb[MTW];
   unsigned vxyz[MTW];
@@ -232,6 +254,24 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     }
     arel[u] = rel;
   }
+  // two-part auxiliary / output tensors: same scheme (static per-piece part choice, part-1 base biased by -csplit channels)
+  const bool aux_two = aux_on && k.aux.ptr2 != nullptr;
+  unsigned a2mask = 0;
+  if (aux_two) {
+#pragma unroll
+    for (int u = 0; u < AMAX; ++u) {
+      const int j = (u * 4 + wave) * 64 + lane;
+      if (j < apieces && split * NT * 16 + (j % ppa) * (16 / (int)aux_es) >= k.aux.csplit) a2mask |= 1u << u;
+    }
+  }
+  const char* aux_base = reinterpret_cast<const char*>(k.aux.ptr);
+  const char* aux_base1 = aux_two ? reinterpret_cast<const char*>(k.aux.ptr2) - (int64_t)k.aux.csplit * aux_es : aux_base;
+  const bool out_two = d.out.ptr2 != nullptr;
+  const int out_csplit = out_two ? d.out.csplit : 0x7fffffff;
+  char* out_base = reinterpret_cast<char*>(d.out.ptr);
+  char* out_base1 = out_two ? reinterpret_cast<char*>(d.out.ptr2) - (int64_t)out_csplit * out_es : out_base;
+  const bool res_two = d.res_mode != VSSEG_RES_NONE && d.res.ptr2 != nullptr;
+  const int res_csplit = res_two ? d.res.csplit : 0x7fffffff;
   const bool fast_store = (d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on;
   const bool vec_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0;
 
@@ -249,6 +289,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   const int nstages = my_tiles * nch;
 
   const char* in_base = reinterpret_cast<const char*>(d.in.ptr);
+  const char* in_base1 = in_two ? reinterpret_cast<const char*>(d.in.ptr2) - (int64_t)in_csplit * ES : in_base;
   const int64_t in_sample_bytes = (int64_t)X * Y * Z * in_vox_bytes;
 
   const TileDesc* tiles = k.tiles + (t_first + slot);  // this workgroup's tiles: tiles[i * S]
@@ -266,6 +307,14 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   for (int u = 0; u < AMAX; ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
   if (nch > 1)
     for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
+  // store instructions a wave issues in the fast epilogue of one tile (exactly one 8/16-byte store per valid 16-channel
+  // block and M tile; the scalar-store variant and the slow epilogue count as 0 = their stores are simply waited for)
+  int nst_fast = 0;
+  if (vec_store) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) nst_fast += (split * NT * 16 + t * 16 < cout) ? MTW : 0;
+  }
+  int st_h0 = 0, st_h1 = 0, st_h2 = 0;
   auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
     const int ch = ch_issue;
     const TileDesc td = td_next;
@@ -278,15 +327,28 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     char* Hdst = Hl + buf_issue * k.h_bytes;
     const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
     if (interior) {
-      const char* origin = in_base + td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
+      const int64_t ooff = td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
+      const char* origin = in_base + ooff;
+      if (!in_two) {
 #pragma unroll
-      for (int u = 0; u < PMAX; ++u) {
-        if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
-        if (pinfo[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
+        for (int u = 0; u < PMAX; ++u) {
+          if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
+          if (pinfo[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
+        }
+      } else {
+        const char* origin1 = in_base1 + ooff;
+        const unsigned m2 = nch == 1 ? p2mask : (c0 >= in_csplit ? 0xffffffffu : 0u);
+#pragma unroll
+        for (int u = 0; u < PMAX; ++u) {
+          if ((u * 4 + wave) * 64 >= pieces) break;
+          if (pinfo[u] != 0xffffffffu) dma16(((m2 >> u) & 1u ? origin1 : origin) + prel[u], Hdst + (u * 4 + wave) * 1024);
+        }
       }
     } else {
       const int gx0 = td.g0[0], gy0 = td.g0[1], gz0 = td.g0[2];
-      const char* sample = in_base + (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
+      const int64_t soff = (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
+      const char* sample = in_base + soff;
+      const char* sample1 = in_base1 + soff;
 #pragma unroll
       for (int u = 0; u < PMAX; ++u) {
         if ((u * 4 + wave) * 64 >= pieces) break;
@@ -295,7 +357,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
           const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
           const int c = c0 + (int)(info >> 24) * EPP;
           const bool ok = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
-          const void* src = ok ? (const void*)(sample + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
+          const void* src = ok ? (const void*)((c >= in_csplit ? sample1 : sample) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
           dma16(src, Hdst + (u * 4 + wave) * 1024);
         }
       }
@@ -304,12 +366,13 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
       // partial tiles use the slow epilogue (ordinary loads) but still issue the same number of DMAs (from the zero page),
       // so that the per-stage instruction count the vmcnt arithmetic relies on stays exact
       const bool whole = (td.flags & 2) != 0;
-      const char* aorigin = reinterpret_cast<const char*>(k.aux.ptr) + td.out_vox * aux_vox_bytes;
+      const char* aorigin = aux_base + td.out_vox * aux_vox_bytes;
+      const char* aorigin1 = aux_base1 + td.out_vox * aux_vox_bytes;
       char* Adst = Al + abuf_issue * k.aux_bytes;
 #pragma unroll
       for (int u = 0; u < AMAX; ++u) {
         if ((u * 4 + wave) * 64 >= apieces) break;
-        if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(aorigin + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
+        if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
       }
       if (++abuf_issue == nbuf) abuf_issue = 0;
     }
@@ -334,10 +397,12 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   for (int s = 0; s < nstages; ++s) {
     // Stage s has landed once at most the DMAs of the younger stages s+1..s+D-1 remain (VMEM ops complete in issue order).  The
     // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
+    // Also younger than stage s's DMAs, and still allowed to be in flight: the output stores of the last D stages (vmcnt retires
+    // loads and stores of a wave in issue order).  Waiting for them too would put a write-acknowledge latency into every stage.
     if (D == 1) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vmcnt(st_h0);
     } else {
-      int younger = 0, chj = ch_cur;
+      int younger = st_h0 + st_h1 + (D >= 3 ? st_h2 : 0), chj = ch_cur;
       for (int j = 1; j < D && s + j < nstages; ++j) {
         if (++chj == nch) chj = 0;
         younger += nh + nw + (chj == 0 ? na : 0);
@@ -415,16 +480,19 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
         }
       }
     }
+    st_h2 = st_h1; st_h1 = st_h0; st_h0 = 0;  // store instructions of the last three stages (this stage's are added below)
     if (++ch_cur != nch) continue;
     ch_cur = 0;
 
     // ---- epilogue of the current tile ----
     ++ti_cur;
     const bool whole = (tc.flags & 2) != 0;
-    char* out_tile = reinterpret_cast<char*>(d.out.ptr) + tc.out_vox * out_vox_bytes;
+    char* out_tile = out_base + tc.out_vox * out_vox_bytes;
+    const int64_t out_delta = out_base1 - out_base;  // 0 for an ordinary tensor
     const char* Aux = Al + abuf_cur * k.aux_bytes;
     if (++abuf_cur == nbuf) abuf_cur = 0;
     if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
+      st_h0 = nst_fast;
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         char* op = out_tile + ovrel[m] * out_vox_bytes;
@@ -462,14 +530,15 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             }
           }
+          char* opt = op + (split * NT * 16 + t * 16 >= out_csplit ? out_delta : 0);  // uniform per 16-channel block
           if (vec_store) {
-            if (out_es == 4) st4(reinterpret_cast<float*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
-            else st4(reinterpret_cast<bf16_t*>(op) + c, make_float4(val[0], val[1], val[2], val[3]));
+            if (out_es == 4) st4(reinterpret_cast<float*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
+            else st4(reinterpret_cast<bf16_t*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
           } else {  // 1- and 2-channel outputs (attention map, logits): scalar stores of the valid channels
             const int nc = min(4, cout - c);
             for (int r = 0; r < nc; ++r) {
-              if (out_es == 4) reinterpret_cast<float*>(op)[c + r] = val[r];
-              else reinterpret_cast<bf16_t*>(op)[c + r] = f2bf(val[r]);
+              if (out_es == 4) reinterpret_cast<float*>(opt)[c + r] = val[r];
+              else reinterpret_cast<bf16_t*>(opt)[c + r] = f2bf(val[r]);
             }
           }
         }
@@ -499,20 +568,23 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
           else if (d.act == VSSEG_ACT_RELU) x = fmaxf(x, 0.f);
           else if (d.act == VSSEG_ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
           if (d.res_mode != VSSEG_RES_NONE) {
-            const int64_t ro = ovox * d.res.pitch + c + r;
-            float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(d.res.ptr)[ro] : bf2f(reinterpret_cast<const bf16_t*>(d.res.ptr)[ro]);
+            const bool r2 = c >= res_csplit;
+            const void* rbase = r2 ? d.res.ptr2 : d.res.ptr;
+            const int64_t ro = ovox * d.res.pitch + c + r - (r2 ? res_csplit : 0);
+            float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(rbase)[ro] : bf2f(reinterpret_cast<const bf16_t*>(rbase)[ro]);
             x = d.res_mode == VSSEG_RES_ADD ? x + rv : (rv > 0.f ? x : 0.f);
           }
           val[r] = x;
         }
         const int64_t oo = ovox * d.out.pitch + c;
+        char* obase = c >= out_csplit ? out_base1 : out_base;
         if (d.out.dtype == VSSEG_F32) {
-          float* op = reinterpret_cast<float*>(d.out.ptr) + oo;
+          float* op = reinterpret_cast<float*>(obase) + oo;
           if (nc == 4 && (d.out.pitch & 3) == 0 && !d.accumulate) st4(op, make_float4(val[0], val[1], val[2], val[3]));
           else
             for (int r = 0; r < nc; ++r) op[r] = d.accumulate ? op[r] + val[r] : val[r];
         } else {
-          bf16_t* op = reinterpret_cast<bf16_t*>(d.out.ptr) + oo;
+          bf16_t* op = reinterpret_cast<bf16_t*>(obase) + oo;
           if (nc == 4 && (d.out.pitch & 3) == 0) {
             if (d.accumulate) {
               float4 o = ld4(op);
@@ -602,13 +674,17 @@ template <typename T> static int launch_nt(const IgemmK& k, dim3 grid, int lds, 
 static const TileDesc* tile_table(const IgemmK& k, hipStream_t stream) {
   static std::map<std::vector<int64_t>, TileDesc*> cache;
   const vsseg_igemm_desc& d = k.d;
-  std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles};
+  static int xb_env = -1;
+  if (xb_env < 0) { const char* e = getenv("VSSEG_TILE_XBAND"); xb_env = e ? atoi(e) : 0; }
+  int xb = xb_env > 0 ? xb_env : 128 / k.ntile[2];  // ~2 scheduling steps of one XCD per (band, y) row
+  xb = xb < 1 ? 1 : (xb > k.ntile[0] ? k.ntile[0] : xb);
+  std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles, xb};
   for (int a = 0; a < 3; ++a) { key.push_back(d.q[a]); key.push_back(d.tile[a]); key.push_back(d.is[a]); key.push_back(d.os[a]); key.push_back(d.oo[a]); key.push_back(k.off_min[a]); key.push_back(k.halo[a]); }
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
   TileDesc* tab = nullptr;
   if (hipMalloc(&tab, sizeof(TileDesc) * k.total_tiles) != hipSuccess) return nullptr;
-  hipLaunchKernelGGL(igemm_tile_setup_kernel, dim3((unsigned)((k.total_tiles + 255) / 256 > 1024 ? 1024 : (k.total_tiles + 255) / 256)), dim3(256), 0, stream, k, tab);
+  hipLaunchKernelGGL(igemm_tile_setup_kernel, dim3((unsigned)((k.total_tiles + 255) / 256 > 1024 ? 1024 : (k.total_tiles + 255) / 256)), dim3(256), 0, stream, k, tab, xb);
   cache[key] = tab;
   return tab;
 }
@@ -629,6 +705,12 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d->in.c % 8 == 0 && d->in.pitch % 8 == 0, "vsseg_igemm: input channels/pitch must be multiples of 8 (c=%d pitch=%d)", d->in.c, d->in.pitch);
   VSSEG_CHECK(d->tile[0] * d->tile[1] * d->tile[2] == 64 * d->mtw, "vsseg_igemm: tile %dx%dx%d != 64*mtw", d->tile[0], d->tile[1], d->tile[2]);
   VSSEG_CHECK(d->nsplit >= 1 && d->nsplit * d->nt * 16 >= d->out.c, "vsseg_igemm: nsplit*nt*16 < cout");
+  for (const vsseg_tensor* t : {&d->in, &d->out, &d->res}) {
+    if (t == &d->res && d->res_mode == VSSEG_RES_NONE) continue;
+    if (t->ptr2) VSSEG_CHECK(t->csplit > 0 && t->csplit < t->c && t->csplit % 16 == 0 && t->pitch >= t->csplit && t->pitch >= t->c - t->csplit,
+                             "vsseg_igemm: bad two-part tensor (c=%d csplit=%d pitch=%d)", t->c, t->csplit, t->pitch);
+  }
+  VSSEG_CHECK(!d->in.ptr2 || d->nchunks == 1 || d->in.csplit % d->ck == 0, "vsseg_igemm: a channel chunk (ck=%d) straddles the input split at %d", d->ck, d->in.csplit);
   k.d = *d;
   const int es = d->in.dtype == VSSEG_F32 ? 4 : 2;
   k.cgs = d->ck / 8;
@@ -653,7 +735,8 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   if (k.aux_mode) {
     const int aes = k.aux.dtype == VSSEG_F32 ? 4 : 2;
     const int row = d->nt * 16 * aes;
-    const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && d->nsplit * d->nt * 16 <= k.aux.pitch && 64 * d->mtw * (row / 16) <= AMAX * 256 &&
+    const int beyond = d->nsplit * d->nt * 16 - (k.aux.ptr2 ? k.aux.csplit : 0);  // channels the DMA rows touch in the last part
+    const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && beyond <= k.aux.pitch && 64 * d->mtw * (row / 16) <= AMAX * 256 && ((uintptr_t)k.aux.ptr2 % 16) == 0 &&
                     ((uintptr_t)k.aux.ptr % 16) == 0 && k.aux.c >= d->out.c;
     if (ok) k.aux_bytes = 64 * d->mtw * row; else k.aux_mode = 0;
   }

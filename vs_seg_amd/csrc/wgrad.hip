@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   }
   const bool p_chan_ok = NTP * 16 <= d.p.c, h_chan_ok = chunk * 16 + 16 <= d.h.c;  // every piece has real channels (fast path)
   const char* p_base = reinterpret_cast<const char*>(d.p.ptr);
-  const char* h_base = reinterpret_cast<const char*>(d.h.ptr) + (int64_t)chunk * 16 * ES;
+  // two-part H (the skip-connection concat as the convolution input): a 16-channel chunk lies in one part (csplit % 16 == 0)
+  const bool h_part1 = d.h.ptr2 != nullptr && chunk * 16 >= d.h.csplit;
+  const char* h_base = h_part1 ? reinterpret_cast<const char*>(d.h.ptr2) + (int64_t)(chunk * 16 - d.h.csplit) * ES : reinterpret_cast<const char*>(d.h.ptr) + (int64_t)chunk * 16 * ES;
   const int64_t p_sample = (int64_t)PX * PY * PZ * p_vox_bytes, h_sample = (int64_t)QX * QY * QZ * h_vox_bytes;
 
   struct TileIdx { int tz, ty, tx, n; };
@@ -331,6 +333,9 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   VSSEG_CHECK(d->p.dtype == d->h.dtype, "vsseg_wgrad: dtype mismatch");
   VSSEG_CHECK(d->ntaps >= 1 && d->ntaps <= VSSEG_MAX_TAPS, "vsseg_wgrad: ntaps out of range");
   VSSEG_CHECK(d->p.c % 8 == 0 && d->p.pitch % 8 == 0 && d->h.c % 8 == 0 && d->h.pitch % 8 == 0, "vsseg_wgrad: channels/pitch must be multiples of 8");
+  VSSEG_CHECK(!d->p.ptr2, "vsseg_wgrad: P may not be a two-part tensor");
+  VSSEG_CHECK(!d->h.ptr2 || (d->h.csplit > 0 && d->h.csplit < d->h.c && d->h.csplit % 16 == 0 && d->h.pitch >= d->h.csplit && d->h.pitch >= d->h.c - d->h.csplit),
+              "vsseg_wgrad: bad two-part H (c=%d csplit=%d pitch=%d)", d->h.c, d->h.csplit, d->h.pitch);
   VSSEG_CHECK(d->ntp >= 1 && d->ntp * 16 >= d->cp_valid && d->cp_valid <= d->p.c, "vsseg_wgrad: ntp too small for %d P channels", d->cp_valid);
   WgradK k;
   k.d = *d;

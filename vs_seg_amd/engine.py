@@ -101,6 +101,8 @@ class Plan:
         return store[root.name]
 
     def _desc(self, spec: TensorSpec, store=None) -> L.Tensor:
+        if spec.parts is not None:  # skip-connection concat: the pair of its dense operands
+            return L.Tensor.two_part(self._desc(spec.parts[0], store), self._desc(spec.parts[1], store))
         buf = self._alloc(spec, self.bufs if store is None else store)
         x, y, z = self.lv[spec.level]
         return L.Tensor(buf.data_ptr() + spec.c0 * buf.element_size(), _tdtype(buf), spec.c, spec.root.c, self.n, x, y, z)
@@ -175,7 +177,7 @@ class Plan:
             fwd, dgrad, wg = [], [], None
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
-                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c, aux_es=aux_es)
+                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c, aux_es=aux_es, in_split=op.x.parts[0].c if op.x.parts else 0)
                 fwd.append((pl, add_map(pl.pack_map, woff)))
                 add_map2(P.pack_map_centre(pl, absorbed.layer.wshape) if absorbed is not None else None, woff2, pl.pack_map.size)
             if self.train:
@@ -296,6 +298,10 @@ class Plan:
 
         def contribution(spec: TensorSpec) -> int:
             """accumulate flag for adding a gradient contribution into g[spec] (first full-width contribution overwrites)."""
+            if spec.parts is not None:  # both operands of a concat receive their first contribution together
+                flags = [contribution(p) for p in spec.parts]
+                assert flags[0] == flags[1], f"operands of {spec.name} have inconsistent gradient state"
+                return flags[0]
             root = spec.root.name
             if written.get(root):
                 return 1

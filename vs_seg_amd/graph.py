@@ -4,8 +4,9 @@ Structure follows ref:params/networks/nets/unet2d5_spvPA.py:56-93 (`_create_bloc
 hard-coded at ref:params/VSparams.py:343-374.  State-dict key prefixes are the reference's, so checkpoints interchange.
 
 The op list is what `vs_seg_amd.engine` lowers to HIP launches (forward in order, backward in reverse).  The
-skip-connection concat (MONAI SkipConnection, `cat([x, sub(x)], 1)`) is expressed by making the encoder output and the
-upsample output channel-slices of one `cat` buffer — nothing is copied.
+skip-connection concat (MONAI SkipConnection, `cat([x, sub(x)], 1)`) is a *two-part* tensor: the pair (encoder output,
+upsample output) of two dense buffers — nothing is copied, and neither operand becomes a strided channel slice (slices
+of a twice-as-wide buffer were measured at less than half the HBM efficiency of dense tensors on the 16/32-channel levels).
 """
 from __future__ import annotations
 
@@ -78,6 +79,7 @@ class TensorSpec:
     base: Optional["TensorSpec"] = None  # channel slice of another tensor
     c0: int = 0
     creal: int = 0  # meaningful channels when the buffer is zero-extended (network input: 1 of 8)
+    parts: Optional[Tuple["TensorSpec", "TensorSpec"]] = None  # channel concatenation of two dense tensors (no buffer of its own)
 
     @property
     def real(self):
@@ -171,8 +173,8 @@ def build_program(attention: bool = True, hp: dict = HP) -> Program:
 
     def block(x, p, lvl, outc, is_top):
         c, k, sk, s = ch[lvl], ks[lvl], sks[lvl], st[lvl]
-        cat = new(f"cat{lvl}", lvl, 2 * c)
-        d = cat.slice(0, c)
+        d, up = new(f"skip{lvl}", lvl, c), new(f"upcat{lvl}", lvl, c)
+        cat = TensorSpec(f"cat{lvl}", lvl, 2 * c, parts=(d, up))
         residual_unit(x, p + ".0", k, lvl, hp["num_res_units"], d)
         sub = p + ".1.submodule"
         ad = new(f"down{lvl}", lvl + 1, c)
@@ -187,7 +189,7 @@ def build_program(attention: bool = True, hp: dict = HP) -> Program:
                 residual_unit(g, sub + ".1.1", kb, lvl + 1, hp["num_res_units"], u)
             else:
                 residual_unit(ad, sub + ".1", kb, lvl + 1, hp["num_res_units"], u)
-        ops.append(ConvBnAct(layer(prefix=sub + ".2", cin=ch[lvl + 1], cout=c, kernel=sk, stride=s, transposed=True, level=lvl + 1, has_bn=True), u, cat.slice(c, c)))
+        ops.append(ConvBnAct(layer(prefix=sub + ".2", cin=ch[lvl + 1], cout=c, kernel=sk, stride=s, transposed=True, level=lvl + 1, has_bn=True), u, up))
         out = new("logits" if is_top else f"up{lvl}", lvl, outc, "f32" if is_top else "act")
         if attention:
             g = attention_block(cat, p + ".2.0.0", k, lvl)

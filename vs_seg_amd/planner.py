@@ -169,7 +169,9 @@ def choose_tile(q, taps, voxels):
     return tuple(tile)
 
 
-def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=158 * 1024, mtw=None, aux_es=4) -> IgemmPlan:
+def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=158 * 1024, mtw=None, aux_es=4, in_split=0) -> IgemmPlan:
+    """in_split: the input is a two-part tensor split at that channel — a channel chunk must not straddle the split
+    unless it is the only chunk (igemm.hip chooses the part per chunk, or per DMA piece when there is one chunk)."""
     kreal, nreal = gemm_dims(kind, wshape)
     kc = round_up(kreal, 8) if kc_pad is None else kc_pad
     nt_total = (nreal + 15) // 16
@@ -181,7 +183,7 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
     else:
         mtws = [mtw]
     ntaps = len(cls.taps)
-    cands = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}, reverse=True)
+    cands = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0 and (not in_split or c == kc or in_split % c == 0)}, reverse=True)
     best = None
     for budget in (lds_budget, LDS_LIMIT - 1024):  # soft budget first (more resident workgroups), then whatever fits
         for nsplit in sorted({nsplit0, min(nt_total, 2 * nsplit0), min(nt_total, 3 * nsplit0)}):  # fewer channel tiles per workgroup when the weights do not fit
