@@ -1,64 +1,7 @@
-// Implicit-GEMM 3-D convolution on the gfx950 matrix cores.
-//
-// One kernel serves Conv3d forward, every parity class of ConvTranspose3d forward and both data gradients
-// (reference ops: ref:params/networks/blocks/convolutions.py:114-146; autograd of them at ref:params/VSparams.py:461).
-//
-//   out[q*os+oo][n] = epilogue( sum_{tap t} sum_{c} in[q*is + off_t][c] * W[t][c][n] )
-//
-// Mapping to MFMA (16x16 output tiles, wave64):
-//   * D rows   <- 16 output channels, D cols <- 16 lattice voxels ("swapped" GEMM), so after the MFMA a lane owns
-//     4 consecutive channels of one voxel and the epilogue stores 8/16 contiguous bytes per lane.
-//   * K        <- (tap, input channel).  K is cut in groups of 8 channels; lane-group g = lane>>4 of a K-step owns
-//     group ks*4+g, i.e. one 16-byte (bf16) / 32-byte (f32) LDS read per lane per K-step.  bf16: one
-//     v_mfma_f32_16x16x32_bf16 per (voxel tile, channel tile); f32: eight v_mfma_f32_16x16x4_f32 (exact fp32).
-//
-// Structure: persistent workgroups walk (tile, channel-chunk) stages.  The input halo tile [hx][hy][hz][ck] of stage s+1
-// is fetched by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip) into the second LDS buffer while stage s is
-// multiplied and stored, so every CU always has a whole tile of HBM reads in flight — most layers of this network are
-// HBM-bound, and a load->barrier->compute->store workgroup measured only ~1.6 TB/s.  Tiles are assigned
-// so that each XCD walks one contiguous eighth of the lattice (neighbouring tiles share halo rows through that XCD's L2).
-// Packed weights stay resident in LDS for single-chunk layers; per-channel epilogue constants live in LDS, so the hot
-// loop issues no ordinary global load that would make hipcc drain the DMA queue (cdna_hip_programming.md §5).
-#include "common.h"
-#include <stdlib.h>
+// Host side of the implicit-GEMM convolution: argument checks, LDS layout, tile-descriptor table, dispatch.
+// The kernel itself is in igemm_kernel.h (instantiated by igemm_inst.hip).
+#include "igemm_kernel.h"
 
-constexpr int PMAX = 8;  // 16-byte halo pieces per thread per stage (halo chunk <= 32 KiB)
-constexpr int AMAX = 8;  // 16-byte pieces per thread of the auxiliary (residual / accumulate) output tile
-
-struct IgemmK {
-  vsseg_igemm_desc d;
-  int halo[3];
-  int off_min[3];
-  int ntile[3];
-  int cgs;      // 8-channel groups per chunk
-  int w_bytes;  // packed weights per chunk
-  int h_bytes;  // halo chunk
-  int lds_ktab, lds_epi, lds_w, lds_h, lds_aux;
-  int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask: the aux tile is prefetched by DMA like the halo
-  int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (0: aux handled by the slow path)
-  int depth;      // prefetch distance in stages (1..3); the LDS rings hold depth+1 buffers
-  vsseg_tensor aux;
-  int64_t total_tiles;
-  const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
-  const struct TileDesc* tiles;
-};
-
-// Per-tile descriptor, computed once per (geometry) by a setup kernel and cached: the main kernel fetches it with one scalar
-// load per stage instead of re-deriving tile coordinates, origins and boundary flags from ~40 uniform values (which made
-// hipcc spill ~500 SGPRs per kernel and left the HBM-bound layers instruction-issue-bound).
-struct __attribute__((aligned(64))) TileDesc {
-  int64_t in_vox;   // voxel index (incl. batch) of the halo origin inside the input tensor (meaningful when interior)
-  int64_t out_vox;  // voxel index (incl. batch) of the tile's first output voxel
-  int32_t g0[3];    // halo origin coordinates (may be negative)
-  int32_t q0[3];    // lattice origin of the tile
-  int32_t n;
-  int32_t flags;    // bit 0: halo entirely inside the input; bit 1: tile entirely inside lattice and output
-};
-
-// Table order = execution order (an XCD's workgroups walk a contiguous range of the table, ~64 tiles at a time).  Tiles are
-// ordered (sample, x-band of `xb` tiles, y, x inside the band, z): the tiles in flight on one XCD then form a compact
-// xb x 1..2 x nz brick whose x- and y-neighbours were fetched at most a few steps earlier, so the halo overlap between
-// neighbouring tiles is served by that XCD's L2 instead of being fetched from HBM again.
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
   const int64_t per_sample = (int64_t)k.ntile[0] * k.ntile[1] * k.ntile[2];
@@ -92,581 +35,29 @@ __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ t
   }
 }
 
-template <typename T> struct Frag;
-template <> struct Frag<bf16_t> {
-  bf16x8 v;
-  static __device__ __forceinline__ Frag ld(const char* p) { Frag f; f.v = *reinterpret_cast<const bf16x8*>(p); return f; }
-};
-template <> struct Frag<float> {
-  float4 lo, hi;
-  static __device__ __forceinline__ Frag ld(const char* p) {
-    Frag f;
-    f.lo = *reinterpret_cast<const float4*>(p);
-    f.hi = *reinterpret_cast<const float4*>(p + 16);
-    return f;
-  }
-};
-__device__ __forceinline__ void mma(f32x4& acc, const Frag<bf16_t>& w, const Frag<bf16_t>& a) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, a.v, acc, 0, 0, 0); }
-__device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag<float>& a) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.x, a.lo.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.y, a.lo.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.z, a.lo.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.lo.w, a.lo.w, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.x, a.hi.x, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.y, a.hi.y, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.z, a.hi.z, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.w, a.hi.w, acc, 0, 0, 0);
-}
 
-typedef __attribute__((address_space(1))) const void gvoid_t;
-typedef __attribute__((address_space(3))) void lvoid_t;
-// 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
-__device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_wave_base, 16, 0, 0);
-}
-
-// s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the immediate must be a literal.  Waiting for a SMALLER count than
-// necessary is always safe (it only waits longer), so n is clamped to the largest literal provided.
-__device__ __forceinline__ void wait_vmcnt(int n) {
-#define VSSEG_VM_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
-  switch (n < 0 ? 0 : (n > 40 ? 40 : n)) {
-    VSSEG_VM_CASE(0) VSSEG_VM_CASE(1) VSSEG_VM_CASE(2) VSSEG_VM_CASE(3) VSSEG_VM_CASE(4) VSSEG_VM_CASE(5) VSSEG_VM_CASE(6) VSSEG_VM_CASE(7) VSSEG_VM_CASE(8) VSSEG_VM_CASE(9)
-    VSSEG_VM_CASE(10) VSSEG_VM_CASE(11) VSSEG_VM_CASE(12) VSSEG_VM_CASE(13) VSSEG_VM_CASE(14) VSSEG_VM_CASE(15) VSSEG_VM_CASE(16) VSSEG_VM_CASE(17) VSSEG_VM_CASE(18) VSSEG_VM_CASE(19)
-    VSSEG_VM_CASE(20) VSSEG_VM_CASE(21) VSSEG_VM_CASE(22) VSSEG_VM_CASE(23) VSSEG_VM_CASE(24) VSSEG_VM_CASE(25) VSSEG_VM_CASE(26) VSSEG_VM_CASE(27) VSSEG_VM_CASE(28) VSSEG_VM_CASE(29)
-    VSSEG_VM_CASE(30) VSSEG_VM_CASE(31) VSSEG_VM_CASE(32) VSSEG_VM_CASE(33) VSSEG_VM_CASE(34) VSSEG_VM_CASE(35) VSSEG_VM_CASE(36) VSSEG_VM_CASE(37) VSSEG_VM_CASE(38) VSSEG_VM_CASE(39)
-    VSSEG_VM_CASE(40)
+// igemm_inst.hip, compiled once per (element type, NT)
+int vsseg_igemm_launch_f32_1(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_f32_2(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_f32_3(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_f32_4(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_f32_5(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_f32_6(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_1(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_2(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_3(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_4(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_5(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+int vsseg_igemm_launch_bf16_6(const IgemmK& k, dim3 grid, int lds, hipStream_t s);
+static int launch_nt(bool f32, const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
+  typedef int (*fn_t)(const IgemmK&, dim3, int, hipStream_t);
+  static const fn_t tab[2][6] = {{vsseg_igemm_launch_bf16_1, vsseg_igemm_launch_bf16_2, vsseg_igemm_launch_bf16_3, vsseg_igemm_launch_bf16_4, vsseg_igemm_launch_bf16_5, vsseg_igemm_launch_bf16_6},
+                                 {vsseg_igemm_launch_f32_1, vsseg_igemm_launch_f32_2, vsseg_igemm_launch_f32_3, vsseg_igemm_launch_f32_4, vsseg_igemm_launch_f32_5, vsseg_igemm_launch_f32_6}};
+  if (k.d.nt < 1 || k.d.nt > 6) {
+    vsseg_set_error("vsseg_igemm: nt must be 1..6 (got %d)", k.d.nt);
+    return VSSEG_EINVAL;
   }
-#undef VSSEG_VM_CASE
-}
-
-template <typename T, int NT, int MTW>
-__global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const IgemmK k) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = sizeof(T);
-  constexpr int GB = 8 * ES;   // bytes of one 8-channel group
-  constexpr int EPP = 16 / ES; // elements per 16-byte piece
-  const vsseg_igemm_desc& d = k.d;
-  int* ktab = reinterpret_cast<int*>(smem + k.lds_ktab);
-  float* epi = reinterpret_cast<float*>(smem + k.lds_epi);  // bias | scale | shift, NT*16 each
-  char* Wl = smem + k.lds_w;
-  char* Hl = smem + k.lds_h;
-  char* Al = smem + k.lds_aux;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
-  const int split = blockIdx.y;
-  const int HY = k.halo[1], HZ = k.halo[2], CK = d.ck;
-  const int hvox = k.halo[0] * HY * HZ;
-  const int ppv = CK / EPP;  // 16-byte pieces per halo voxel
-  const int pieces = hvox * ppv;
-  const int wpieces = k.w_bytes >> 4;
-  const int cout = d.out.c;
-  const int nch = d.nchunks;
-
-  // ---- per-workgroup tables ----
-  for (int i = tid; i < d.ksteps * 4; i += 256) {
-    int off = 0;
-    if (i < d.ntaps * k.cgs) {
-      int t = i / k.cgs, cg = i - t * k.cgs;
-      int hx = d.tap_off[t][0] - k.off_min[0], hy = d.tap_off[t][1] - k.off_min[1], hz = d.tap_off[t][2] - k.off_min[2];
-      off = ((hx * HY + hy) * HZ + hz) * CK * ES + cg * GB;
-    }
-    ktab[i] = off;
-  }
-  for (int i = tid; i < NT * 16; i += 256) {
-    const int c = split * NT * 16 + i;
-    const bool ok = c < cout;
-    epi[i] = ((ok && d.bias) ? d.bias[c] : 0.f) + ((ok && d.bias2) ? d.bias2[c] : 0.f);
-    epi[NT * 16 + i] = (ok && d.scale) ? d.scale[c] : 1.f;
-    epi[2 * NT * 16 + i] = (ok && d.scale) ? d.shift[c] : 0.f;
-  }
-  if (nch == 1) {  // packed weights stay resident for the whole kernel
-    const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wpack) + (int64_t)split * k.w_bytes);
-    uint4* dst = reinterpret_cast<uint4*>(Wl);
-    for (int i = tid; i < wpieces; i += 256) dst[i] = src[i];
-  }
-  const float alpha = (d.act == VSSEG_ACT_PRELU && d.alpha) ? *d.alpha : 0.f;
-
-  // ---- per-thread constants: the halo pieces this thread fetches every stage, and the voxels it stores.
-  //      Everything that does not depend on the tile is computed once here: the per-tile work is then a handful of
-  //      32-bit adds (the unoptimised version spent ~1100 VALU+SALU instructions per tile and wave on index arithmetic
-  //      and was issue-bound at 1.7 TB/s on the HBM-bound layers).
-  const int X = d.in.x, Y = d.in.y, Z = d.in.z;
-  const unsigned in_vox_bytes = (unsigned)d.in.pitch * ES;
-  unsigned pinfo[PMAX];  // packed halo coordinates (slow path: bounds checks on boundary tiles)
-  unsigned prel[PMAX];   // byte offset relative to the halo origin voxel (fast path: interior tiles)
-#pragma unroll
-  for (int u = 0; u < PMAX; ++u) {
-    const int j = (u * 4 + wave) * 64 + lane;
-    unsigned info = 0xffffffffu, rel = 0;
-    if (j < pieces) {
-      int hv = j / ppv, c16 = j - hv * ppv;
-      int hz = hv % HZ, r = hv / HZ;
-      int hy = r % HY, hx = r / HY;
-      info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)c16 << 24);
-      rel = (unsigned)((hx * Y + hy) * Z + hz) * in_vox_bytes + (unsigned)c16 * 16u;
-    }
-    pinfo[u] = info;
-    prel[u] = rel;
-  }
-  // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  prel/pinfo keep the channel offset of the
-  // virtual concatenated row; part 1's base is biased by -csplit channels so the same offsets address it.  A chunk never
-  // straddles the split unless it is the only chunk (checked on the host), so the per-piece choice is static per thread.
-  const bool in_two = d.in.ptr2 != nullptr;
-  const int in_csplit = in_two ? d.in.csplit : 0x7fffffff;
-  unsigned p2mask = 0;  // bit u: piece u of this thread lies in part 1 (single-chunk case)
-  if (in_two && nch == 1) {
-#pragma unroll
-    for (int u = 0; u < PMAX; ++u)
-      if (pinfo[u] != 0xffffffffu && (int)(pinfo[u] >> 24) * EPP >= in_csplit) p2mask |= 1u << u;
-  }
-  const int OX = d.out.x, OY = d.out.y, OZ = d.out.z;
-  int vb[MTW];
-  unsigned vxyz[MTW];
-  unsigned ovrel[MTW];  // output voxel index relative to the tile's first output voxel
-#pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    const int v = (wave * MTW + m) * 16 + l15;
-    int vz = v % d.tile[2], r = v / d.tile[2];
-    int vy = r % d.tile[1], vx = r / d.tile[1];
-    vb[m] = (((vx * d.is[0]) * HY + vy * d.is[1]) * HZ + vz * d.is[2]) * CK * ES;
-    vxyz[m] = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16);
-    ovrel[m] = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]);
-  }
-  const unsigned out_es = d.out.dtype == VSSEG_F32 ? 4u : 2u;
-  const unsigned out_vox_bytes = (unsigned)d.out.pitch * out_es;
-  // auxiliary tile (old output for accumulate / residual / ReLU mask): [tile voxel][NT*16] fetched by DMA one tile ahead
-  const bool aux_on = k.aux_bytes > 0;
-  const unsigned aux_es = k.aux.dtype == VSSEG_F32 ? 4u : 2u;
-  const unsigned aux_vox_bytes = (unsigned)k.aux.pitch * aux_es;
-  const int aux_row = NT * 16 * (int)aux_es;  // LDS bytes per voxel
-  const int ppa = aux_row >> 4;
-  const int apieces = aux_on ? 64 * MTW * ppa : 0;
-  unsigned arel[AMAX];
-#pragma unroll
-  for (int u = 0; u < AMAX; ++u) {
-    const int j = (u * 4 + wave) * 64 + lane;
-    unsigned rel = 0xffffffffu;
-    if (j < apieces) {
-      const int v = j / ppa, c16 = j - v * ppa;
-      int vz = v % d.tile[2], r = v / d.tile[2];
-      int vy = r % d.tile[1], vx = r / d.tile[1];
-      rel = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]) * aux_vox_bytes + (unsigned)(split * NT * 16) * aux_es + (unsigned)c16 * 16u;
-    }
-    arel[u] = rel;
-  }
-  // two-part auxiliary / output tensors: same scheme (static per-piece part choice, part-1 base biased by -csplit channels)
-  const bool aux_two = aux_on && k.aux.ptr2 != nullptr;
-  unsigned a2mask = 0;
-  if (aux_two) {
-#pragma unroll
-    for (int u = 0; u < AMAX; ++u) {
-      const int j = (u * 4 + wave) * 64 + lane;
-      if (j < apieces && split * NT * 16 + (j % ppa) * (16 / (int)aux_es) >= k.aux.csplit) a2mask |= 1u << u;
-    }
-  }
-  const char* aux_base = reinterpret_cast<const char*>(k.aux.ptr);
-  const char* aux_base1 = aux_two ? reinterpret_cast<const char*>(k.aux.ptr2) - (int64_t)k.aux.csplit * aux_es : aux_base;
-  const bool out_two = d.out.ptr2 != nullptr;
-  const int out_csplit = out_two ? d.out.csplit : 0x7fffffff;
-  char* out_base = reinterpret_cast<char*>(d.out.ptr);
-  char* out_base1 = out_two ? reinterpret_cast<char*>(d.out.ptr2) - (int64_t)out_csplit * out_es : out_base;
-  const bool res_two = d.res_mode != VSSEG_RES_NONE && d.res.ptr2 != nullptr;
-  const int res_csplit = res_two ? d.res.csplit : 0x7fffffff;
-  const bool fast_store = (d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on;
-  const bool vec_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0;
-
-  // ---- tile schedule: XCD x (= blockIdx % 8) owns tiles [x*tpx, (x+1)*tpx); its workgroups stride through them ----
-  const int G = gridDim.x;
-  const bool xcd_map = (G % 8) == 0;
-  const int tpx = xcd_map ? (int)((k.total_tiles + 7) / 8) : (int)k.total_tiles;
-  const int xcd = xcd_map ? (int)(blockIdx.x & 7) : 0;
-  const int slot = xcd_map ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int S = xcd_map ? G / 8 : G;
-  const int t_first = xcd * tpx;
-  int cnt = (int)k.total_tiles - t_first;
-  if (cnt > tpx) cnt = tpx;
-  const int my_tiles = cnt > slot ? (cnt - 1 - slot) / S + 1 : 0;
-  const int nstages = my_tiles * nch;
-
-  const char* in_base = reinterpret_cast<const char*>(d.in.ptr);
-  const char* in_base1 = in_two ? reinterpret_cast<const char*>(d.in.ptr2) - (int64_t)in_csplit * ES : in_base;
-  const int64_t in_sample_bytes = (int64_t)X * Y * Z * in_vox_bytes;
-
-  const TileDesc* tiles = k.tiles + (t_first + slot);  // this workgroup's tiles: tiles[i * S]
-  // descriptors are fetched (scalar loads) one tile ahead of their first use, so their latency never sits in front of a DMA issue
-  TileDesc td_next = tiles[0];  // descriptor of the next tile to be issued
-  int ti_issue = 0, ti_cur = 0;
-  int ch_issue = 0, ch_cur = 0;
-  const int D = k.depth, nbuf = D + 1;
-  int buf_issue = 0, buf_cur = 0, abuf_issue = 0, abuf_cur = 0;  // ring positions (stage ring / per-tile auxiliary ring)
-  // VMEM instructions this wave issues per stage: the counted waits below rely on these being exact and wave-uniform
-  int nh = 0, na = 0, nw = 0;
-#pragma unroll
-  for (int u = 0; u < PMAX; ++u) nh += ((u * 4 + wave) * 64 < pieces) ? 1 : 0;
-#pragma unroll
-  for (int u = 0; u < AMAX; ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
-  if (nch > 1)
-    for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
-  // store instructions a wave issues in the fast epilogue of one tile (exactly one 8/16-byte store per valid 16-channel
-  // block and M tile; the scalar-store variant and the slow epilogue count as 0 = their stores are simply waited for)
-  int nst_fast = 0;
-  if (vec_store) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) nst_fast += (split * NT * 16 + t * 16 < cout) ? MTW : 0;
-  }
-  int st_h0 = 0, st_h1 = 0, st_h2 = 0;
-  auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
-    const int ch = ch_issue;
-    const TileDesc td = td_next;
-    if (++ch_issue == nch) {
-      ch_issue = 0;
-      ++ti_issue;
-      if (ti_issue < my_tiles) td_next = tiles[(int64_t)ti_issue * S];  // uniform address: scalar loads, consumed a whole stage later
-    }
-    const int c0 = ch * CK;
-    char* Hdst = Hl + buf_issue * k.h_bytes;
-    const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
-    if (interior) {
-      const int64_t ooff = td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
-      const char* origin = in_base + ooff;
-      if (!in_two) {
-#pragma unroll
-        for (int u = 0; u < PMAX; ++u) {
-          if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
-          if (pinfo[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
-        }
-      } else {
-        const char* origin1 = in_base1 + ooff;
-        const unsigned m2 = nch == 1 ? p2mask : (c0 >= in_csplit ? 0xffffffffu : 0u);
-#pragma unroll
-        for (int u = 0; u < PMAX; ++u) {
-          if ((u * 4 + wave) * 64 >= pieces) break;
-          if (pinfo[u] != 0xffffffffu) dma16(((m2 >> u) & 1u ? origin1 : origin) + prel[u], Hdst + (u * 4 + wave) * 1024);
-        }
-      }
-    } else {
-      const int gx0 = td.g0[0], gy0 = td.g0[1], gz0 = td.g0[2];
-      const int64_t soff = (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
-      const char* sample = in_base + soff;
-      const char* sample1 = in_base1 + soff;
-#pragma unroll
-      for (int u = 0; u < PMAX; ++u) {
-        if ((u * 4 + wave) * 64 >= pieces) break;
-        const unsigned info = pinfo[u];
-        if (info != 0xffffffffu) {
-          const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
-          const int c = c0 + (int)(info >> 24) * EPP;
-          const bool ok = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
-          const void* src = ok ? (const void*)((c >= in_csplit ? sample1 : sample) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
-          dma16(src, Hdst + (u * 4 + wave) * 1024);
-        }
-      }
-    }
-    if (aux_on && ch == 0) {
-      // partial tiles use the slow epilogue (ordinary loads) but still issue the same number of DMAs (from the zero page),
-      // so that the per-stage instruction count the vmcnt arithmetic relies on stays exact
-      const bool whole = (td.flags & 2) != 0;
-      const char* aorigin = aux_base + td.out_vox * aux_vox_bytes;
-      const char* aorigin1 = aux_base1 + td.out_vox * aux_vox_bytes;
-      char* Adst = Al + abuf_issue * k.aux_bytes;
-#pragma unroll
-      for (int u = 0; u < AMAX; ++u) {
-        if ((u * 4 + wave) * 64 >= apieces) break;
-        if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
-      }
-      if (++abuf_issue == nbuf) abuf_issue = 0;
-    }
-    if (nch > 1) {
-      const char* wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
-      char* Wdst = Wl + buf_issue * k.w_bytes;
-      for (int j0 = wave * 64; j0 < wpieces; j0 += 256)
-        if (j0 + lane < wpieces) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);
-    }
-    if (++buf_issue == nbuf) buf_issue = 0;
-  };
-
-  f32x4 acc[MTW][NT];
-  float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ssum[t][r] = ssq[t][r] = 0.f;
-
-  __syncthreads();  // tables / resident weights / epilogue constants written above are visible before the pipeline starts
-  for (int j = 0; j < D && j < nstages; ++j) issue(j);  // stages 0..D-1 in flight
-  for (int s = 0; s < nstages; ++s) {
-    // Stage s has landed once at most the DMAs of the younger stages s+1..s+D-1 remain (VMEM ops complete in issue order).  The
-    // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
-    // Also younger than stage s's DMAs, and still allowed to be in flight: the output stores of the last D stages (vmcnt retires
-    // loads and stores of a wave in issue order).  Waiting for them too would put a write-acknowledge latency into every stage.
-    if (D == 1) {
-      wait_vmcnt(st_h0);
-    } else {
-      int younger = st_h0 + st_h1 + (D >= 3 ? st_h2 : 0), chj = ch_cur;
-      for (int j = 1; j < D && s + j < nstages; ++j) {
-        if (++chj == nch) chj = 0;
-        younger += nh + nw + (chj == 0 ? na : 0);
-      }
-      wait_vmcnt(younger);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring
-    if (s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
-    const TileDesc tc = tiles[(int64_t)ti_cur * S];  // this stage's tile (scalar load, consumed in the epilogue)
-    const int ch = ch_cur;
-    if (ch == 0) {
-#pragma unroll
-      for (int m = 0; m < MTW; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const char* Hs = Hl + buf_cur * k.h_bytes;
-    const char* Ws = nch > 1 ? Wl + buf_cur * k.w_bytes : Wl;
-    if (++buf_cur == nbuf) buf_cur = 0;
-    if constexpr (NT <= 2) {
-      // HBM-bound configurations (<= 32 output channels per workgroup): plain K loop — two resident workgroups per CU hide the
-      // LDS latency, and the registers of a second fragment set would cost that second workgroup
-      const char* Wlane = Ws + lane * GB;
-      for (int ks = 0; ks < d.ksteps; ++ks) {
-        const int koff = ktab[ks * 4 + g];
-        Frag<T> w[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) w[t] = Frag<T>::ld(Wlane + (ks * NT + t) * 64 * GB);
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) {
-          Frag<T> a = Frag<T>::ld(Hs + vb[m] + koff);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) mma(acc[m][t], w[t], a);
-        }
-      }
-    } else
-    {  // K loop, software-pipelined by hand with two fragment sets (no register moves): the fragments of K-step ks+1 are
-       // read from LDS before the MFMAs of ks issue (with 1-2 waves per SIMD nothing else hides the ds_read -> MFMA latency)
-      Frag<T> w0[NT], a0[MTW], w1[NT], a1[MTW];
-      const char* Wlane = Ws + lane * GB;
-      const int nks = d.ksteps;
-      {
-        const int koff = ktab[g];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + t * 64 * GB);
-#pragma unroll
-        for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
-      }
-      for (int ks = 0; ks < nks; ks += 2) {
-        const bool has1 = ks + 1 < nks;
-        if (has1) {
-          const int koff = ktab[(ks + 1) * 4 + g];
-#pragma unroll
-          for (int t = 0; t < NT; ++t) w1[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
-#pragma unroll
-          for (int m = 0; m < MTW; ++m) a1[m] = Frag<T>::ld(Hs + vb[m] + koff);
-        }
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) mma(acc[m][t], w0[t], a0[m]);
-        if (has1) {
-          if (ks + 2 < nks) {
-            const int koff = ktab[(ks + 2) * 4 + g];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + ((ks + 2) * NT + t) * 64 * GB);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
-          }
-#pragma unroll
-          for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mma(acc[m][t], w1[t], a1[m]);
-        }
-      }
-    }
-    st_h2 = st_h1; st_h1 = st_h0; st_h0 = 0;  // store instructions of the last three stages (this stage's are added below)
-    if (++ch_cur != nch) continue;
-    ch_cur = 0;
-
-    // ---- epilogue of the current tile ----
-    ++ti_cur;
-    const bool whole = (tc.flags & 2) != 0;
-    char* out_tile = out_base + tc.out_vox * out_vox_bytes;
-    const int64_t out_delta = out_base1 - out_base;  // 0 for an ordinary tensor
-    const char* Aux = Al + abuf_cur * k.aux_bytes;
-    if (++abuf_cur == nbuf) abuf_cur = 0;
-    if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
-      st_h0 = nst_fast;
-#pragma unroll
-      for (int m = 0; m < MTW; ++m) {
-        char* op = out_tile + ovrel[m] * out_vox_bytes;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int cl = t * 16 + g * 4;
-          const int c = split * NT * 16 + cl;
-          if (c >= cout) continue;
-          const float4 bi = *reinterpret_cast<const float4*>(epi + cl);
-          float val[4] = {acc[m][t][0] + bi.x, acc[m][t][1] + bi.y, acc[m][t][2] + bi.z, acc[m][t][3] + bi.w};
-          if (d.stats) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { ssum[t][r] += val[r]; ssq[t][r] += val[r] * val[r]; }
-          }
-          if (d.scale) {
-            const float4 sc = *reinterpret_cast<const float4*>(epi + NT * 16 + cl), sh = *reinterpret_cast<const float4*>(epi + 2 * NT * 16 + cl);
-            val[0] = val[0] * sc.x + sh.x; val[1] = val[1] * sc.y + sh.y; val[2] = val[2] * sc.z + sh.z; val[3] = val[3] * sc.w + sh.w;
-          }
-          if (d.act == VSSEG_ACT_PRELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) val[r] = val[r] > 0.f ? val[r] : alpha * val[r];
-          } else if (d.act == VSSEG_ACT_RELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) val[r] = fmaxf(val[r], 0.f);
-          } else if (d.act == VSSEG_ACT_SIGMOID) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) val[r] = 1.f / (1.f + __expf(-val[r]));
-          }
-          if (aux_on) {
-            const char* ap = Aux + ((wave * MTW + m) * 16 + l15) * aux_row + cl * (int)aux_es;
-            const float4 av = aux_es == 4 ? *reinterpret_cast<const float4*>(ap) : ld4(reinterpret_cast<const bf16_t*>(ap));
-            if (k.aux_mode == 3) {
-              val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
-            } else {
-              val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
-            }
-          }
-          char* opt = op + (split * NT * 16 + t * 16 >= out_csplit ? out_delta : 0);  // uniform per 16-channel block
-          if (vec_store) {
-            if (out_es == 4) st4(reinterpret_cast<float*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
-            else st4(reinterpret_cast<bf16_t*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
-          } else {  // 1- and 2-channel outputs (attention map, logits): scalar stores of the valid channels
-            const int nc = min(4, cout - c);
-            for (int r = 0; r < nc; ++r) {
-              if (out_es == 4) reinterpret_cast<float*>(opt)[c + r] = val[r];
-              else reinterpret_cast<bf16_t*>(opt)[c + r] = f2bf(val[r]);
-            }
-          }
-        }
-      }
-    } else {
-    const int n = tc.n, q0x = tc.q0[0], q0y = tc.q0[1], q0z = tc.q0[2];
-#pragma unroll
-    for (int m = 0; m < MTW; ++m) {
-      const int qx = q0x + (int)(vxyz[m] & 255u), qy = q0y + (int)((vxyz[m] >> 8) & 255u), qz = q0z + (int)(vxyz[m] >> 16);
-      const int ox = qx * d.os[0] + d.oo[0], oy = qy * d.os[1] + d.oo[1], oz = qz * d.os[2] + d.oo[2];
-      const bool vok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && ox < OX && oy < OY && oz < OZ;
-      const int64_t ovox = (((int64_t)n * OX + ox) * OY + oy) * OZ + oz;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int cl = t * 16 + g * 4;  // channel inside this workgroup's NT*16 slice
-        const int c = split * NT * 16 + cl;
-        if (!vok || c >= cout) continue;
-        float val[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
-        const int nc = min(4, cout - c);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r >= nc) break;
-          float x = val[r] + epi[cl + r];
-          if (d.stats) { ssum[t][r] += x; ssq[t][r] += x * x; }
-          x = x * epi[NT * 16 + cl + r] + epi[2 * NT * 16 + cl + r];
-          if (d.act == VSSEG_ACT_PRELU) x = x > 0.f ? x : alpha * x;
-          else if (d.act == VSSEG_ACT_RELU) x = fmaxf(x, 0.f);
-          else if (d.act == VSSEG_ACT_SIGMOID) x = 1.f / (1.f + __expf(-x));
-          if (d.res_mode != VSSEG_RES_NONE) {
-            const bool r2 = c >= res_csplit;
-            const void* rbase = r2 ? d.res.ptr2 : d.res.ptr;
-            const int64_t ro = ovox * d.res.pitch + c + r - (r2 ? res_csplit : 0);
-            float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(rbase)[ro] : bf2f(reinterpret_cast<const bf16_t*>(rbase)[ro]);
-            x = d.res_mode == VSSEG_RES_ADD ? x + rv : (rv > 0.f ? x : 0.f);
-          }
-          val[r] = x;
-        }
-        const int64_t oo = ovox * d.out.pitch + c;
-        char* obase = c >= out_csplit ? out_base1 : out_base;
-        if (d.out.dtype == VSSEG_F32) {
-          float* op = reinterpret_cast<float*>(obase) + oo;
-          if (nc == 4 && (d.out.pitch & 3) == 0 && !d.accumulate) st4(op, make_float4(val[0], val[1], val[2], val[3]));
-          else
-            for (int r = 0; r < nc; ++r) op[r] = d.accumulate ? op[r] + val[r] : val[r];
-        } else {
-          bf16_t* op = reinterpret_cast<bf16_t*>(obase) + oo;
-          if (nc == 4 && (d.out.pitch & 3) == 0) {
-            if (d.accumulate) {
-              float4 o = ld4(op);
-              val[0] += o.x; val[1] += o.y; val[2] += o.z; val[3] += o.w;
-            }
-            st4(op, make_float4(val[0], val[1], val[2], val[3]));
-          } else
-            for (int r = 0; r < nc; ++r) op[r] = f2bf(d.accumulate ? bf2f(op[r]) + val[r] : val[r]);
-        }
-      }
-    }
-    }  // slow epilogue
-  }
-
-  if (d.stats) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics
-    __syncthreads();
-    float* red = epi;  // reuse [2][NT*16]
-    for (int i = tid; i < 2 * NT * 16; i += 256) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = ssum[t][r], q = ssq[t][r];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l15 == 0) {
-          atomicAdd(&red[t * 16 + g * 4 + r], s);
-          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
-        }
-      }
-    __syncthreads();
-    double* st = d.stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * d.stats_stride;
-    for (int i = tid; i < 2 * NT * 16; i += 256) {
-      int which = i / (NT * 16), cc = i - which * NT * 16;
-      int c = split * NT * 16 + cc;
-      if (c < cout) atomicAdd(&st[which * d.stats_stride + c], (double)red[i]);
-    }
-  }
-}
-
-template <typename T, int NT, int MTW> static int launch(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, MTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  // persistent grid = resident workgroups only (registers AND LDS), otherwise the late workgroups form a tail
-  static int cached_lds = -1, cached_per_cu = 1;
-  if (cached_lds != lds) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW>, 256, lds) != hipSuccess || n < 1) n = 1;
-    cached_per_cu = n > 4 ? 4 : n;
-    cached_lds = lds;
-  }
-  int64_t gx = 256ll * cached_per_cu;
-  if (gx > k.total_tiles) gx = k.total_tiles;
-  grid.x = (unsigned)gx;
-  hipLaunchKernelGGL((igemm_kernel<T, NT, MTW>), grid, dim3(256), lds, s, k);
-  VSSEG_LAUNCH_CHECK("vsseg_igemm");
-  return VSSEG_OK;
-}
-template <typename T, int NT> static int launch_mtw(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
-  switch (k.d.mtw) {
-    case 1: return launch<T, NT, 1>(k, grid, lds, s);
-    case 2: return launch<T, NT, 2>(k, grid, lds, s);
-    case 4: return launch<T, NT, 4>(k, grid, lds, s);
-  }
-  vsseg_set_error("vsseg_igemm: mtw must be 1, 2 or 4 (got %d)", k.d.mtw);
-  return VSSEG_EINVAL;
-}
-template <typename T> static int launch_nt(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
-  switch (k.d.nt) {
-    case 1: return launch_mtw<T, 1>(k, grid, lds, s);
-    case 2: return launch_mtw<T, 2>(k, grid, lds, s);
-    case 3: return launch_mtw<T, 3>(k, grid, lds, s);
-    case 4: return launch_mtw<T, 4>(k, grid, lds, s);
-    case 5: return launch_mtw<T, 5>(k, grid, lds, s);
-    case 6: return launch_mtw<T, 6>(k, grid, lds, s);
-  }
-  vsseg_set_error("vsseg_igemm: nt must be 1..6 (got %d)", k.d.nt);
-  return VSSEG_EINVAL;
+  return tab[f32 ? 1 : 0][k.d.nt - 1](k, grid, lds, s);
 }
 
 #include <map>
@@ -732,6 +123,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   if (d->accumulate && d->res_mode == VSSEG_RES_NONE) { k.aux_mode = 1; k.aux = d->out; }
   else if (!d->accumulate && d->res_mode == VSSEG_RES_ADD) { k.aux_mode = 2; k.aux = d->res; }
   else if (!d->accumulate && d->res_mode == VSSEG_RES_RELUMASK) { k.aux_mode = 3; k.aux = d->res; }
+  if (d->stats) k.aux_mode = 0;  // statistics + residual in one launch does not occur in this network: generic epilogue
   if (k.aux_mode) {
     const int aes = k.aux.dtype == VSSEG_F32 ? 4 : 2;
     const int row = d->nt * 16 * aes;
@@ -750,6 +142,8 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? nbuf : 1);
   k.lds_h = off; off += nbuf * k.h_bytes;
   k.lds_aux = off; off += nbuf * k.aux_bytes;
+  k.npu = (k.h_bytes / 16 + 255) / 256;
+  k.lds_pinfo = off; off += (k.npu + d->mtw) * 1024;  // slow-path coordinate tables (boundary / partial tiles)
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }
@@ -769,6 +163,5 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   k.tiles = tile_table(k, as_stream(stream));
   VSSEG_CHECK(k.tiles, "vsseg_igemm: could not allocate the tile table");
   dim3 grid(1, (unsigned)d->nsplit);  // grid.x is set to the resident workgroup count by launch<>()
-  if (d->in.dtype == VSSEG_F32) return launch_nt<float>(k, grid, lds, as_stream(stream));
-  return launch_nt<bf16_t>(k, grid, lds, as_stream(stream));
+  return launch_nt(d->in.dtype == VSSEG_F32, k, grid, lds, as_stream(stream));
 }

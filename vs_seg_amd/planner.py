@@ -130,11 +130,13 @@ def igemm_halo_bytes(tile, is_, taps, ck, es):
 
 
 def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=4, depth=1):
-    """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers."""
+    """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers | aux | coordinate tables."""
     w = ksteps * nt * 64 * 8 * es
     nbuf = depth + 1
     aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
-    return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * igemm_halo_bytes(tile, is_, taps, ck, es) + aux
+    hb = igemm_halo_bytes(tile, is_, taps, ck, es)
+    tables = ((hb // 16 + 255) // 256 + mtw) * 1024  # per-thread coordinate tables of the boundary-tile paths
+    return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * hb + aux + tables
 
 
 def _pow2_floor(v):
