@@ -42,7 +42,7 @@ def main():
     w = torch.randn(a.cout, a.cin, *k) / (a.cin * k[0] * k[1] * k[2]) ** 0.5
     cls = P.lattice_classes(a.kind, k, s)[0]
     odims = P.out_dims("conv_fwd", a.dims, k, s)
-    plan = P.plan_igemm(a.kind, tuple(w.shape), cls, odims, es, kc_pad=P.round_up(a.cin, 8), mtw=a.mtw, lds_budget=a.lds_budget)
+    plan = P.plan_igemm(a.kind, tuple(w.shape), cls, odims, es, kc_pad=P.round_up(a.cin, 8), mtw=a.mtw, lds_budget=a.lds_budget, aux_es=0)
     if a.tile or a.ck:
         import dataclasses
 
@@ -51,7 +51,7 @@ def main():
         ksteps = (plan.ntaps * (ck // 8) + 3) // 4
         plan = dataclasses.replace(plan, tile=tile, ck=ck, nchunks=plan.kc // ck, ksteps=ksteps, mtw=tile[0] * tile[1] * tile[2] // 64)
         plan.pack_map = P.pack_map(plan, tuple(w.shape))
-        plan.lds = P.igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, plan.nt, plan.mtw, es, plan.kc // ck)
+        plan.lds = P.igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, plan.nt, plan.mtw, es, plan.kc // ck, 0)
     if a.depth:
         plan.depth = a.depth
         plan.lds = P.igemm_lds_bytes(plan.tile, cls.is_, cls.taps, plan.ck, plan.ksteps, plan.nt, plan.mtw, es, plan.nchunks, 0, a.depth)

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   char* Hl = smem + k.lds_h;
   char* Al = smem + k.lds_aux;
   unsigned* pinfo_l = reinterpret_cast<unsigned*>(smem + k.lds_pinfo);  // [u][256] packed halo coordinates of this thread's pieces (boundary tiles only)
-  unsigned* vxyz_l = pinfo_l + k.npu * 256;                             // [m][256] packed tile coordinates of this thread's voxels (partial tiles only)
+  unsigned* vxyz_l = pinfo_l + k.npu * 256;                             // [64*MTW] packed tile coordinates of the tile's voxels (partial tiles only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int split = blockIdx.y;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     int vz = v % d.tile[2], r = v / d.tile[2];
     int vy = r % d.tile[1], vx = r / d.tile[1];
     vb[m] = (((vx * d.is[0]) * HY + vy * d.is[1]) * HZ + vz * d.is[2]) * CK * ES;
-    vxyz_l[m * 256 + tid] = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16);
+    if (g == 0) vxyz_l[v] = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16);
     ovrel[m] = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]);
   }
   const unsigned out_es = d.out.dtype == VSSEG_F32 ? 4u : 2u;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     const int n = tc.n, q0x = tc.q0[0], q0y = tc.q0[1], q0z = tc.q0[2];
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
-      const unsigned vx_ = vxyz_l[m * 256 + tid];
+      const unsigned vx_ = vxyz_l[(wave * MTW + m) * 16 + l15];
       const int qx = q0x + (int)(vx_ & 255u), qy = q0y + (int)((vx_ >> 8) & 255u), qz = q0z + (int)(vx_ >> 16);
       const int ox = qx * d.os[0] + d.oo[0], oy = qy * d.os[1] + d.oo[1], oz = qz * d.os[2] + d.oo[2];
       const bool vok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && ox < OX && oy < OY && oz < OZ;

@@ -9,6 +9,7 @@ torch tensors are used only as device-memory containers.  There is no CPU/eager 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -56,9 +57,22 @@ class ParamLayout:
 
 
 @dataclass
+class _Choice:
+    """One implicit-GEMM launch of a layer (one lattice class): the candidate plans and, once lowered, the chosen one."""
+
+    cands: List[P.IgemmPlan]  # default (heuristic) plan first
+    woff: int  # offset of the layer's weight inside the flat parameter buffer
+    wshape2: Optional[tuple] = None  # merged 1x1x1 residual convolution: its weight shape ...
+    woff2: int = 0  # ... and flat offset
+    chosen: Optional[P.IgemmPlan] = None
+    map_off: int = -1  # element offset of the chosen plan's packed weights inside Plan.wpack
+    tuned_ms: Optional[list] = None  # autotuner measurements, one per candidate
+
+
+@dataclass
 class _ConvPlans:
-    fwd: list  # [(IgemmPlan, wpack element offset)]
-    dgrad: list
+    fwd: List[_Choice]
+    dgrad: List[_Choice]
     wgrad: Optional[P.WgradPlan]
 
 
@@ -135,14 +149,13 @@ class Plan:
     # ------------------------------------------------------------------ conv planning + weight pack buffer
     def _plan_layers(self):
         eng = self.eng
-        maps: List[np.ndarray] = []
+        self._maps: List[np.ndarray] = []
+        self._maps2: List[np.ndarray] = []
         self._map_len = 0
-
-        def add_map(m: np.ndarray, param_off: int) -> int:
-            off = self._map_len
-            maps.append(np.where(m >= 0, m + param_off, -1).astype(np.int32))
-            self._map_len += m.size
-            return off
+        self._wpack_fixups: list = []  # (descriptor, element offset): wpack is allocated after every launch chose its plan
+        # Autotune (default on a GPU): every launch measures its candidate plans on the real buffers at lowering time and keeps
+        # the fastest.  VSSEG_AUTOTUNE=0 keeps the heuristic plan (deterministic; what the CPU dry-run lowering always uses).
+        self.tune = (not eng.dry_run) and os.environ.get("VSSEG_AUTOTUNE", "1") != "0"
 
         # a 1x1x1 residual conv added to a plain (no BatchNorm) conv of the same input merges into that conv's centre tap
         plain = {op.out.name: op for op in eng.prog.ops if isinstance(op, ConvPlain)}
@@ -154,10 +167,17 @@ class Plan:
                 if a.x is op.x and a.act == "none" and a.layer.kernel == (1, 1, 1) and all(k % 2 == 1 for k in op.layer.kernel):
                     self.merged[a.layer.prefix] = op
                     self.absorbs[op.layer.prefix] = a
-        maps2: List[np.ndarray] = []
 
-        def add_map2(m2, param_off2, n):
-            maps2.append(np.full(n, -1, np.int32) if m2 is None else np.where(m2 >= 0, m2 + param_off2, -1).astype(np.int32))
+        def choices(kind, Lr, q, kc_pad, aux_es, in_split, absorbed):
+            out = []
+            woff = eng.layout.param_off[Lr.wkey][0]
+            for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
+                if self.tune:
+                    cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)
+                else:
+                    cands = [P.plan_igemm(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)]
+                out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0))
+            return out
 
         self.cplans: Dict[str, _ConvPlans] = {}
         for op in eng.prog.ops:
@@ -168,55 +188,100 @@ class Plan:
                 self.cplans[Lr.prefix] = _ConvPlans([], [], None)
                 continue
             absorbed = self.absorbs.get(Lr.prefix)
-            woff2 = eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0
-            woff = eng.layout.param_off[Lr.wkey][0]
             dims_in = self.lv[Lr.level]
             kind = "convT_fwd" if Lr.transposed else "conv_fwd"
             dims_out = P.out_dims(kind, dims_in, Lr.kernel, Lr.stride)
             assert dims_out == self.lv[Lr.out_level]
-            fwd, dgrad, wg = [], [], None
-            for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
-                aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
-                pl = P.plan_igemm(kind, Lr.wshape, cls, dims_in if Lr.transposed else dims_out, eng.es, kc_pad=op.x.c, aux_es=aux_es, in_split=op.x.parts[0].c if op.x.parts else 0)
-                fwd.append((pl, add_map(pl.pack_map, woff)))
-                add_map2(P.pack_map_centre(pl, absorbed.layer.wshape) if absorbed is not None else None, woff2, pl.pack_map.size)
+            aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
+            fwd = choices(kind, Lr, dims_in if Lr.transposed else dims_out, op.x.c, aux_es, op.x.parts[0].c if op.x.parts else 0, absorbed)
+            dgrad, wg = [], None
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
-                    for cls in P.lattice_classes(dk, Lr.kernel, Lr.stride):
-                        q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                        pl = P.plan_igemm(dk, Lr.wshape, cls, q, eng.es, kc_pad=P.round_up(Lr.cout, 8), aux_es=eng.es)
-                        dgrad.append((pl, add_map(pl.pack_map, woff)))
-                        add_map2(P.pack_map_centre(pl, absorbed.layer.wshape) if absorbed is not None else None, woff2, pl.pack_map.size)
+                    q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
+                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg)
-        self.pack_map = torch.from_numpy(np.concatenate(maps)).to(eng.device)
-        self.pack_map2 = torch.from_numpy(np.concatenate(maps2)).to(eng.device) if self.absorbs else None
+
+    def _register(self, ch: _Choice, pl: P.IgemmPlan):
+        """Append the chosen plan's weight gather map(s) to the step's pack list."""
+        ch.chosen, ch.map_off = pl, self._map_len
+        self._maps.append(np.where(pl.pack_map >= 0, pl.pack_map + ch.woff, -1).astype(np.int32))
+        if ch.wshape2 is not None:
+            m2 = P.pack_map_centre(pl, ch.wshape2)
+            self._maps2.append(np.where(m2 >= 0, m2 + ch.woff2, -1).astype(np.int32))
+        else:
+            self._maps2.append(np.full(pl.pack_map.size, -1, np.int32))
+        self._map_len += pl.pack_map.size
+
+    def _finish_pack(self):
+        eng = self.eng
+        self.pack_map = torch.from_numpy(np.concatenate(self._maps)).to(eng.device)
+        self.pack_map2 = torch.from_numpy(np.concatenate(self._maps2)).to(eng.device) if self.absorbs else None
         assert self.pack_map2 is None or self.pack_map2.numel() == self.pack_map.numel()
         self.wpack = torch.zeros(self._map_len, dtype=eng.tdtype, device=eng.device)
+        for d, off in self._wpack_fixups:
+            d.wpack = self.wpack.data_ptr() + eng.es * off
+        del self._maps, self._maps2, self._wpack_fixups
 
-    def _igemm(self, lst, pl: P.IgemmPlan, woff: int, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
-        d = L.IgemmDesc()
-        d.inp, d.out = inp, out
+    @staticmethod
+    def _fill_desc(d: L.IgemmDesc, pl: P.IgemmPlan):
         d.q, d.is_, d.os, d.oo = L.i3(pl.q), L.i3(pl.cls.is_), L.i3(pl.cls.os), L.i3(pl.cls.oo)
         d.ntaps = pl.ntaps
         for t, (off, _) in enumerate(pl.cls.taps):
             d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
-        d.wpack = self.wpack.data_ptr() + self.eng.es * woff
+
+    def _autotune(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
+        """Measure every candidate of one launch with its real operands and epilogue (HIP events, best of 3 after a warm-up)."""
+        eng, lib = self.eng, self.eng.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        times = []
+        for pl in ch.cands:
+            m = torch.from_numpy(np.where(pl.pack_map >= 0, pl.pack_map + ch.woff, -1).astype(np.int32)).to(eng.device)
+            wp = torch.empty(m.numel(), dtype=eng.tdtype, device=eng.device)
+            L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), m.data_ptr(), None, wp.data_ptr(), m.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
+            self._fill_desc(d, pl)
+            d.wpack = wp.data_ptr()
+            if lib.vsseg_igemm(C.byref(d), stream):  # a candidate the kernel rejects is simply not chosen
+                times.append(float("inf"))
+                continue
+            best = float("inf")
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                lib.vsseg_igemm(C.byref(d), stream)
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            times.append(best)
+        ch.tuned_ms = times
+        i = int(np.argmin(times))
+        if times[i] > 0.97 * times[0]:  # keep the default unless a candidate is clearly faster (timer noise on the tiny layers)
+            i = 0
+        return ch.cands[i]
+
+    def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
+        d = L.IgemmDesc()
+        d.inp, d.out = inp, out
         d.bias, d.bias2, d.scale, d.shift, d.alpha = bias or None, bias2 or None, scale or None, shift or None, alpha or None
         d.act, d.res_mode, d.accumulate = act, res_mode, accumulate
         if res is not None:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
+        pl = self._autotune(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
+        self._register(ch, pl)
+        self._fill_desc(d, pl)
+        self._wpack_fixups.append((d, ch.map_off))
         self.keep.append(d)
         nvalid = self.n  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
-        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ks={pl.ksteps} D={pl.depth} lds={pl.lds}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+        tuned = "" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]"
+        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
@@ -257,15 +322,15 @@ class Plan:
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
                 if self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                    for pl, woff in cp.fwd:
-                        self._igemm(F, pl, woff, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
+                    for ch in cp.fwd:
+                        self._igemm(F, ch, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
                 else:
                     F.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
-                    for pl, woff in cp.fwd:
-                        self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
+                    for ch in cp.fwd:
+                        self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
                                     res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
@@ -274,8 +339,8 @@ class Plan:
                 absorbed = self.absorbs.get(Lr.prefix)
                 xin, out = self._desc(op.x), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
-                for pl, woff in cp.fwd:
-                    self._igemm(F, pl, woff, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
+                for ch in cp.fwd:
+                    self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
                                 res_mode=L.RES_ADD if res is not None else L.RES_NONE)
             elif isinstance(op, AttGate):
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
@@ -284,6 +349,7 @@ class Plan:
         self.out_logits = self._alloc(prog.logits, self.bufs)
         self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
         if not self.train:
+            self._finish_pack()
             return
 
         # ---- backward
@@ -352,8 +418,8 @@ class Plan:
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
-                for pl, woff in cp.dgrad:
-                    self._igemm(B, pl, woff, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
+                for ch in cp.dgrad:
+                    self._igemm(B, ch, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
@@ -397,6 +463,7 @@ class Plan:
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
                 B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey)]])
+        self._finish_pack()
 
     def _index_slots(self):
         self.seed_slots, self.ext_slots = [], []
@@ -458,6 +525,7 @@ class Engine:
         if not flat.is_cuda and not dry_run:  # dry_run: build plans on CPU to check the lowering (tests); nothing can be launched
             raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
         self.device = flat.device
+        self.dry_run = dry_run
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
         self.es = 2 if dtype == "bf16" else 4

@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import itertools
 from dataclasses import dataclass, field
-from typing import List, Sequence, Tuple
+from typing import Optional,  List, Sequence, Tuple
 
 import numpy as np
 
@@ -135,7 +135,7 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
     nbuf = depth + 1
     aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
     hb = igemm_halo_bytes(tile, is_, taps, ck, es)
-    tables = ((hb // 16 + 255) // 256 + mtw) * 1024  # per-thread coordinate tables of the boundary-tile paths
+    tables = ((hb // 16 + 255) // 256) * 1024 + mtw * 256  # coordinate tables of the boundary-tile paths
     return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * hb + aux + tables
 
 
@@ -171,9 +171,19 @@ def choose_tile(q, taps, voxels):
     return tuple(tile)
 
 
+def _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw, nt, nsplit, ck, aux_es) -> Optional[IgemmPlan]:
+    ntaps = len(cls.taps)
+    ksteps = (ntaps * (ck // 8) + 3) // 4
+    lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw, es, kc // ck, aux_es)
+    if lds > LDS_LIMIT - 1024 or igemm_halo_bytes(tile, cls.is_, cls.taps, ck, es) > HALO_MAX:
+        return None
+    return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tuple(tile), mtw, nt, nsplit, ck, kc // ck, ksteps, lds, 1)
+
+
 def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=158 * 1024, mtw=None, aux_es=4, in_split=0) -> IgemmPlan:
-    """in_split: the input is a two-part tensor split at that channel — a channel chunk must not straddle the split
-    unless it is the only chunk (igemm.hip chooses the part per chunk, or per DMA piece when there is one chunk)."""
+    """The default (heuristic) plan.  in_split: the input is a two-part tensor split at that channel — a channel chunk must
+    not straddle the split unless it is the only chunk (igemm_kernel.h chooses the part per chunk, or per DMA piece when
+    there is one chunk).  `candidate_plans` lists the alternatives the engine's autotuner measures against this one."""
     kreal, nreal = gemm_dims(kind, wshape)
     kc = round_up(kreal, 8) if kc_pad is None else kc_pad
     nt_total = (nreal + 15) // 16
@@ -184,10 +194,9 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
         mtws = [m for m in (4, 2, 1) if m <= mtw0]
     else:
         mtws = [mtw]
-    ntaps = len(cls.taps)
     cands = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0 and (not in_split or c == kc or in_split % c == 0)}, reverse=True)
     best = None
-    for budget in (lds_budget, LDS_LIMIT - 1024):  # soft budget first (more resident workgroups), then whatever fits
+    for budget in (lds_budget, LDS_LIMIT - 1024):  # soft budget first, then whatever fits
         for nsplit in sorted({nsplit0, min(nt_total, 2 * nsplit0), min(nt_total, 3 * nsplit0)}):  # fewer channel tiles per workgroup when the weights do not fit
             nt = (nt_total + nsplit - 1) // nsplit
             for mtw_ in mtws:  # a smaller voxel tile when even the smallest channel chunk does not fit (stride-2 3x3x3 halos in fp32)
@@ -195,10 +204,9 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
                     continue
                 tile = choose_tile(q, cls.taps, 64 * mtw_)
                 for ck in cands:
-                    ksteps = (ntaps * (ck // 8) + 3) // 4
-                    lds = igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, nt, mtw_, es, kc // ck, aux_es)
-                    if lds <= budget and igemm_halo_bytes(tile, cls.is_, cls.taps, ck, es) <= HALO_MAX:
-                        best = (ck, ksteps, lds, tile, mtw_, nt, nsplit)
+                    pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw_, nt, nsplit, ck, aux_es)
+                    if pl is not None and pl.lds <= budget:
+                        best = pl
                         break
                 if best:
                     break
@@ -208,12 +216,45 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
             break
     if best is None:
         raise ValueError(f"no LDS-feasible plan for {kind} w={tuple(wshape)} q={q}")
-    ck, ksteps, lds, tile, mtw, nt, nsplit = best
-    depth = 1  # deeper rings (2-3 stages ahead) measured slower: they cost the second resident workgroup, and two workgroups per CU
-    #            overlapping each other's compute/epilogue chain matter more than extra bytes in flight (tools/bench_igemm.py --depth)
-    plan = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tile, mtw, nt, nsplit, ck, kc // ck, ksteps, lds, depth)
-    plan.pack_map = pack_map(plan, wshape)
-    return plan
+    best.pack_map = pack_map(best, wshape)
+    return best
+
+
+def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=4, in_split=0, limit=10) -> List[IgemmPlan]:
+    """Feasible alternatives to `plan_igemm`'s choice, default first (pack maps are filled for all of them).
+
+    What differs between them is what the heuristic cannot see without measuring: the channel chunk (LDS footprint, hence
+    how many workgroups share a CU, against the number of pipeline stages per tile), the voxel tile (MTW) and the
+    output-channel split.  The measured optimum moved by up to 1.7x between neighbouring candidates (tools/sweep_ck.sh)."""
+    default = plan_igemm(kind, wshape, cls, q, es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)
+    kreal, nreal = gemm_dims(kind, wshape)
+    kc = default.kc
+    nt_total = (nreal + 15) // 16
+    out, seen = [default], {(default.tile, default.nt, default.nsplit, default.ck)}
+    cks = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0 and (not in_split or c == kc or in_split % c == 0)}, reverse=True)
+    nvox = q[0] * q[1] * q[2]
+    for nsplit in sorted({default.nsplit, min(nt_total, default.nsplit + 1), max(1, default.nsplit - 1)}):
+        nt = (nt_total + nsplit - 1) // nsplit
+        if nt > 6:
+            continue
+        for mtw in (4, 2):
+            if (nt >= 5 and mtw == 4) or nvox < 512 * (mtw // 2):
+                continue
+            tile = choose_tile(q, cls.taps, 64 * mtw)
+            for ck in cks:
+                key = (tuple(tile), nt, nsplit, ck)
+                if key in seen:
+                    continue
+                pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw, nt, nsplit, ck, aux_es)
+                if pl is None:
+                    continue
+                seen.add(key)
+                out.append(pl)
+    # keep the default, then prefer few chunks / the default split; cap the list
+    rest = sorted(out[1:], key=lambda p: (p.nsplit != default.nsplit, p.nchunks, -p.mtw))[: limit - 1]
+    for pl in rest:
+        pl.pack_map = pack_map(pl, wshape)
+    return [default] + rest
 
 
 def pack_map(plan: IgemmPlan, wshape) -> np.ndarray:
