@@ -20,7 +20,7 @@ def short(name):
 def bench_name(short_name):
     """rocprof kernel name -> the name bench.py uses for its roofline block (igemm<bf16,NT,MTW>, wgrad<bf16,NTP>)."""
     import re
-    m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+)>", short_name)
+    m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+), \d+>", short_name)  # the MODE variants of one (type, NT, MTW) share a bench name
     if m:
         return f"igemm<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(2)},{m.group(3)}>"
     m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)>", short_name)

@@ -33,6 +33,36 @@ def _tdtype(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+TUNED_DEFAULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+
+
+def _tune_cache() -> dict:
+    """launch signature -> [tile, nt, nsplit, ck] of the plan measured fastest.  Seeded from the in-tree file of plans tuned on an
+    MI355X for the benchmark shapes and from $VSSEG_TUNE_CACHE; new measurements are written back to $VSSEG_TUNE_CACHE if set."""
+    if getattr(_tune_cache, "data", None) is None:
+        import json
+
+        _tune_cache.data, _tune_cache.dirty = {}, False
+        for f in (TUNED_DEFAULTS, os.environ.get("VSSEG_TUNE_CACHE")):
+            if f and os.path.exists(f):
+                try:
+                    _tune_cache.data.update(json.load(open(f)))
+                except (OSError, ValueError):
+                    pass
+    return _tune_cache.data
+
+
+def _tune_cache_save():
+    f = os.environ.get("VSSEG_TUNE_CACHE")
+    if f and getattr(_tune_cache, "dirty", False):
+        import json
+
+        tmp = f"{f}.{os.getpid()}.tmp"
+        json.dump(_tune_cache.data, open(tmp, "w"), indent=0, sort_keys=True)
+        os.replace(tmp, f)
+        _tune_cache.dirty = False
+
+
 class ParamLayout:
     """Offsets of every state_dict entry inside the flat buffers owned by the model (params fp32, buffers fp32, counters int64)."""
 
@@ -67,6 +97,8 @@ class _Choice:
     chosen: Optional[P.IgemmPlan] = None
     map_off: int = -1  # element offset of the chosen plan's packed weights inside Plan.wpack
     tuned_ms: Optional[list] = None  # autotuner measurements, one per candidate
+    wshape: tuple = ()
+    cached: bool = False  # the choice came from the tuned-plan cache, nothing was measured
 
 
 @dataclass
@@ -176,7 +208,7 @@ class Plan:
                     cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)
                 else:
                     cands = [P.plan_igemm(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)]
-                out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0))
+                out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0, wshape=tuple(Lr.wshape)))
             return out
 
         self.cplans: Dict[str, _ConvPlans] = {}
@@ -223,6 +255,7 @@ class Plan:
         for d, off in self._wpack_fixups:
             d.wpack = self.wpack.data_ptr() + eng.es * off
         del self._maps, self._maps2, self._wpack_fixups
+        _tune_cache_save()
 
     @staticmethod
     def _fill_desc(d: L.IgemmDesc, pl: P.IgemmPlan):
@@ -232,6 +265,23 @@ class Plan:
             d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
+
+    def _choose(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
+        """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
+        p0 = ch.cands[0]
+        key = (f"{p0.kind}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}")
+        cache = _tune_cache()
+        hit = cache.get(key)
+        if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+            for pl in ch.cands:
+                if [list(pl.tile), pl.nt, pl.nsplit, pl.ck] == hit:
+                    ch.cached = True
+                    return pl
+        pl = self._autotune(ch, d)
+        cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck]
+        _tune_cache.dirty = True
+        return pl
 
     def _autotune(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
         """Measure every candidate of one launch with its real operands and epilogue (HIP events, best of 3 after a warm-up)."""
@@ -271,7 +321,7 @@ class Plan:
         if res is not None:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
-        pl = self._autotune(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
+        pl = self._choose(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
         self._register(ch, pl)
         self._fill_desc(d, pl)
         self._wpack_fixups.append((d, ch.map_off))
@@ -280,7 +330,7 @@ class Plan:
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
-        tuned = "" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]"
+        tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
