@@ -167,6 +167,21 @@ int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, const float*
 /* torch.optim.Adam(lr, weight_decay) over the flat parameter buffer (ref:params/VSparams.py:388-391,462). */
 int vsseg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2, float gscale, void* stream);
 
+/* ---- data side: the reference's MONAI transform chain on volumes cached in HBM -------------------- */
+/* One crop of one cached volume: RandFlipd(spatial_axis=0) then RandSpatialCropd / SpatialPadd's zero padding
+ * (ref:params/VSparams.py:208-222).  origin is in flipped + padded coordinates and may be negative. */
+typedef struct {
+  const float* src;     /* [sx][sy][sz] fp32, z contiguous (the reference's X,Y,Z array order) */
+  int32_t sdims[3];
+  int32_t origin[3];
+  int32_t flip_x;
+} vsseg_crop_job;
+/* dst[j][rx][ry][rz] for j < njobs; `jobs` is a DEVICE array of vsseg_crop_job structs, image and label of every batch element. */
+int vsseg_crop_flip(const void* jobs, int32_t njobs, float* dst, const int32_t roi[3], void* stream);
+/* NormalizeIntensityd (ref:params/VSparams.py:213): y = (x - mean) / std over all n voxels (population std; std == 0: no
+ * division).  acc2 = 2 doubles of device scratch (sum, sum of squares; left filled for inspection). */
+int vsseg_normalize_intensity(const float* x, float* y, int64_t n, double* acc2, void* stream);
+
 /* Sliding-window blend (MONAI sliding_window_inference steps 6-7; call site ref:params/VSparams.py:568-574). */
 int vsseg_swi_accumulate(const float* seg /* [rx][ry][rz][c] */, const float* imap /* [rx][ry][rz] */, const int32_t roi[3], const int32_t start[3], int32_t c,
                          float* out /* [PX][PY][PZ][c] */, float* cnt /* [PX][PY][PZ] */, const int32_t pdims[3], void* stream);

@@ -79,6 +79,13 @@ def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def allreduce_sum(x: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks (identity in a single process); returns x."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+    return x
+
+
 def all_gather_scalars(values: Sequence[float], total: int, device="cpu") -> List[float]:
     """Each rank passes the scores of its `shard_indices(total)`; returns the `total` scores in case order on every rank."""
     W, r = world_size(), get_rank()
@@ -166,7 +173,9 @@ class DataParallelTrainer:
         if hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = 1.0 / self.world
 
-    def step(self, inputs, labels):
+    def step(self, inputs, labels, sync: bool = True):
+        """Returns the loss tensor (device scalar).  `sync` is accepted for symmetry with the reference loop, which reads
+        `loss.item()` every step (ref:params/VSparams.py:463); nothing here forces a host read either way."""
         self.opt.zero_grad()
         outputs = self.model(inputs)
         loss = self.loss_fn(outputs, labels)
@@ -174,4 +183,4 @@ class DataParallelTrainer:
         _, gflat = self.model.flat_parameters()
         allreduce_gradients(gflat)
         self.opt.step()
-        return loss
+        return loss.detach()
