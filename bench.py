@@ -207,6 +207,23 @@ def main():
                    mode="gaussian", sharding="volumes round-robin over ranks")
         model.train()
 
+    # ---- data side: RandFlipd + RandSpatialCropd of image+label batches from volumes cached in HBM
+    from vs_seg_amd.data.transforms import PatchSampler
+
+    rng = np.random.default_rng(11 + rank)
+    cached = [dict(image=torch.from_numpy(rng.standard_normal((448, 448, 128), dtype=np.float32)).to(dev), label=torch.zeros((448, 448, 128), device=dev)) for _ in range(2)]
+    sampler = PatchSampler(cached, PATCH, flip_prob=0.5, seed=rank)
+    sampler.sample([0, 1, 0, 1])
+    barrier()
+    s0 = time.perf_counter()
+    for _ in range(20):
+        sampler.sample([0, 1, 0, 1])
+    barrier()
+    sdt2 = time.perf_counter() - s0
+    data_side = dict(patches_per_sec=20 * args.batch * world / sdt2, note="image+label crops of 384x128x128 from GPU-cached 448x448x128 volumes, one vsseg_crop_flip launch per batch of 4",
+                     gb_per_sec=20 * args.batch * 2 * 2 * 4 * PATCH[0] * PATCH[1] * PATCH[2] / sdt2 / 1e9)
+    del cached, sampler
+
     if rank != 0:
         return
     peak = PEAK[args.dtype]
@@ -245,6 +262,7 @@ def main():
         "loss": loss_val,
         "roofline": roof,
         "sliding_window": swi,
+        "data_side": data_side,
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
