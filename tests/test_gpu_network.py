@@ -211,6 +211,31 @@ def test_train_step_with_dropout_mask_injection_fp32():
     _check_grads(m, sd, 3e-2, robust=True)
 
 
+def test_autotuned_plans_agree_with_heuristic_plans(monkeypatch):
+    """The plan autotuner only changes how a launch is tiled / chunked: forward and backward of the tuned model must agree
+    with the heuristic-plan model to fp32 summation-order accuracy, and at least one launch must have been measured."""
+    att, hard, seed, shape = True, True, 41, (2, 1, 128, 64, 32)
+    x, y = synth_input(seed, shape).cuda(), synth_label(seed, shape).cuda()
+    res = {}
+    for mode in ("0", "force"):
+        monkeypatch.setenv("VSSEG_AUTOTUNE", mode)
+        m = make_model(att, "fp32", seed, dropout=0.0).train()
+        logits, atts = m(x)
+        loss = V.Dice_spvPA(to_onehot_y=True, softmax=True)((logits, atts), y)
+        loss.backward()
+        plan = next(iter(m._engine.plans.values()))
+        tuned = [c for cp in plan.cplans.values() for c in cp.fwd + cp.dgrad if c.tuned_ms is not None]
+        res[mode] = (logits.detach().clone(), [a.detach().clone() for a in atts], float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters()}, tuned)
+    assert not res["0"][4] and len(res["force"][4]) > 20
+    assert any(c.chosen is not c.cands[0] for c in res["force"][4]), "no launch preferred a non-default plan (suspicious on an MI355X)"
+    assert abs(res["0"][2] - res["force"][2]) < 2e-6
+    np.testing.assert_allclose(res["force"][0].cpu().numpy(), res["0"][0].cpu().numpy(), atol=2e-4)
+    gf = torch.cat([g.flatten() for g in res["force"][3].values()]).double()
+    g0 = torch.cat([g.flatten() for g in res["0"][3].values()]).double()
+    assert float((gf - g0).norm() / g0.norm()) < 2e-3
+    assert float((gf * g0).sum() / (gf.norm() * g0.norm())) > 0.999999
+
+
 def test_train_step_bf16_close_to_oracle():
     att, hard, seed, shape = True, True, 33, (2, 1, 64, 64, 16)
     m = make_model(att, "bf16", seed, dropout=0.0).train()
