@@ -89,9 +89,13 @@ def golden_manifest():
     print("manifest: %d / %d keys" % (len(out["attention"]), len(out["no_attention"])))
 
 
-def golden_net_eval():
-    cases = [("b2_32x32x8", True, 11, (2, 1, 32, 32, 8)), ("b1_64x64x16", True, 12, (1, 1, 64, 64, 16)), ("b1_32x32x8_noatt", False, 13, (1, 1, 32, 32, 8)), ("b1_128x128x32", True, 14, (1, 1, 128, 128, 32)), ("b1_64x32x24", True, 15, (1, 1, 64, 32, 24))]
+def golden_net_eval(only=None):
+    cases = [("b2_32x32x8", True, 11, (2, 1, 32, 32, 8)), ("b1_64x64x16", True, 12, (1, 1, 64, 64, 16)), ("b1_32x32x8_noatt", False, 13, (1, 1, 32, 32, 8)), ("b1_128x128x32", True, 14, (1, 1, 128, 128, 32)), ("b1_64x32x24", True, 15, (1, 1, 64, 32, 24)),
+             # BASELINE.json's full sizes: the benchmark patch / sliding-window roi and the reference-native roi; sub-sample + checksums only
+             ("b1_384x128x128", True, 16, (1, 1, 384, 128, 128)), ("b1_384x384x64", True, 17, (1, 1, 384, 384, 64))]
     for name, att, seed, shape in cases:
+        if only and name not in only:
+            continue
         model = build_reference_model(att)
         model.load_state_dict(O.seeded_state_dict(att, seed))
         model.eval()
@@ -115,9 +119,13 @@ def golden_net_eval():
         print("net_eval", name, float(logits.abs().mean()))
 
 
-def golden_net_train():
+def golden_net_train(only=None):
     """One training-mode fwd + loss + bwd with dropout p=0 (torch's dropout stream cannot be reproduced elsewhere)."""
-    for name, att, hard, seed, shape in [("b2_32x32x8", True, True, 21, (2, 1, 32, 32, 8)), ("b2_32x32x8_noatt_nohard", False, False, 22, (2, 1, 32, 32, 8)), ("b1_64x64x16", True, True, 23, (1, 1, 64, 64, 16))]:
+    for name, att, hard, seed, shape in [("b2_32x32x8", True, True, 21, (2, 1, 32, 32, 8)), ("b2_32x32x8_noatt_nohard", False, False, 22, (2, 1, 32, 32, 8)), ("b1_64x64x16", True, True, 23, (1, 1, 64, 64, 16)),
+                                         ("b1_384x128x128", True, True, 24, (1, 1, 384, 128, 128))]:  # the benchmark patch: sub-samples + checksums only
+        if only and name not in only:
+            continue
+        big = int(np.prod(shape)) > 1_000_000
         model = build_reference_model(att, dropout=0.0)
         model.load_state_dict(O.seeded_state_dict(att, seed))
         model.train()
@@ -129,10 +137,16 @@ def golden_net_train():
             a.retain_grad()
         loss = loss_fn((logits, atts), y)
         loss.backward()
-        d = dict(seed=seed, shape=np.array(shape), attention=att, hardness=hard, loss=float(loss), logits=logits.detach().numpy(), dlogits=logits.grad.numpy(), n_att=len(atts))
-        for i, a in enumerate(atts):
-            d[f"att{i}"] = a.detach().numpy()
-            d[f"datt{i}"] = a.grad.numpy()
+        d = dict(seed=seed, shape=np.array(shape), attention=att, hardness=hard, loss=float(loss), n_att=len(atts))
+        if big:
+            for key, t in [("logits", logits.detach()), ("dlogits", logits.grad)] + [(f"att{i}", a.detach()) for i, a in enumerate(atts)] + [(f"datt{i}", a.grad) for i, a in enumerate(atts)]:
+                meta, sub = summarize(t)
+                d[key + "_meta"], d[key + "_sub"] = json.dumps(meta), sub
+        else:
+            d["logits"], d["dlogits"] = logits.detach().numpy(), logits.grad.numpy()
+            for i, a in enumerate(atts):
+                d[f"att{i}"] = a.detach().numpy()
+                d[f"datt{i}"] = a.grad.numpy()
         gs, gsub = {}, {}
         for k, p in model.named_parameters():
             g = p.grad.double().flatten()
@@ -244,6 +258,12 @@ def golden_adam():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--only-net-eval":  # regenerate selected eval cases only, e.g. the full-size ones
+        golden_net_eval(set(sys.argv[2:]))
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only-net-train":
+        golden_net_train(set(sys.argv[2:]))
+        sys.exit(0)
     golden_manifest()
     golden_blocks()
     golden_loss()

@@ -26,7 +26,7 @@ def test_manifest_matches_reference_state_dict(golden_dir):
     assert n_param == 3453012
 
 
-@pytest.mark.parametrize("name", ["b2_32x32x8", "b1_64x64x16", "b1_32x32x8_noatt", "b1_128x128x32", "b1_64x32x24"])
+@pytest.mark.parametrize("name", ["b2_32x32x8", "b1_64x64x16", "b1_32x32x8_noatt", "b1_128x128x32", "b1_64x32x24", "b1_384x128x128"])
 def test_net_eval(name):
     g = load(f"net_eval_{name}.npz")
     att, seed, shape = bool(g["attention"]), int(g["seed"]), tuple(int(v) for v in g["shape"])
