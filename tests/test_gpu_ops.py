@@ -387,6 +387,43 @@ def test_sliding_window_blend_matches_oracle(vol, roi, ov, mode, swb):
         np.testing.assert_array_equal(importance_map(r, "gaussian", "cpu").numpy(), O.gaussian_importance_map(r).numpy())
 
 
+@pytest.mark.parametrize("vol,roi,ov,nwin", [((512, 512, 120), (384, 128, 128), 0.5, 14), ((512, 512, 120), (384, 384, 64), 0.25, 12)])
+def test_sliding_window_full_size_properties(vol, roi, ov, nwin):
+    """BASELINE.json's inference volume (512x512x120) with the benchmark roi and with the reference-native roi.  Size-independent
+    properties of the blend: a predictor that is voxel-wise (its output at a voxel depends on that voxel only) must come back
+    un-blended whatever the window grid (sum_w imap*f(x) / sum_w imap = f(x)); the window table equals SURVEY App. B.2; the
+    output is independent of sw_batch_size bit for bit (windows are blended sequentially in reference order)."""
+    import vs_seg_amd as V
+    from vs_seg_amd.inferers import window_geometry
+
+    _, padded, pad_before, _, starts = window_geometry(vol, roi, ov)
+    assert len(starts) == nwin
+    if roi == (384, 128, 128):
+        assert starts == [(x, y, 0) for x in (0, 128) for y in range(0, 385, 64)] and padded == (512, 512, 128) and tuple(pad_before) == (0, 0, 4)
+    else:
+        assert starts == [(x, y, z) for x in (0, 128) for y in (0, 128) for z in (0, 48, 56)]
+    torch.manual_seed(8)
+    x = torch.randn(1, 1, *vol, device="cuda")
+
+    def pred(w):
+        return torch.cat([w * 2.0 + 1.0, torch.tanh(w) - 0.5], 1)
+
+    out1 = V.sliding_window_inference(x, roi, 1, pred, overlap=ov, mode="gaussian")
+    assert tuple(out1.shape) == (1, 2, *vol)
+    np.testing.assert_allclose(out1.cpu().numpy(), pred(x).cpu().numpy(), atol=3e-6, rtol=3e-6)
+    out4 = V.sliding_window_inference(x, roi, 4, pred, overlap=ov, mode="gaussian")
+    assert torch.equal(out1, out4)
+    # a window-dependent predictor: constant 1 per window in channel 0, window centre weight dominates -> stays within [min,max] (convexity)
+    k = [0]
+
+    def pred_idx(w):
+        k[0] += 1
+        return torch.cat([torch.full_like(w, float(k[0])), torch.zeros_like(w)], 1)
+
+    o = V.sliding_window_inference(x, roi, 1, pred_idx, overlap=ov, mode="gaussian")
+    assert k[0] == nwin and float(o[:, 0].min()) >= 1.0 - 1e-5 and float(o[:, 0].max()) <= nwin + 1e-4 and float(o[:, 1].abs().max()) == 0.0
+
+
 def test_hard_dice_matches_oracle():
     import vs_seg_amd as V
 
