@@ -69,7 +69,7 @@ typedef struct {
   int32_t ck;              /* input channels staged per chunk (multiple of 8, divides padded Cin) */
   int32_t nchunks;
   int32_t ksteps;          /* K-steps (4 groups of 8 channels) per chunk */
-  int32_t depth;           /* LDS-DMA prefetch distance in stages (1..3; 0 = 1): the halo ring holds depth+1 buffers */
+  int32_t depth;           /* LDS-DMA prefetch distance in stages (1..3; 0 = 1): the halo ring holds depth+1 buffers.  -1: no prefetch, one buffer (half the LDS, more resident workgroups) */
   const void* wpack;       /* [nsplit][nchunks][ksteps][nt][64 lanes][8] in the compute dtype (== in.dtype) */
   /* epilogue: v = acc + bias; stats(v); v = v*scale+shift; v = act(v); residual; accumulate; store */
   const float* bias;       /* [cout] or NULL */

@@ -53,7 +53,7 @@ def main():
         plan.pack_map = P.pack_map(plan, tuple(w.shape))
         plan.lds = P.igemm_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, plan.nt, plan.mtw, es, plan.kc // ck, 0)
     if a.depth:
-        plan.depth = a.depth
+        plan.depth = a.depth  # -1: no prefetch
         plan.lds = P.igemm_lds_bytes(plan.tile, cls.is_, cls.taps, plan.ck, plan.ksteps, plan.nt, plan.mtw, es, plan.nchunks, 0, a.depth)
     x = torch.randn(a.batch, *a.dims, P.round_up(a.cin, 8), device="cuda").to(dt)
     out = torch.zeros(a.batch, *odims, a.cout, dtype=dt, device="cuda")

@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 # the first run measures the launch plans and stores its choices; the profiled runs replay exactly those plans
 export VSSEG_TUNE_CACHE=$OUT/tuned_plans.json
-python $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+VSSEG_AUTOTUNE=force python $R/bench.py --steps 10 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err   # re-measures every launch plan
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --steps 5 --warmup 2 --swi-volumes 0 --no-cpu-baseline > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --steps 2 --warmup 1 --swi-volumes 0 --no-cpu-baseline > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --steps 2 --warmup 1 --swi-volumes 0 --no-cpu-baseline > $OUT/write.log 2>&1

@@ -137,7 +137,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   int off = 0;
   k.lds_ktab = off; off += ((d->ksteps * 4 * 4 + 15) / 16) * 16;
   k.lds_epi = off; off += 3 * d->nt * 16 * 4;
-  k.depth = d->depth < 1 ? 1 : (d->depth > 3 ? 3 : d->depth);
+  k.depth = d->depth < 0 ? 0 : (d->depth == 0 ? 1 : (d->depth > 3 ? 3 : d->depth));  // -1: no prefetch (single buffer); 0: default = 1
   const int nbuf = k.depth + 1;
   k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? nbuf : 1);
   k.lds_h = off; off += nbuf * k.h_bytes;

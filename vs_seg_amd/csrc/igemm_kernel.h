@@ -370,7 +370,16 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
     // Also younger than stage s's DMAs, and still allowed to be in flight: the output stores of the last D stages (vmcnt retires
     // loads and stores of a wave in issue order).  Waiting for them too would put a write-acknowledge latency into every stage.
-    if (D == 1) {
+    if (D == 0) {
+      // No prefetch, one LDS buffer: the workgroup is half the LDS size, so twice as many share a CU and overlap each other's
+      // load and compute phases instead (what the streaming kernels do with plain occupancy).
+      if (s > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // every wave is done reading the previous stage's tile
+      }
+      issue(s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else if (D == 1) {
       wait_vmcnt(st_h0);
     } else {
       int younger = st_h0 + st_h1 + (D >= 3 ? st_h2 : 0), chj = ch_cur;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring
-    if (s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
+    if (D > 0 && s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
     const TileDesc tc = tiles[(int64_t)ti_cur * S];  // this stage's tile (scalar load, consumed in the epilogue)
     const int ch = ch_cur;
     if (ch == 0) {

@@ -275,11 +275,11 @@ class Plan:
         hit = cache.get(key)
         if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
             for pl in ch.cands:
-                if [list(pl.tile), pl.nt, pl.nsplit, pl.ck] == hit:
+                if [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth] == (hit if len(hit) > 4 else hit + [1]):
                     ch.cached = True
                     return pl
         pl = self._autotune(ch, d)
-        cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck]
+        cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth]
         _tune_cache.dirty = True
         return pl
 
@@ -331,7 +331,7 @@ class Plan:
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
-        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 

@@ -16,6 +16,7 @@ autograd of those ops):
 """
 from __future__ import annotations
 
+import dataclasses
 import itertools
 from dataclasses import dataclass, field
 from typing import Optional,  List, Sequence, Tuple
@@ -132,7 +133,7 @@ def igemm_halo_bytes(tile, is_, taps, ck, es):
 def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=4, depth=1):
     """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers | aux | coordinate tables."""
     w = ksteps * nt * 64 * 8 * es
-    nbuf = depth + 1
+    nbuf = max(depth, 0) + 1  # depth -1: no prefetch, single buffer
     aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
     hb = igemm_halo_bytes(tile, is_, taps, ck, es)
     tables = ((hb // 16 + 255) // 256) * 1024 + mtw * 256  # coordinate tables of the boundary-tile paths
@@ -252,8 +253,17 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
                 out.append(pl)
     # keep the default, then prefer few chunks / the default split; cap the list
     rest = sorted(out[1:], key=lambda p: (p.nsplit != default.nsplit, p.nchunks, -p.mtw))[: limit - 1]
+    # no-prefetch twins (depth -1: one LDS buffer, about half the footprint) where registers allow more than one resident
+    # workgroup: 32->16 full-res 0.85 -> 0.78 ms, 64->32 half-res 0.86 -> 0.61 ms (tools/sweep_depth0.sh)
+    twins = []
+    for pl in [default] + rest:
+        if pl.nt <= 2:
+            lds = igemm_lds_bytes(pl.tile, cls.is_, cls.taps, pl.ck, pl.ksteps, pl.nt, pl.mtw, es, pl.nchunks, aux_es, -1)
+            twins.append(dataclasses.replace(pl, depth=-1, lds=lds))
+    rest = rest + twins[: max(0, limit + 4 - 1 - len(rest))]
     for pl in rest:
-        pl.pack_map = pack_map(pl, wshape)
+        if pl.pack_map is None:
+            pl.pack_map = pack_map(pl, wshape)
     return [default] + rest
 
 
