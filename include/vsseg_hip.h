@@ -102,6 +102,8 @@ typedef struct {
   int32_t persistent_blocks;
   float* scratch;          /* partial-sum slabs: >= ceil(ch_valid/16) * ntaps * ntp*16 * 16 floats per workgroup */
   int64_t scratch_elems;   /* capacity in floats; the number of persistent workgroups is clamped to what fits */
+  int32_t single_buffer;   /* 1: no prefetch, one LDS tile buffer (half the LDS, more resident workgroups); 0: double-buffered */
+  int32_t reserved;
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);

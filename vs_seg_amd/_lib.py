@@ -87,6 +87,8 @@ class WgradDesc(C.Structure):
         ("persistent_blocks", C.c_int32),
         ("scratch", C.c_void_p),
         ("scratch_elems", C.c_int64),
+        ("single_buffer", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -23,7 +23,9 @@ struct WgradK {
   int wt, wv;     // wave split: taps x K-steps (wt*wv == 4)
   int tvox;       // voxels per tile
   int p_row;      // bytes per P row in LDS
-  int lds_hbase, lds_p, lds_h;
+  int lds_hbase, lds_p, lds_h, lds_tab;
+  int npp, nph;   // rows of the per-thread coordinate tables (P pieces, H pieces) kept in LDS for the boundary-tile path
+  int nbuf;       // 2: tile s+1 streams in while tile s is multiplied; 1: no prefetch, half the LDS, more resident workgroups
   int64_t total_tiles;
   const void* zeros;  // >= 16 zero bytes in global memory (source of out-of-bounds pieces)
   float* slab;     // [gridDim.x][hchunks][ntaps][ntp*16][16] partial sums
@@ -48,6 +50,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   int* hbase = reinterpret_cast<int*>(smem + k.lds_hbase);
   char* Pl = smem + k.lds_p;
   char* Hl = smem + k.lds_h;
+  unsigned* pinfo_l = reinterpret_cast<unsigned*>(smem + k.lds_tab);  // [npp][256] packed tile coordinates of this thread's P pieces
+  unsigned* hinfo_l = pinfo_l + k.npp * 256;                          // [nph][256] ... of its halo pieces
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int wt = wave % k.wt, wv = wave / k.wt;
   const int HX = k.halo[0], HY = k.halo[1], HZ = k.halo[2];
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   const int ppp = k.p_row >> 4;   // 16-byte pieces per P voxel row (NTP*16 channels)
   const int ppieces = k.tvox * ppp;
   const int hpieces = hvox * ES;  // 16 channels = ES pieces of 16 B
-  unsigned pinfo[WPP], prel[WPP], hinfo[WPH], hrel[WPH];
+  unsigned prel[WPP], hrel[WPH];  // 0xffffffff: no piece
 #pragma unroll
   for (int u = 0; u < WPP; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
-    unsigned info = 0xffffffffu, rel = 0;
+    unsigned info = 0xffffffffu, rel = 0xffffffffu;
     if (j < ppieces) {
       const int v = j / ppp, c16 = j - v * ppp;
       int vz = v % d.tile[2], r = v / d.tile[2];
@@ -91,13 +95,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
       info = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
       rel = (unsigned)((vx * PY + vy) * PZ + vz) * p_vox_bytes + (unsigned)c16 * 16u;
     }
-    pinfo[u] = info;
+    if (u < k.npp) pinfo_l[u * 256 + tid] = info;
     prel[u] = rel;
   }
 #pragma unroll
   for (int u = 0; u < WPH; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
-    unsigned info = 0xffffffffu, rel = 0;
+    unsigned info = 0xffffffffu, rel = 0xffffffffu;
     if (j < hpieces) {
       const int hv = j / ES, c16 = j - hv * ES;
       int hz = hv % HZ, r = hv / HZ;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
       info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
       rel = (unsigned)((hx * QY + hy) * QZ + hz) * h_vox_bytes + (unsigned)c16 * 16u;
     }
-    hinfo[u] = info;
+    if (u < k.nph) hinfo_l[u * 256 + tid] = info;
     hrel[u] = rel;
   }
   const bool p_chan_ok = NTP * 16 <= d.p.c, h_chan_ok = chunk * 16 + 16 <= d.h.c;  // every piece has real channels (fast path)
@@ -136,11 +140,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   TileIdx t_issue = tile_decode((int)blockIdx.x);
   const int my_tiles = (int)blockIdx.x < (int)k.total_tiles ? ((int)k.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
 
-  auto issue = [&](int s) {  // LDS-DMA of tile s into buffer s&1
+  const int bufmask = k.nbuf - 1;
+  auto issue = [&](int s) {  // LDS-DMA of tile s into buffer s & bufmask
     const int n = t_issue.n, q0x = t_issue.tx * d.tile[0], q0y = t_issue.ty * d.tile[1], q0z = t_issue.tz * d.tile[2];
     tile_advance(t_issue);
-    char* Pdst = Pl + (s & 1) * p_bytes;
-    char* Hdst = Hl + (s & 1) * h_bytes;
+    char* Pdst = Pl + (s & bufmask) * p_bytes;
+    char* Hdst = Hl + (s & bufmask) * h_bytes;
     {
       const char* sample = p_base + (int64_t)n * p_sample;
       const bool interior = q0x + d.tile[0] <= d.q[0] && q0y + d.tile[1] <= d.q[1] && q0z + d.tile[2] <= d.q[2] && p_chan_ok;
@@ -149,13 +154,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
         for (int u = 0; u < WPP; ++u) {
           if ((u * 4 + wave) * 64 >= ppieces) break;
-          if (pinfo[u] != 0xffffffffu) wg_dma16(origin + prel[u], Pdst + (u * 4 + wave) * 1024);
+          if (prel[u] != 0xffffffffu) wg_dma16(origin + prel[u], Pdst + (u * 4 + wave) * 1024);
         }
       } else {
 #pragma unroll
         for (int u = 0; u < WPP; ++u) {
           if ((u * 4 + wave) * 64 >= ppieces) break;
-          const unsigned info = pinfo[u];
+          const unsigned info = pinfo_l[u * 256 + tid];
           if (info != 0xffffffffu) {
             const int qx = q0x + (int)(info & 255u), qy = q0y + (int)((info >> 8) & 255u), qz = q0z + (int)((info >> 16) & 255u);
             const unsigned c16 = info >> 24;
@@ -175,13 +180,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
         for (int u = 0; u < WPH; ++u) {
           if ((u * 4 + wave) * 64 >= hpieces) break;
-          if (hinfo[u] != 0xffffffffu) wg_dma16(origin + hrel[u], Hdst + (u * 4 + wave) * 1024);
+          if (hrel[u] != 0xffffffffu) wg_dma16(origin + hrel[u], Hdst + (u * 4 + wave) * 1024);
         }
       } else {
 #pragma unroll
         for (int u = 0; u < WPH; ++u) {
           if ((u * 4 + wave) * 64 >= hpieces) break;
-          const unsigned info = hinfo[u];
+          const unsigned info = hinfo_l[u * 256 + tid];
           if (info != 0xffffffffu) {
             const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
             const unsigned c16 = info >> 24;
@@ -195,13 +200,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   };
 
   const int ksteps = k.tvox / 32;
-  if (my_tiles > 0) issue(0);
+  __syncthreads();  // coordinate tables visible
+  if (bufmask && my_tiles > 0) issue(0);
   for (int s = 0; s < my_tiles; ++s) {
+    if (!bufmask) {  // single buffer: refill only after every wave finished the previous tile
+      if (s > 0) __syncthreads();
+      issue(s);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile s landed for every wave; every wave is done reading tile s-1's buffers
-    if (s + 1 < my_tiles) issue(s + 1);
-    const char* Ps = Pl + (s & 1) * p_bytes;
-    const char* Hs = Hl + (s & 1) * h_bytes;
+    if (bufmask && s + 1 < my_tiles) issue(s + 1);
+    const char* Ps = Pl + (s & bufmask) * p_bytes;
+    const char* Hs = Hl + (s & bufmask) * h_bytes;
     for (int ks = wv; ks < ksteps; ks += k.wv) {
       if constexpr (ES == 2) {
         // lane (g, i=l15): rows r=i>>2 of two 4-voxel blocks, 4-channel column chunk q=i&3
@@ -357,8 +367,12 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   k.p_row = d->ntp * 16 * es;
   int off = 0;
   k.lds_hbase = off; off += ((k.tvox * 4 + 15) / 16) * 16;
-  k.lds_p = off; off += 2 * k.tvox * k.p_row;                          // double-buffered: tile s+1 streams in by LDS-DMA while tile s is multiplied
-  k.lds_h = off; off += 2 * k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
+  k.nbuf = d->single_buffer ? 1 : 2;
+  k.lds_p = off; off += k.nbuf * k.tvox * k.p_row;                     // double-buffered: tile s+1 streams in by LDS-DMA while tile s is multiplied
+  k.lds_h = off; off += k.nbuf * k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
+  k.npp = (k.tvox * (k.p_row >> 4) + 255) / 256;
+  k.nph = (k.halo[0] * k.halo[1] * k.halo[2] * es + 255) / 256;
+  k.lds_tab = off; off += (k.npp + k.nph) * 1024;
   VSSEG_CHECK(k.tvox * k.p_row <= WPP * 256 * 16 && k.halo[0] * k.halo[1] * k.halo[2] * 16 * es <= WPH * 256 * 16, "vsseg_wgrad: tile too large for the DMA piece budget");
   for (int a = 0; a < 3; ++a) VSSEG_CHECK(k.halo[a] <= 255 && d->tile[a] <= 255, "vsseg_wgrad: tile/halo extent > 255");
   {

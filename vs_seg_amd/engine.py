@@ -460,8 +460,32 @@ class Plan:
             scr = self.eng.wgrad_scratch()
             d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
             self.keep.append(d)
+            tuned = ""
+            if self.tune:  # double-buffered DMA pipeline vs one buffer and more resident workgroups: measured per launch
+                key = f"wgrad|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}"
+                cache = _tune_cache()
+                if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+                    d.single_buffer, tuned = int(cache[key]), " tuned[cache]"
+                else:
+                    stream = torch.cuda.current_stream().cuda_stream
+                    ms = []
+                    for sb in (0, 1):
+                        d.single_buffer = sb
+                        best = float("inf") if not lib.vsseg_wgrad(C.byref(d), stream) else None
+                        for _ in range(3 if best is not None else 0):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            lib.vsseg_wgrad(C.byref(d), stream)
+                            e1.record()
+                            e1.synchronize()
+                            best = min(best, e0.elapsed_time(e1))
+                        ms.append(float("inf") if best is None else best)
+                    d.single_buffer = 1 if ms[1] < 0.97 * ms[0] else 0
+                    cache[key] = d.single_buffer
+                    _tune_cache.dirty = True
+                    tuned = f" tuned[{ms[0]:.3f}/{ms[1]:.3f}ms]"
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} lds={wg.lds}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad:
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])

@@ -398,7 +398,8 @@ def plan_wgrad(transposed: bool, wshape, kernel, stride, lattice_dims, es, cp_va
             offs = [t[0][a] for t in taps]
             halo *= (tile[a] - 1) * stride[a] + (max(offs) - min(offs) + 1)
         p_bytes, h_bytes = tv * ntp * 16 * es, halo * 16 * es
-        lds = round_up(tv * 4, 16) + 2 * p_bytes + 2 * h_bytes  # double-buffered tiles (LDS-DMA pipeline), mirrors vsseg_wgrad()
+        tables = ((p_bytes // 16 + 255) // 256 + (h_bytes // 16 + 255) // 256) * 1024  # boundary-path coordinate tables
+        lds = round_up(tv * 4, 16) + 2 * p_bytes + 2 * h_bytes + tables  # double-buffered tiles (LDS-DMA pipeline), mirrors vsseg_wgrad()
         if lds <= LDS_LIMIT - 1024 and p_bytes <= 12 * 256 * 16 and h_bytes <= 8 * 256 * 16:
             break
     else:
