@@ -143,7 +143,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.lds_h = off; off += nbuf * k.h_bytes;
   k.lds_aux = off; off += nbuf * k.aux_bytes;
   k.npu = (k.h_bytes / 16 + 255) / 256;
-  k.lds_pinfo = off; off += k.npu * 1024 + d->mtw * 256;  // slow-path coordinate tables (boundary / partial tiles)
+  k.lds_pinfo = off; off += (2 * k.npu + 1) * 1024;  // per-thread DMA offset table + slow-path coordinate tables (boundary / partial tiles)
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }

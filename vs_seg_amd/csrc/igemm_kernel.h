@@ -114,7 +114,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // gradient accumulation / ReLU mask fetched by DMA).
 enum { IG_PLAIN = 0, IG_STATS = 1, IG_AUX = 2 };
 template <typename T, int NT, int MTW, int MODE>
-__global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const IgemmK k) {
+__global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3 : 2) : 1)) void igemm_kernel(const IgemmK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool STATS = MODE == IG_STATS, AUXM = MODE == IG_AUX;
   constexpr int ES = sizeof(T);
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
   //      and was issue-bound at 1.7 TB/s on the HBM-bound layers).
   const int X = d.in.x, Y = d.in.y, Z = d.in.z;
   const unsigned in_vox_bytes = (unsigned)d.in.pitch * ES;
-  unsigned prel[PMAX];   // byte offset relative to the halo origin voxel (fast path: interior tiles); 0xffffffff: no piece
+  unsigned* prel_l = pinfo_l + (k.npu + 1) * 256;  // [npu][256] byte offset of each piece relative to the halo origin voxel (interior tiles); 0xffffffff: no piece
   unsigned p2mask = 0;   // bit u: piece u lies in part 1 of a two-part input (single-chunk case, see below)
   const bool in_two = d.in.ptr2 != nullptr;
   const int in_csplit = in_two ? d.in.csplit : 0x7fffffff;
@@ -185,8 +185,7 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
       rel = (unsigned)((hx * Y + hy) * Z + hz) * in_vox_bytes + (unsigned)c16 * 16u;
       if (in_two && nch == 1 && c16 * EPP >= in_csplit) p2mask |= 1u << u;
     }
-    if (u < k.npu) pinfo_l[u * 256 + tid] = info;
-    prel[u] = rel;
+    if (u < k.npu) { pinfo_l[u * 256 + tid] = info; prel_l[u * 256 + tid] = rel; }
   }
   // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  prel/pinfo keep the channel offset of the
   // virtual concatenated row; part 1's base is biased by -csplit channels so the same offsets address it.  A chunk never
@@ -304,7 +303,8 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
 #pragma unroll
         for (int u = 0; u < PMAX; ++u) {
           if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
-          if (prel[u] != 0xffffffffu) dma16(origin + prel[u], Hdst + (u * 4 + wave) * 1024);
+          const unsigned rel = prel_l[u * 256 + tid];
+          if (rel != 0xffffffffu) dma16(origin + rel, Hdst + (u * 4 + wave) * 1024);
         }
       } else {
         const char* origin1 = in_base1 + ooff;
@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256, (NT <= 2) ? 2 : 1) void igemm_kernel(const Ige
 #pragma unroll
         for (int u = 0; u < PMAX; ++u) {
           if ((u * 4 + wave) * 64 >= pieces) break;
-          if (prel[u] != 0xffffffffu) dma16(((m2 >> u) & 1u ? origin1 : origin) + prel[u], Hdst + (u * 4 + wave) * 1024);
+          const unsigned rel = prel_l[u * 256 + tid];
+          if (rel != 0xffffffffu) dma16(((m2 >> u) & 1u ? origin1 : origin) + rel, Hdst + (u * 4 + wave) * 1024);
         }
       }
     } else {
@@ -618,7 +619,7 @@ template <typename T, int NT, int MTW, int MODE> static int launch_mode(const Ig
   if (cached_lds != lds) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW, MODE>, 256, lds) != hipSuccess || n < 1) n = 1;
-    cached_per_cu = n > 4 ? 4 : n;
+    cached_per_cu = n > 6 ? 6 : n;
     cached_lds = lds;
   }
   int64_t gx = 256ll * cached_per_cu;

@@ -136,7 +136,7 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
     nbuf = max(depth, 0) + 1  # depth -1: no prefetch, single buffer
     aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
     hb = igemm_halo_bytes(tile, is_, taps, ck, es)
-    tables = ((hb // 16 + 255) // 256) * 1024 + mtw * 256  # coordinate tables of the boundary-tile paths
+    tables = (2 * ((hb // 16 + 255) // 256) + 1) * 1024  # per-thread DMA offset table + coordinate tables of the boundary-tile paths
     return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * hb + aux + tables
 
 
@@ -257,10 +257,10 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     # workgroup: 32->16 full-res 0.85 -> 0.78 ms, 64->32 half-res 0.86 -> 0.61 ms (tools/sweep_depth0.sh)
     twins = []
     for pl in [default] + rest:
-        if pl.nt <= 2:
+        if pl.nt <= 2 or pl.mtw <= 2:  # register budget allows a second resident workgroup
             lds = igemm_lds_bytes(pl.tile, cls.is_, cls.taps, pl.ck, pl.ksteps, pl.nt, pl.mtw, es, pl.nchunks, aux_es, -1)
             twins.append(dataclasses.replace(pl, depth=-1, lds=lds))
-    rest = rest + twins[: max(0, limit + 4 - 1 - len(rest))]
+    rest = rest + twins
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
