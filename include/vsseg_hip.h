@@ -104,6 +104,7 @@ typedef struct {
   int64_t scratch_elems;   /* capacity in floats; the number of persistent workgroups is clamped to what fits */
   int32_t single_buffer;   /* 1: no prefetch, one LDS tile buffer (half the LDS, more resident workgroups); 0: double-buffered */
   int32_t reserved;
+  float* dbias_p;          /* optional: dbias_p[cP] += sum_q P[q][cP] (bias gradient of a convolution without BatchNorm, P = dY) or NULL */
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);

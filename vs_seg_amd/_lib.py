@@ -89,6 +89,7 @@ class WgradDesc(C.Structure):
         ("scratch_elems", C.c_int64),
         ("single_buffer", C.c_int32),
         ("reserved", C.c_int32),
+        ("dbias_p", C.c_void_p),
     ]
 
 

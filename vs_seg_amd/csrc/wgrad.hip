@@ -199,6 +199,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     }
   };
 
+  // optional bias gradient dbias[cP] += sum_q P[q][cP] (P = dY of a convolution without BatchNorm): one extra MFMA per K-step
+  // against an all-ones operand in the workgroups of H-chunk 0 — replaces a separate pass over dY (vsseg_channel_sum)
+  const bool do_bias = d.dbias_p != nullptr && chunk == 0 && wt == 0;
+  f32x4 accb[NTP];
+#pragma unroll
+  for (int p = 0; p < NTP; ++p) accb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ksteps = k.tvox / 32;
   __syncthreads();  // coordinate tables visible
   if (bufmask && my_tiles > 0) issue(0);
@@ -226,6 +232,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
           bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Ps + v1 * k.p_row + p * 32 + qc));
           pa[p] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
+        if (do_bias) {
+          const short one = 0x3F80;  // bf16 1.0
+          const bf16x8 ones = bf16x8{one, one, one, one, one, one, one, one};
+#pragma unroll
+          for (int p = 0; p < NTP; ++p) accb[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[p], ones, accb[p], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
           if (toff[i] < 0) continue;
@@ -244,6 +256,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
           float pa[NTP];
 #pragma unroll
           for (int p = 0; p < NTP; ++p) pa[p] = *reinterpret_cast<const float*>(Ps + v * k.p_row + (p * 16 + l15) * 4);
+          if (do_bias) {
+#pragma unroll
+            for (int p = 0; p < NTP; ++p) accb[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[p], 1.0f, accb[p], 0, 0, 0);
+          }
 #pragma unroll
           for (int i = 0; i < MAXT; ++i) {
             if (toff[i] < 0) continue;
@@ -256,6 +272,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     }
   }
 
+  if (do_bias && l15 == 0) {  // every column of accb holds the same row sums
+#pragma unroll
+    for (int p = 0; p < NTP; ++p)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cp = p * 16 + g * 4 + r;
+        if (cp < d.cp_valid) atomicAdd(&d.dbias_p[cp], accb[p][r]);
+      }
+  }
   // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) -> this workgroup's slab [tap][cP][16]
   float* slab = k.slab + ((int64_t)blockIdx.x * gridDim.y + chunk) * k.slab_chunk;
 #pragma unroll
