@@ -30,6 +30,11 @@ def init_distributed(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Smoke-testing the multi-rank code path on a single-GPU box: VSSEG_DIST_BACKEND=gloo VSSEG_SHARE_DEVICE=1 lets several ranks
+    # share cuda:0 (RCCL refuses two ranks on one device; gloo moves CUDA tensors through the host).  Never used for measurements.
+    backend = backend or os.environ.get("VSSEG_DIST_BACKEND") or None
+    if os.environ.get("VSSEG_SHARE_DEVICE") == "1" and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
