@@ -59,6 +59,10 @@ def igemm_desc(plan: P.IgemmPlan, wpack: torch.Tensor, inp: L.Tensor, out: L.Ten
     return d
 
 
+def _split_cl(t_cl: torch.Tensor, c0: int):
+    return t_cl[..., :c0].contiguous(), t_cl[..., c0:].contiguous()
+
+
 def two_part(a: torch.Tensor, b: torch.Tensor) -> L.Tensor:
     """Descriptor of the channel concatenation [a | b] of two dense channels-last tensors (nothing is copied)."""
     return L.Tensor.two_part(tdesc(a), tdesc(b))

@@ -227,12 +227,63 @@ def test_attention_gate_forward_backward(dt, c):
     assert abs(float(dbias) - float(pre.grad.sum())) < 2e-2 * float(pre.grad.abs().sum()) ** 0.5 + 1e-3
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind,k,cin,cout,dims,split", [("conv_fwd", (3, 3, 1), 32, 16, (32, 32, 8), 0), ("conv_fwd", (3, 3, 3), 96, 48, (8, 16, 16), 48), ("conv_dgrad", (3, 3, 1), 32, 64, (16, 32, 8), 0),
+                                                          ("conv_fwd", (3, 3, 3), 48, 96, (8, 8, 16), 0)])
+def test_every_candidate_plan_gives_the_same_convolution(kind, k, cin, cout, dims, split, dt):
+    """The autotuner may pick any of `planner.candidate_plans` (channel chunk, voxel tile, output-channel split, prefetch
+    depth incl. the single-buffer mode): each of them must compute the same convolution, with bias + BN statistics +
+    accumulation exercising every epilogue MODE of the kernel."""
+    lib = L.lib()
+    torch.manual_seed(21)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k)) ** 0.5, dt)
+    b = torch.randn(cout)
+    xd = x.double().requires_grad_(True)
+    y = F.conv3d(xd, w.double(), b.double(), padding=P.same_pad(k))
+    if kind == "conv_fwd":
+        inp_cl, want, nout, bias = H.to_cl(x, H.DT[dt]), y.detach(), cout, b.cuda()
+    else:
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        inp_cl, want, nout, bias = H.to_cl(gy, H.DT[dt]), xd.grad, cin, None
+    cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
+    cands = P.candidate_plans(kind, tuple(w.shape), cls, dims, inp_cl.element_size(), kc_pad=inp_cl.shape[-1], aux_es=inp_cl.element_size(), in_split=split)
+    assert len(cands) >= 2 and (dt == "fp32" or (len(cands) >= 4 and any(c.depth == -1 for c in cands) and len({(c.ck, c.mtw, c.nsplit) for c in cands}) >= 3))
+    parts = H._split_cl(inp_cl, split) if split else None
+    for mode in ("plain", "stats", "accumulate"):
+        for pl in cands:
+            out = torch.zeros(2, *dims, nout, dtype=H.DT[dt], device="cuda")
+            ref = want
+            kw = {}
+            stats = None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "accumulate":
+                old = _round(torch.randn(2, nout, *dims), dt)
+                out = H.to_cl(old, H.DT[dt])
+                ref = want + old.double()
+                kw = dict(accumulate=1)
+            if bias is not None:
+                kw["bias"] = bias.data_ptr()
+            wp = H.pack(pl, w, inp_cl.dtype)
+            d = H.igemm_desc(pl, wp, H.two_part(*parts) if parts else H.tdesc(inp_cl), H.tdesc(out), **kw)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm {pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth}")
+            torch.cuda.synchronize()
+            tag = f"{mode} tile={pl.tile} mtw={pl.mtw} ck={pl.ck} ns={pl.nsplit} D={pl.depth}"
+            np.testing.assert_allclose(H.from_cl(out).numpy(), ref.float().numpy(), atol=_tol(dt, ref), err_msg=tag)
+            if stats is not None:
+                st = stats.cpu().view(L.STAT_SHARDS, 2, -1).sum(0)[:, :nout]
+                np.testing.assert_allclose(st[0].numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2, err_msg=tag)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # two-part tensors: the skip-connection concat cat([skip, up], 1) (MONAI SkipConnection) addressed as a pair of dense
 # tensors.  Every kernel that accepts one must give exactly what it gives on the materialised concatenation.
 # ---------------------------------------------------------------------------------------------------------------
 def _split_cl(t_cl, c0):
-    return t_cl[..., :c0].contiguous(), t_cl[..., c0:].contiguous()
+    return H._split_cl(t_cl, c0)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
