@@ -1,6 +1,7 @@
 """Print VGPR/SGPR/spill/scratch/occupancy of every kernel in a HIP source (hipcc -Rpass-analysis=kernel-resource-usage).
 
-    python tools/kernel_resources.py vs_seg_amd/csrc/igemm.hip [filter]
+    python tools/kernel_resources.py vs_seg_amd/csrc/wgrad.hip [filter]
+    python tools/kernel_resources.py vs_seg_amd/csrc/igemm_inst.hip "" -DIG_T=bf16_t -DIG_TNAME=bf16 -DIG_NT=2
 """
 import re
 import subprocess
@@ -8,7 +9,8 @@ import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Iinclude", "-I../../include", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+extra = [a for a in sys.argv[3:] if a.startswith("-")]
+cmd = ["/opt/rocm/bin/hipcc", *extra, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Iinclude", "-I../../include", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None
 for line in err.splitlines():
