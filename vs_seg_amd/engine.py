@@ -128,6 +128,8 @@ class Plan:
         self.eng, self.n, self.dims, self.train = eng, n, tuple(dims), train
         self.lv = level_dims(dims, eng.hp)
         self.fwd: List[list] = []
+        self.fwd_pre: List[list] = []  # eval only: launches that depend on parameters / buffers alone (BatchNorm folding); re-run with the weight packing when those change
+        self.params_key = None  # parameter version the packed weights + folded BatchNorm constants of an eval plan belong to
         self.bwd: List[list] = []
         self.keep: list = []  # ctypes objects that must outlive the launches
         self.bufs: Dict[str, torch.Tensor] = {}
@@ -379,7 +381,7 @@ class Plan:
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
                 else:
-                    F.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
+                    self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
                     for ch in cp.fwd:
                         self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
                                     res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))

@@ -175,6 +175,14 @@ class UNet2d5_spvPA(nn.Module):
         self._ensure_flat()
         return self._flat, self._gflat
 
+    def train(self, mode: bool = True):
+        self._mode_epoch = getattr(self, "_mode_epoch", 0) + 1  # entering eval re-validates the cached eval constants (covers writes through `.data`)
+        return super().train(mode)
+
+    def invalidate_cache(self):
+        """Force eval plans to re-pack weights / re-fold BatchNorm on their next forward (after out-of-band parameter writes)."""
+        self._mode_epoch = getattr(self, "_mode_epoch", 0) + 1
+
     # ------------------------------------------------------------------ forward / backward
     def forward(self, x: torch.Tensor):
         if not x.is_cuda:
@@ -199,12 +207,24 @@ class UNet2d5_spvPA(nn.Module):
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.to(torch.float32).contiguous()
-        plan.pack_weights(stream)
         if train:
+            plan.pack_weights(stream)
             self._step += 1
             plan.step_seed = (self._seed_base << 32) | (self._step & 0xFFFFFFFF)
             plan.set_seed(plan.step_seed)
             plan.stats.zero_()
+            torch.autograd.graph.increment_version(self._bflat)  # bn_finalize updates the running statistics through raw pointers
+        else:
+            # eval: packed weights and folded BatchNorm constants depend on parameters / buffers only — the 14 windows of a
+            # sliding-window volume (ref:params/VSparams.py:568-574) reuse them; refreshed when a tensor version changes
+            # (Parameters / buffers re-pointed into the flat storage via `.data` keep their own version counters, so theirs are
+            # summed in; the flat tensors' counters are the ones the raw-pointer kernels — Adam, bn_finalize — bump)
+            key = (self._flat.data_ptr(), self._flat._version, self._bflat.data_ptr(), self._bflat._version, getattr(self, "_mode_epoch", 0),
+                   sum(p._version for p in self._params.values()), sum(b._version for b in self.buffers()))
+            if plan.params_key != key:
+                plan.pack_weights(stream)
+                plan.run(plan.fwd_pre, stream)
+                plan.params_key = key
         inp = plan._desc(eng.prog.input)
         L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), inp, stream), "stage_input")
         plan.run(plan.fwd, stream)

@@ -44,4 +44,5 @@ class Adam(torch.optim.Optimizer):
             t = st["step"]
             L.check(lib.vsseg_adam(flat.data_ptr(), gflat.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                    float(group["weight_decay"]), 1.0 - b1**t, 1.0 - b2**t, float(self.grad_scale), stream), "adam")
+            torch.autograd.graph.increment_version(flat)  # the kernel wrote through the raw pointer: let version-keyed caches (eval weight packing) see it
         return loss
