@@ -83,6 +83,10 @@ typedef struct {
   int32_t accumulate;      /* out += value (gradient accumulation at fan-out points) */
   double* stats;           /* [VSSEG_STAT_SHARDS][2][cout_padded] sum / sum-of-squares of v, or NULL */
   int32_t stats_stride;    /* cout_padded */
+  /* z-folded launches (a convolution without taps along z, with 1 real input or output channel, run on tensors whose 8
+   * z-neighbours are reinterpreted as 8 channels; the packed weights are block-diagonal): output channel c of the launch is
+   * real channel c % cout_mod for bias / bias2 / scale / shift / stats.  0: off. */
+  int32_t cout_mod;
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
@@ -152,7 +156,8 @@ int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint6
 int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream);
 /* dx (+)= dout*(1+att);  dpre[voxel][0] = (sum_c dout*x + datt_ext) * att*(1-att)  (sigmoid backward), channels 1..7 zero. */
 int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre,
-                        float* dbias /* += sum(dpre): bias gradient of the sigmoid convolution, or NULL */, void* stream);
+                        float* dbias /* += sum(dpre): bias gradient of the sigmoid convolution, or NULL */,
+                        void* dpre1 /* optional compact [N,X,Y,Z] copy of channel 0 of dpre (x's dtype), or NULL */, void* stream);
 
 /* generic helpers */
 int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);

@@ -218,12 +218,14 @@ def test_attention_gate_forward_backward(dt, c):
     dpre = torch.zeros(n, *dims, 8, dtype=H.DT[dt], device="cuda")
     ge = gatt_ext.reshape(n, *dims).contiguous().cuda()
     dbias = torch.zeros(1, device="cuda")
-    L.check(lib.vsseg_att_apply_bwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(gcl), ge.data_ptr(), H.tdesc(dx), 0, H.tdesc(dpre), dbias.data_ptr(), S))
+    dpre1 = torch.zeros(n, *dims, dtype=H.DT[dt], device="cuda")
+    L.check(lib.vsseg_att_apply_bwd(H.tdesc(xcl), attd.data_ptr(), H.tdesc(gcl), ge.data_ptr(), H.tdesc(dx), 0, H.tdesc(dpre), dbias.data_ptr(), dpre1.data_ptr(), S))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(o).numpy(), out.detach().float().numpy(), atol=_tol(dt, out))
     np.testing.assert_allclose(H.from_cl(dx).numpy(), x.grad.float().numpy(), atol=_tol(dt, x.grad))
     np.testing.assert_allclose(H.from_cl(dpre, 1).numpy(), pre.grad.float().numpy(), atol=_tol(dt, pre.grad))
     assert float(dpre[..., 1:].float().abs().max()) == 0.0
+    assert torch.equal(dpre1, dpre[..., 0])  # the compact copy feeds the z-folded data gradient of the sigmoid convolution
     assert abs(float(dbias) - float(pre.grad.sum())) < 2e-2 * float(pre.grad.abs().sum()) ** 0.5 + 1e-3
 
 
@@ -364,7 +366,7 @@ def test_two_part_attention_gate(dt, c0):
     old = _round(torch.randn(n, c, *dims), dt)
     da, db = _split_cl(H.to_cl(old, H.DT[dt]), c0)
     dpre = torch.zeros(n, *dims, 8, dtype=H.DT[dt], device="cuda")
-    L.check(lib.vsseg_att_apply_bwd(H.two_part(xa, xb), attd.data_ptr(), H.tdesc(gcl), None, H.two_part(da, db), 1, H.tdesc(dpre), None, S))
+    L.check(lib.vsseg_att_apply_bwd(H.two_part(xa, xb), attd.data_ptr(), H.tdesc(gcl), None, H.two_part(da, db), 1, H.tdesc(dpre), None, None, S))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(o).numpy(), out.detach().float().numpy(), atol=_tol(dt, out))
     ref = old.double() + x.grad

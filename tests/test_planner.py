@@ -145,3 +145,33 @@ def test_merged_residual_pack_map():
     gy_cl = np.zeros((2, *dims, 8))
     gy_cl[..., :cout] = _cl(gy)
     np.testing.assert_allclose(merged("conv_dgrad", gy_cl, dims, 8), _cl(x.grad), atol=1e-9)
+
+
+@pytest.mark.parametrize("cin,cout,kind", [(1, 16, "conv_fwd"), (16, 1, "conv_fwd"), (16, 1, "conv_dgrad"), (1, 16, "conv_fwd_1x1")])
+def test_z_folded_plans_compute_the_same_convolution(cin, cout, kind):
+    """planner.folded_candidate_plans: the 3x3x1 (or 1x1x1) convolution with one real input / output channel as a block-diagonal
+    convolution on tensors whose 8 z-neighbours are reinterpreted as channels — every candidate, fwd and dgrad."""
+    torch.manual_seed(9)
+    k = (1, 1, 1) if kind.endswith("1x1") else (3, 3, 1)
+    kind = "conv_fwd" if kind.startswith("conv_fwd") else kind
+    dims = (8, 8, 16)
+    assert P.foldable(k, (1, 1, 1), False, cin, cout, dims) and not P.foldable((3, 3, 3), (1, 1, 1), False, cin, cout, dims) and not P.foldable(k, (1, 1, 1), False, 16, 16, dims)
+    x = torch.randn(2, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64)
+    y = F.conv3d(x, w, padding=P.same_pad(k))
+    cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
+    if kind == "conv_fwd":
+        src, want, cs, cd = x.detach(), y.detach(), cin, cout
+    else:
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        src, want, cs, cd = gy, x.grad, cout, cin
+    # fold: [N,X,Y,Z,C] -> [N,X,Y,Z/8,8*C] is a pure reinterpretation of the channels-last memory
+    src_f = _cl(src).reshape(2, dims[0], dims[1], dims[2] // 8, 8 * cs)
+    cands = P.folded_candidate_plans(kind, tuple(w.shape), cls, dims, es=2)
+    assert len(cands) >= 2
+    for pl in cands:
+        assert pl.kc == 8 * cs and pl.nc == 8 * cd and pl.q == (8, 8, 2)
+        ident = dataclasses.replace(pl)  # simulate_igemm gathers the weights through pack_map itself
+        got = P.simulate_igemm(ident, src_f, w.numpy().reshape(-1), (8, 8, 2))
+        np.testing.assert_allclose(got.reshape(2, *dims, cd), _cl(want), atol=1e-9, err_msg=f"tile={pl.tile} ck={pl.ck} ns={pl.nsplit}")

@@ -70,7 +70,7 @@ def main():
             ("bn_act_bwd_reduce", 2 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_reduce(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, sums.data_ptr(), c, acc.data_ptr(), st))),
             ("bn_act_bwd_apply", 3 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_apply(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, p[6], p[7], T(dy), st))),
             ("att_apply_fwd", 2 * tb + nvox * 4, lambda: L.check(lib.vsseg_att_apply_fwd(T(y), att.data_ptr(), T(out), st))),
-            ("att_apply_bwd", 3 * tb + nvox * (4 + 8 * es), lambda: L.check(lib.vsseg_att_apply_bwd(T(y), att.data_ptr(), T(dout), None, T(dy), 0, T(dpre), dbias.data_ptr(), st))),
+            ("att_apply_bwd", 3 * tb + nvox * (4 + 8 * es), lambda: L.check(lib.vsseg_att_apply_bwd(T(y), att.data_ptr(), T(dout), None, T(dy), 0, T(dpre), dbias.data_ptr(), None, st))),
             ("torch copy", 2 * tb, lambda: out.copy_(y)),
         ]
         print(f"--- c={c} dims={dims} batch={a.batch} {a.dtype}: one tensor = {tb / 1e6:.0f} MB")

@@ -64,6 +64,7 @@ class IgemmDesc(C.Structure):
         ("accumulate", C.c_int32),
         ("stats", C.c_void_p),
         ("stats_stride", C.c_int32),
+        ("cout_mod", C.c_int32),
     ]
 
 
@@ -135,7 +136,7 @@ def lib():
         L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp]
         L.vsseg_dropout_mask.argtypes = [vp, i64, i32, f32, u64, u32, vp]
         L.vsseg_att_apply_fwd.argtypes = [Tensor, vp, Tensor, vp]
-        L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp, vp]
+        L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp, vp, vp]
         L.vsseg_channel_sum.argtypes = [Tensor, vp, vp]
         L.vsseg_add_inplace.argtypes = [Tensor, Tensor, vp]
         L.vsseg_copy_cast.argtypes = [Tensor, Tensor, vp]

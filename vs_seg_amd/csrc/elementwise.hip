@@ -400,7 +400,7 @@ extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tenso
 // dpre = (sum_c dout*x + datt_ext) * att*(1-att) in channel 0 of an 8-wide row; sum(dpre) -> bias gradient of attention conv2
 template <typename T, bool ACC, int G>
 __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int xsplit, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
-                                     T* __restrict__ dx0, T* __restrict__ dx1, int dxsplit, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias) {
+                                     T* __restrict__ dx0, T* __restrict__ dx1, int dxsplit, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias, T* __restrict__ dpre1) {
   const int sub = threadIdx.x % G;
   // two-part x / dx (skip-connection concat and its gradient): this lane's 8-channel group lies in one part
   const T* x = sub * 8 >= xsplit ? x1 - xsplit : x0;
@@ -431,6 +431,7 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restri
       if (datt_ext) dot += datt_ext[v];
       const float r = dot * a * (1.f - a);
       st8(dpre + v * dprep, f8{{r, 0, 0, 0, 0, 0, 0, 0}});
+      if (dpre1) Elem<T>::st(dpre1 + v, r);  // compact 1-channel copy for the z-folded data gradient of the sigmoid convolution
       bsum += r;
     }
   }
@@ -446,8 +447,8 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restri
     }
   }
 }
-template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, vsseg_tensor x, const float* att, const T* dout, int dp, const float* de, vsseg_tensor dx, T* dpre, int dprep, int cgs, int64_t nv, float* dbias) {
-#define VSSEG_ATT_BWD(GG) hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, GG>), g, b, 0, s, (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, dout, dp, de, (T*)dx.ptr, (T*)dx.ptr2, split_of(dx), dx.pitch, dpre, dprep, cgs, nv, dbias)
+template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, vsseg_tensor x, const float* att, const T* dout, int dp, const float* de, vsseg_tensor dx, T* dpre, int dprep, int cgs, int64_t nv, float* dbias, T* dpre1) {
+#define VSSEG_ATT_BWD(GG) hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, GG>), g, b, 0, s, (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, dout, dp, de, (T*)dx.ptr, (T*)dx.ptr2, split_of(dx), dx.pitch, dpre, dprep, cgs, nv, dbias, dpre1)
   switch (G) {
     case 1: VSSEG_ATT_BWD(1); break;
     case 2: VSSEG_ATT_BWD(2); break;
@@ -458,7 +459,7 @@ template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b
   }
 #undef VSSEG_ATT_BWD
 }
-extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, float* dbias, void* stream) {
+extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, float* dbias, void* dpre1, void* stream) {
   VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && dpre.ptr && x.dtype == dout.dtype && x.dtype == dx.dtype && x.dtype == dpre.dtype && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 && dpre.c == 8 &&
                   x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && dpre.pitch % 8 == 0 && x.c <= 256,
               "vsseg_att_apply_bwd: bad arguments");
@@ -469,8 +470,8 @@ extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tenso
   dim3 g(grid_for(nv * G, 256)), b(256);
   hipStream_t s = as_stream(stream);
   VSSEG_CHECK(two_part_ok(x) && two_part_ok(dx) && !dout.ptr2 && !dpre.ptr2, "vsseg_att_apply_bwd: bad two-part tensor");
-  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias);
-             else att_bwd_launch<T, false>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias));
+  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1);
+             else att_bwd_launch<T, false>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1));
   VSSEG_LAUNCH_CHECK("vsseg_att_apply_bwd");
   return VSSEG_OK;
 }

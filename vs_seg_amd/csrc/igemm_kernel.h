@@ -152,9 +152,10 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   for (int i = tid; i < NT * 16; i += 256) {
     const int c = split * NT * 16 + i;
     const bool ok = c < cout;
-    epi[i] = ((ok && d.bias) ? d.bias[c] : 0.f) + ((ok && d.bias2) ? d.bias2[c] : 0.f);
-    epi[NT * 16 + i] = (ok && d.scale) ? d.scale[c] : 1.f;
-    epi[2 * NT * 16 + i] = (ok && d.scale) ? d.shift[c] : 0.f;
+    const int cv = d.cout_mod > 0 ? c % d.cout_mod : c;  // z-folded launches: 8 z-neighbours x cout real channels share the per-channel vectors
+    epi[i] = ((ok && d.bias) ? d.bias[cv] : 0.f) + ((ok && d.bias2) ? d.bias2[cv] : 0.f);
+    epi[NT * 16 + i] = (ok && d.scale) ? d.scale[cv] : 1.f;
+    epi[2 * NT * 16 + i] = (ok && d.scale) ? d.shift[cv] : 0.f;
   }
   if (nch == 1) {  // packed weights stay resident for the whole kernel
     const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(d.wpack) + (int64_t)split * k.w_bytes);
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     for (int i = tid; i < 2 * NT * 16; i += 256) {
       int which = i / (NT * 16), cc = i - which * NT * 16;
       int c = split * NT * 16 + cc;
-      if (c < cout) atomicAdd(&st[which * d.stats_stride + c], (double)red[i]);
+      if (c < cout) atomicAdd(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)red[i]);
     }
   }
 }

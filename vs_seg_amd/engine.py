@@ -99,6 +99,8 @@ class _Choice:
     tuned_ms: Optional[list] = None  # autotuner measurements, one per candidate
     wshape: tuple = ()
     cached: bool = False  # the choice came from the tuned-plan cache, nothing was measured
+    fold: int = 0  # z-folded formulation (planner.FOLD z-neighbours as channels): the launch runs on reinterpreted tensors
+    cmod: int = 0  # ... and output channel c is real channel c % cmod for the per-channel vectors
 
 
 @dataclass
@@ -106,6 +108,8 @@ class _ConvPlans:
     fwd: List[_Choice]
     dgrad: List[_Choice]
     wgrad: Optional[P.WgradPlan]
+    fold_fwd: bool = False
+    fold_dgrad: bool = False
 
 
 class _Slot:
@@ -127,6 +131,8 @@ class Plan:
     def __init__(self, eng: "Engine", n: int, dims: Tuple[int, int, int], train: bool):
         self.eng, self.n, self.dims, self.train = eng, n, tuple(dims), train
         self.lv = level_dims(dims, eng.hp)
+        self.compact_input: Optional[torch.Tensor] = None  # [N,X,Y,Z,1] copy of the network input for the z-folded first-layer launches
+        self.needs_padded_input = train  # the 8-channel zero-extended input is only read by launches that are not z-folded (weight gradients)
         self.fwd: List[list] = []
         self.fwd_pre: List[list] = []  # eval only: launches that depend on parameters / buffers alone (BatchNorm folding); re-run with the weight packing when those change
         self.params_key = None  # parameter version the packed weights + folded BatchNorm constants of an eval plan belong to
@@ -154,6 +160,13 @@ class Plan:
         buf = self._alloc(spec, self.bufs if store is None else store)
         x, y, z = self.lv[spec.level]
         return L.Tensor(buf.data_ptr() + spec.c0 * buf.element_size(), _tdtype(buf), spec.c, spec.root.c, self.n, x, y, z)
+
+    def _xdesc(self, spec: TensorSpec, folded: bool) -> L.Tensor:
+        """Input descriptor of a convolution; the z-folded launches of the 1-channel network input read its compact copy."""
+        if folded and spec.root.name == self.eng.prog.input.name:
+            self.compact_input = self._raw("input:c1", 0, 1)
+            return self._tdesc(self.compact_input, 0)
+        return self._desc(spec)
 
     def _raw(self, name: str, level: int, c: int, dtype=None) -> torch.Tensor:
         if name not in self.bufs:
@@ -202,10 +215,14 @@ class Plan:
                     self.merged[a.layer.prefix] = op
                     self.absorbs[op.layer.prefix] = a
 
-        def choices(kind, Lr, q, kc_pad, aux_es, in_split, absorbed):
+        def choices(kind, Lr, q, kc_pad, aux_es, in_split, absorbed, fold=False):
             out = []
             woff = eng.layout.param_off[Lr.wkey][0]
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
+                if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
+                    cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
+                    out.append(_Choice(cands, woff, wshape=tuple(Lr.wshape), fold=P.FOLD, cmod=P.gemm_dims(kind, Lr.wshape)[1]))
+                    continue
                 if self.tune:
                     cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)
                 else:
@@ -227,15 +244,19 @@ class Plan:
             dims_out = P.out_dims(kind, dims_in, Lr.kernel, Lr.stride)
             assert dims_out == self.lv[Lr.out_level]
             aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
-            fwd = choices(kind, Lr, dims_in if Lr.transposed else dims_out, op.x.c, aux_es, op.x.parts[0].c if op.x.parts else 0, absorbed)
-            dgrad, wg = [], None
+            can_fold = (eng.fold and absorbed is None and op.res is None and op.x.parts is None and op.x.base is None and op.out.base is None
+                        and P.foldable(Lr.kernel, Lr.stride, Lr.transposed, Lr.cin, Lr.cout, dims_in))
+            fold_fwd = can_fold and (Lr.cout == 1 or op.x.root.name == eng.prog.input.name)  # a 1-channel input exists compactly only for the network input
+            fwd = choices(kind, Lr, dims_in if Lr.transposed else dims_out, op.x.c, aux_es, op.x.parts[0].c if op.x.parts else 0, absorbed, fold=fold_fwd)
+            dgrad, wg, fold_dgrad = [], None, False
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
                     q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
+                    fold_dgrad = can_fold and Lr.cout == 1 and getattr(op, "act", "") == "sigmoid"  # dY of the sigmoid convolution is written compactly by att_apply_bwd
+                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed, fold=fold_dgrad)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
-            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg)
+            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd, fold_dgrad)
 
     def _register(self, ch: _Choice, pl: P.IgemmPlan):
         """Append the chosen plan's weight gather map(s) to the step's pack list."""
@@ -272,7 +293,7 @@ class Plan:
     def _choose(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
-        key = (f"{p0.kind}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
+        key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
                f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}")
         cache = _tune_cache()
         hit = cache.get(key)
@@ -315,9 +336,18 @@ class Plan:
             i = 0
         return ch.cands[i]
 
+    @staticmethod
+    def _fold_desc(t: L.Tensor, fold: int) -> L.Tensor:
+        """[N,X,Y,Z,C] dense -> the bit-identical [N,X,Y,Z/fold,fold*C] view."""
+        assert t.c == t.pitch and not t.ptr2 and t.z % fold == 0, "z-folding needs a dense, single-part tensor"
+        return L.Tensor(t.ptr, t.dtype, t.c * fold, t.pitch * fold, t.n, t.x, t.y, t.z // fold)
+
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
                res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
         d = L.IgemmDesc()
+        if ch.fold:
+            inp, out, res = self._fold_desc(inp, ch.fold), self._fold_desc(out, ch.fold), (self._fold_desc(res, ch.fold) if res is not None else None)
+            d.cout_mod = ch.cmod
         d.inp, d.out = inp, out
         d.bias, d.bias2, d.scale, d.shift, d.alpha = bias or None, bias2 or None, scale or None, shift or None, alpha or None
         d.act, d.res_mode, d.accumulate = act, res_mode, accumulate
@@ -334,7 +364,8 @@ class Plan:
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
-        meta = dict(tag=f"{pl.kind} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc,
+        fold_tag = f" zfold{ch.fold}" if ch.fold else ""
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>", kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
                     bytes=float(nvalid) * pl.nc * es_out + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
@@ -369,7 +400,7 @@ class Plan:
         for op in ops:
             if isinstance(op, ConvBnAct):
                 Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
-                xin, out = self._desc(op.x), self._desc(op.out)
+                xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if op.res is not None else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
@@ -390,7 +421,7 @@ class Plan:
                 if Lr.prefix in self.merged:  # computed inside the convolution it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
-                xin, out = self._desc(op.x), self._desc(op.out)
+                xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for ch in cp.fwd:
                     self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
@@ -399,6 +430,8 @@ class Plan:
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
+        if any((not self.cplans[op.layer.prefix].fold_fwd) and op.layer.prefix not in self.merged and op.x.root.name == prog.input.name for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
+            self.needs_padded_input = True
         self.out_logits = self._alloc(prog.logits, self.bufs)
         self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
         if not self.train:
@@ -438,7 +471,7 @@ class Plan:
             assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
             return gdesc(t)
 
-        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None):
+        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None):
             cp = self.cplans[Lr.prefix]
             wg = cp.wgrad
             xin = self._desc(x)
@@ -506,7 +539,7 @@ class Plan:
                 acc = contribution(x)
                 gx = gdesc(x)
                 for ch in cp.dgrad:
-                    self._igemm(B, ch, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
+                    self._igemm(B, ch, dy_compact if ch.fold else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
@@ -542,14 +575,16 @@ class Plan:
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
-                conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name))
+                dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and self.cplans[Lr.prefix].fold_dgrad) else None
+                conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc)
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
                 acc = contribution(op.x)
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey)]])
+                dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if self.cplans[sig.prefix].fold_dgrad else None
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1]])
         self._finish_pack()
 
     def _index_slots(self):
@@ -613,6 +648,7 @@ class Engine:
             raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
         self.device = flat.device
         self.dry_run = dry_run
+        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded first-layer / attention-map launches (planner.FOLD); 0 disables
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
         self.es = 2 if dtype == "bf16" else 4

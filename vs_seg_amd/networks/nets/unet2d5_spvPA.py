@@ -225,8 +225,11 @@ class UNet2d5_spvPA(nn.Module):
                 plan.pack_weights(stream)
                 plan.run(plan.fwd_pre, stream)
                 plan.params_key = key
-        inp = plan._desc(eng.prog.input)
-        L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), inp, stream), "stage_input")
+        if plan.needs_padded_input:  # 8-channel zero-extended copy (one MFMA K-group) for the launches that are not z-folded
+            inp = plan._desc(eng.prog.input)
+            L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), inp, stream), "stage_input")
+        if plan.compact_input is not None:  # 1-channel copy in the compute dtype for the z-folded first-layer launches
+            L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), plan._tdesc(plan.compact_input, 0), stream), "stage_input")
         plan.run(plan.fwd, stream)
         logits = plan.out_logits.permute(0, 4, 1, 2, 3)  # [B,2,X,Y,Z] view of channels-last storage (torch.channels_last_3d strides)
         atts = [a.permute(0, 4, 1, 2, 3) for a in plan.out_atts]

@@ -289,6 +289,53 @@ def pack_map(plan: IgemmPlan, wshape) -> np.ndarray:
     return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
 
 
+# ---- z-folding: convolutions without taps along z and with a single real input or output channel ---------------------
+# A [N,X,Y,Z,C] tensor is bit-identical to [N,X,Y,Z/8,8*C] (folded channel = (z % 8)*C + c).  A kernel with kz == 1 maps
+# z-slice j of the input to z-slice j of the output, so the convolution equals one with 8*Cin inputs, 8*Cout outputs and
+# block-diagonal weights on the folded tensors.  For Cin == 1 or Cout == 1 this replaces the 8-fold zero-extended channel
+# group the MFMA path needs by 8 real z-neighbours: the launch reads / writes 1/8 of the bytes on that side and the MFMA
+# count is unchanged (the zeros move from padded channels to off-diagonal blocks).
+FOLD = 8
+
+
+def foldable(kernel, stride, transposed, cin, cout, dims) -> bool:
+    return (not transposed) and kernel[2] == 1 and tuple(stride) == (1, 1, 1) and dims[2] % FOLD == 0 and (cin == 1 or cout == 1) and max(cin, cout) * FOLD <= 128
+
+
+def folded_wshape(wshape) -> tuple:
+    return (wshape[0] * FOLD, wshape[1] * FOLD, *wshape[2:])
+
+
+def fold_pack_map(vmap: np.ndarray, wshape) -> np.ndarray:
+    """Pack map of a plan made for `folded_wshape(wshape)` -> flat indices into the REAL weight (or -1 off the diagonal)."""
+    cout, cin = int(wshape[0]), int(wshape[1])
+    T = int(np.prod(wshape[2:]))
+    v = vmap.astype(np.int64)
+    ok = v >= 0
+    vv = np.where(ok, v, 0)
+    t = vv % T
+    iv = (vv // T) % (cin * FOLD)
+    ov = vv // (T * cin * FOLD)
+    jo, co = ov // cout, ov % cout
+    ji, ci = iv // cin, iv % cin
+    real = (co * cin + ci) * T + t
+    return np.where(ok & (jo == ji), real, -1).astype(np.int32)
+
+
+def folded_candidate_plans(kind, wshape, cls: LatticeClass, q, es, aux_es=4, heuristic_only=False) -> List[IgemmPlan]:
+    """`candidate_plans` of the z-folded formulation; q is the REAL lattice extent, the plans' q / kc / nc are folded."""
+    vw = folded_wshape(wshape)
+    qv = (q[0], q[1], q[2] // FOLD)
+    kreal, _ = gemm_dims(kind, vw)
+    if heuristic_only:
+        cands = [plan_igemm(kind, vw, cls, qv, es, kc_pad=round_up(kreal, 8), aux_es=aux_es)]
+    else:
+        cands = candidate_plans(kind, vw, cls, qv, es, kc_pad=round_up(kreal, 8), aux_es=aux_es)
+    for pl in cands:
+        pl.pack_map = fold_pack_map(pl.pack_map, wshape)
+    return cands
+
+
 def pack_map_centre(plan: IgemmPlan, wshape_1x1) -> np.ndarray:
     """Gather map (same layout as `pack_map`) that places a 1x1x1 convolution's weights on the zero-offset tap of `plan`
     and -1 elsewhere: adding it to the plan's own map merges `conv_k(x) + conv_1x1(x)` into one convolution."""
