@@ -246,14 +246,19 @@ class Plan:
             aux_es = 0 if (op.res is None or absorbed is not None) else (4 if op.res.kind == 'f32' else eng.es)
             can_fold = (eng.fold and absorbed is None and op.res is None and op.x.parts is None and op.x.base is None and op.out.base is None
                         and P.foldable(Lr.kernel, Lr.stride, Lr.transposed, Lr.cin, Lr.cout, dims_in))
-            fold_fwd = can_fold and (Lr.cout == 1 or op.x.root.name == eng.prog.input.name)  # a 1-channel input exists compactly only for the network input
+            # Measured (tools: bench.py --profile, VSSEG_ZFOLD=all): folding pays on the narrow-OUTPUT side only — the attention sigmoid
+            # convolution 16->1 drops from 0.51 to 0.33 ms (its input is read as 128 real channels, the 1-channel map is written as
+            # 32-byte rows).  On the narrow-INPUT side (network input 1->16, dY of the sigmoid conv) the folded output rows are 256 B
+            # wide and every 16-channel N-tile stores 32-byte fragments of them: 0.46 -> 0.50 ms and 0.51 -> 0.70 ms, so those stay unfolded.
+            wide_n = eng.fold_all
+            fold_fwd = can_fold and (Lr.cout == 1 or (wide_n and op.x.root.name == eng.prog.input.name))
             fwd = choices(kind, Lr, dims_in if Lr.transposed else dims_out, op.x.c, aux_es, op.x.parts[0].c if op.x.parts else 0, absorbed, fold=fold_fwd)
             dgrad, wg, fold_dgrad = [], None, False
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
                     q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                    fold_dgrad = can_fold and Lr.cout == 1 and getattr(op, "act", "") == "sigmoid"  # dY of the sigmoid convolution is written compactly by att_apply_bwd
+                    fold_dgrad = wide_n and can_fold and Lr.cout == 1 and getattr(op, "act", "") == "sigmoid"  # dY of the sigmoid convolution is written compactly by att_apply_bwd
                     dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed, fold=fold_dgrad)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd, fold_dgrad)
@@ -648,7 +653,8 @@ class Engine:
             raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
         self.device = flat.device
         self.dry_run = dry_run
-        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded first-layer / attention-map launches (planner.FOLD); 0 disables
+        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
+        self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
         self.es = 2 if dtype == "bf16" else 4

@@ -234,7 +234,10 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     out, seen = [default], {(default.tile, default.nt, default.nsplit, default.ck)}
     cks = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0 and (not in_split or c == kc or in_split % c == 0)}, reverse=True)
     nvox = q[0] * q[1] * q[2]
-    for nsplit in sorted({default.nsplit, min(nt_total, default.nsplit + 1), max(1, default.nsplit - 1)}):
+    nsplits = {default.nsplit, min(nt_total, default.nsplit + 1), max(1, default.nsplit - 1)}
+    if kc <= 16:  # tiny K (z-folded 1-channel inputs): re-reading the input per split is free, small NT keeps 3-4 workgroups per CU
+        nsplits |= {nt_total, (nt_total + 1) // 2}
+    for nsplit in sorted(nsplits):
         nt = (nt_total + nsplit - 1) // nsplit
         if nt > 6:
             continue
