@@ -33,6 +33,8 @@ extern "C" {
 #define VSSEG_RES_NONE 0
 #define VSSEG_RES_ADD 1      /* out = f(acc) + res                      (ResidualUnit add, ref:.../convolutions.py:252-255) */
 #define VSSEG_RES_RELUMASK 2 /* out = acc * (res > 0)                   (backward of the attention ReLU)                   */
+#define VSSEG_RES_GATE 3     /* out = acc + res * (1 + gate[voxel])     (backward of AttentionBlock2 `att*x + x`, ref:.../attentionblock.py:43-47, fused
+                              *  into the data gradient of the attention branch's first convolution: both flow into d(x))                          */
 
 #define VSSEG_MAX_TAPS 27
 #define VSSEG_STAT_SHARDS 256
@@ -87,6 +89,7 @@ typedef struct {
    * z-neighbours are reinterpreted as 8 channels; the packed weights are block-diagonal): output channel c of the launch is
    * real channel c % cout_mod for bias / bias2 / scale / shift / stats.  0: off. */
   int32_t cout_mod;
+  const float* gate;       /* VSSEG_RES_GATE: fp32 attention map [N][X][Y][Z] of the output tensor, or NULL */
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
@@ -155,6 +158,7 @@ int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint6
 /* AttentionBlock2: out = x * (1 + att)   (ref:params/networks/blocks/attentionblock.py:43-47); att is f32 [voxel]. */
 int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tensor out, void* stream);
 /* dx (+)= dout*(1+att);  dpre[voxel][0] = (sum_c dout*x + datt_ext) * att*(1-att)  (sigmoid backward), channels 1..7 zero. */
+/* accumulate_dx: 0 dx = dout*(1+att); 1 dx += ...; 2 dx is not written (its contribution is fused into a VSSEG_RES_GATE igemm launch). */
 int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre,
                         float* dbias /* += sum(dpre): bias gradient of the sigmoid convolution, or NULL */,
                         void* dpre1 /* optional compact [N,X,Y,Z] copy of channel 0 of dpre (x's dtype), or NULL */, void* stream);

@@ -12,7 +12,7 @@ SO_PATH = os.path.join(_HERE, "libvsseg_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-RES_NONE, RES_ADD, RES_RELUMASK = 0, 1, 2
+RES_NONE, RES_ADD, RES_RELUMASK, RES_GATE = 0, 1, 2, 3
 MAX_TAPS = 27
 STAT_SHARDS = 256
 EINVAL, ELAUNCH = -1, -2
@@ -65,6 +65,7 @@ class IgemmDesc(C.Structure):
         ("stats", C.c_void_p),
         ("stats_stride", C.c_int32),
         ("cout_mod", C.c_int32),
+        ("gate", C.c_void_p),
     ]
 
 

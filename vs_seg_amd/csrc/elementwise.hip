@@ -400,7 +400,7 @@ extern "C" int vsseg_att_apply_fwd(vsseg_tensor x, const float* att, vsseg_tenso
 // dpre = (sum_c dout*x + datt_ext) * att*(1-att) in channel 0 of an 8-wide row; sum(dpre) -> bias gradient of attention conv2
 template <typename T, bool ACC, int G>
 __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int xsplit, int xp, const float* __restrict__ att, const T* __restrict__ dout, int dp, const float* __restrict__ datt_ext,
-                                     T* __restrict__ dx0, T* __restrict__ dx1, int dxsplit, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias, T* __restrict__ dpre1) {
+                                     T* __restrict__ dx0, T* __restrict__ dx1, int dxsplit, int dxp, T* __restrict__ dpre, int dprep, int cgs, int64_t nvox, float* __restrict__ dbias, T* __restrict__ dpre1, int skip_dx) {
   const int sub = threadIdx.x % G;
   // two-part x / dx (skip-connection concat and its gradient): this lane's 8-channel group lies in one part
   const T* x = sub * 8 >= xsplit ? x1 - xsplit : x0;
@@ -422,7 +422,7 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restri
           dot += d.v[j] * xx.v[j];
           o.v[j] = ACC ? o.v[j] + d.v[j] * g : d.v[j] * g;
         }
-        st8(dx + v * dxp + sub * 8, o);
+        if (!skip_dx) st8(dx + v * dxp + sub * 8, o);  // skip_dx: d(x) is produced by the attention conv's data gradient (VSSEG_RES_GATE)
       }
     }
 #pragma unroll
@@ -447,8 +447,8 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restri
     }
   }
 }
-template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, vsseg_tensor x, const float* att, const T* dout, int dp, const float* de, vsseg_tensor dx, T* dpre, int dprep, int cgs, int64_t nv, float* dbias, T* dpre1) {
-#define VSSEG_ATT_BWD(GG) hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, GG>), g, b, 0, s, (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, dout, dp, de, (T*)dx.ptr, (T*)dx.ptr2, split_of(dx), dx.pitch, dpre, dprep, cgs, nv, dbias, dpre1)
+template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b, hipStream_t s, vsseg_tensor x, const float* att, const T* dout, int dp, const float* de, vsseg_tensor dx, T* dpre, int dprep, int cgs, int64_t nv, float* dbias, T* dpre1, int skip_dx) {
+#define VSSEG_ATT_BWD(GG) hipLaunchKernelGGL((att_apply_bwd_kernel<T, ACC, GG>), g, b, 0, s, (const T*)x.ptr, (const T*)x.ptr2, split_of(x), x.pitch, att, dout, dp, de, (T*)dx.ptr, (T*)dx.ptr2, split_of(dx), dx.pitch, dpre, dprep, cgs, nv, dbias, dpre1, skip_dx)
   switch (G) {
     case 1: VSSEG_ATT_BWD(1); break;
     case 2: VSSEG_ATT_BWD(2); break;
@@ -470,8 +470,9 @@ extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tenso
   dim3 g(grid_for(nv * G, 256)), b(256);
   hipStream_t s = as_stream(stream);
   VSSEG_CHECK(two_part_ok(x) && two_part_ok(dx) && !dout.ptr2 && !dpre.ptr2, "vsseg_att_apply_bwd: bad two-part tensor");
-  DISPATCH_T(x.dtype, if (accumulate_dx) att_bwd_launch<T, true>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1);
-             else att_bwd_launch<T, false>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1));
+  const int skip_dx = accumulate_dx == 2;  // 2: do not produce d(x) here at all
+  DISPATCH_T(x.dtype, if (accumulate_dx == 1) att_bwd_launch<T, true>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1, 0);
+             else att_bwd_launch<T, false>(G, g, b, s, x, att, (const T*)dout.ptr, dout.pitch, datt_ext, dx, (T*)dpre.ptr, dpre.pitch, cgs, nv, dbias, (T*)dpre1, skip_dx));
   VSSEG_LAUNCH_CHECK("vsseg_att_apply_bwd");
   return VSSEG_OK;
 }

@@ -102,6 +102,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
                              "vsseg_igemm: bad two-part tensor (c=%d csplit=%d pitch=%d)", t->c, t->csplit, t->pitch);
   }
   VSSEG_CHECK(!d->in.ptr2 || d->nchunks == 1 || d->in.csplit % d->ck == 0, "vsseg_igemm: a channel chunk (ck=%d) straddles the input split at %d", d->ck, d->in.csplit);
+  VSSEG_CHECK(d->res_mode != VSSEG_RES_GATE || (d->gate && !d->accumulate), "vsseg_igemm: RES_GATE needs the gate map and does not combine with accumulate");
   k.d = *d;
   const int es = d->in.dtype == VSSEG_F32 ? 4 : 2;
   k.cgs = d->ck / 8;
@@ -119,10 +120,12 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.w_bytes = d->ksteps * d->nt * 64 * 8 * es;
   k.h_bytes = k.halo[0] * k.halo[1] * k.halo[2] * d->ck * es;
   k.aux_mode = 0;
+  k.aux_gate_off = 0;
   k.aux_bytes = 0;
   if (d->accumulate && d->res_mode == VSSEG_RES_NONE) { k.aux_mode = 1; k.aux = d->out; }
   else if (!d->accumulate && d->res_mode == VSSEG_RES_ADD) { k.aux_mode = 2; k.aux = d->res; }
   else if (!d->accumulate && d->res_mode == VSSEG_RES_RELUMASK) { k.aux_mode = 3; k.aux = d->res; }
+  else if (!d->accumulate && d->res_mode == VSSEG_RES_GATE) { k.aux_mode = 4; k.aux = d->res; }
   if (d->stats) k.aux_mode = 0;  // statistics + residual in one launch does not occur in this network: generic epilogue
   if (k.aux_mode) {
     const int aes = k.aux.dtype == VSSEG_F32 ? 4 : 2;
@@ -131,6 +134,12 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
     const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && beyond <= k.aux.pitch && 64 * d->mtw * (row / 16) <= AMAX * 256 && ((uintptr_t)k.aux.ptr2 % 16) == 0 &&
                     ((uintptr_t)k.aux.ptr % 16) == 0 && k.aux.c >= d->out.c;
     if (ok) k.aux_bytes = 64 * d->mtw * row; else k.aux_mode = 0;
+    // the gate map of a gated add is DMA-prefetched with the tile when 4 z-consecutive tile voxels are 16 contiguous, aligned bytes
+    if (ok && k.aux_mode == 4 && d->tile[2] % 4 == 0 && d->out.z % 4 == 0 && d->os[0] == 1 && d->os[1] == 1 && d->os[2] == 1 && d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 &&
+        ((uintptr_t)d->gate % 16) == 0) {
+      k.aux_gate_off = k.aux_bytes;
+      k.aux_bytes += 64 * d->mtw * 4;
+    }
   }
   VSSEG_CHECK(k.h_bytes <= PMAX * 256 * 16, "vsseg_igemm: halo chunk of %d bytes exceeds %d; reduce ck or the tile", k.h_bytes, PMAX * 256 * 16);
   VSSEG_CHECK(d->ck * es / 16 <= 255, "vsseg_igemm: ck too large");

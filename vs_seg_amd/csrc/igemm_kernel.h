@@ -36,8 +36,9 @@ struct IgemmK {
   int h_bytes;  // halo chunk
   int lds_ktab, lds_epi, lds_w, lds_h, lds_aux, lds_pinfo;
   int npu;        // 16-byte halo pieces per thread and stage = rows of the per-thread coordinate table in LDS
-  int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask: the aux tile is prefetched by DMA like the halo
-  int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (0: aux handled by the slow path)
+  int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask, 4 gated add (aux * (1 + gate[voxel])): the aux tile is prefetched by DMA like the halo
+  int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (+ the gate floats) (0: aux handled by the slow path)
+  int aux_gate_off;  // aux_mode 4 with the gate map DMA-prefetched: byte offset of the tile's 64*MTW gate floats inside an aux buffer; 0: ordinary loads
   int depth;      // prefetch distance in stages (1..3); the LDS rings hold depth+1 buffers
   vsseg_tensor aux;
   int64_t total_tiles;
@@ -243,6 +244,16 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   char* out_base1 = out_two ? reinterpret_cast<char*>(d.out.ptr2) - (int64_t)out_csplit * out_es : out_base;
   const bool res_two = d.res_mode != VSSEG_RES_NONE && d.res.ptr2 != nullptr;
   const int res_csplit = res_two ? d.res.csplit : 0x7fffffff;
+  // gated add (aux_mode 4): the tile's attention values ride in the aux buffer too — one 16-byte piece per 4 z-consecutive voxels,
+  // fetched by wave 0 (16*MTW pieces); an ordinary load in the epilogue would make hipcc drain the DMA queue
+  const bool gate_dma = AUXM && k.aux_gate_off > 0;
+  unsigned grel = 0;  // voxel offset (relative to the tile's first output voxel) of this lane's gate piece
+  if (gate_dma && wave == 0 && lane < 16 * MTW) {
+    const int v = lane * 4;
+    int vz = v % d.tile[2], r = v / d.tile[2];
+    int vy = r % d.tile[1], vx = r / d.tile[1];
+    grel = (unsigned)((vx * OY + vy) * OZ + vz);
+  }
   const bool fast_store = (d.res_mode == VSSEG_RES_NONE && !d.accumulate) || aux_on;
   const bool vec_store = (d.out.pitch & 3) == 0 && (cout & 3) == 0;
 
@@ -276,6 +287,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   for (int u = 0; u < PMAX; ++u) nh += ((u * 4 + wave) * 64 < pieces) ? 1 : 0;
 #pragma unroll
   for (int u = 0; u < (AUXM ? AMAX : 0); ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
+  if (gate_dma && wave == 0) ++na;
   if (nch > 1)
     for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
   // store instructions a wave issues in the fast epilogue of one tile (exactly one 8/16-byte store per valid 16-channel
@@ -346,6 +358,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       for (int u = 0; u < (AUXM ? AMAX : 0); ++u) {
         if ((u * 4 + wave) * 64 >= apieces) break;
         if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
+      }
+      if (gate_dma && wave == 0) {
+        if (lane < 16 * MTW) dma16(whole ? (const void*)(d.gate + td.out_vox + grel) : k.zeros, Adst + k.aux_gate_off);
       }
       if (++abuf_issue == nbuf) abuf_issue = 0;
     }
@@ -475,6 +490,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     if (++abuf_cur == nbuf) abuf_cur = 0;
     if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
       st_h0 = nst_fast;
+      float gate[MTW];  // aux_mode 4: 1 + attention value of this lane's voxels (one ordinary load each, issued together)
+      if constexpr (AUXM) {
+        if (k.aux_mode == 4) {
+#pragma unroll
+          for (int m = 0; m < MTW; ++m)
+            gate[m] = 1.f + (gate_dma ? reinterpret_cast<const float*>(Aux + k.aux_gate_off)[(wave * MTW + m) * 16 + l15] : d.gate[tc.out_vox + ovrel[m]]);
+        }
+      }
 #pragma unroll
       for (int m = 0; m < MTW; ++m) {
         char* op = out_tile + ovrel[m] * out_vox_bytes;
@@ -508,6 +531,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
             const float4 av = aux_es == 4 ? *reinterpret_cast<const float4*>(ap) : ld4(reinterpret_cast<const bf16_t*>(ap));
             if (k.aux_mode == 3) {
               val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
+            } else if (k.aux_mode == 4) {
+              val[0] += av.x * gate[m]; val[1] += av.y * gate[m]; val[2] += av.z * gate[m]; val[3] += av.w * gate[m];
             } else {
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             }
@@ -555,7 +580,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
             const void* rbase = r2 ? d.res.ptr2 : d.res.ptr;
             const int64_t ro = ovox * d.res.pitch + c + r - (r2 ? res_csplit : 0);
             float rv = d.res.dtype == VSSEG_F32 ? reinterpret_cast<const float*>(rbase)[ro] : bf2f(reinterpret_cast<const bf16_t*>(rbase)[ro]);
-            x = d.res_mode == VSSEG_RES_ADD ? x + rv : (rv > 0.f ? x : 0.f);
+            x = d.res_mode == VSSEG_RES_ADD ? x + rv : (d.res_mode == VSSEG_RES_GATE ? x + rv * (1.f + d.gate[ovox]) : (rv > 0.f ? x : 0.f));
           }
           val[r] = x;
         }

@@ -348,8 +348,9 @@ class Plan:
         return L.Tensor(t.ptr, t.dtype, t.c * fold, t.pitch * fold, t.n, t.x, t.y, t.z // fold)
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0):
         d = L.IgemmDesc()
+        d.gate = gate or None
         if ch.fold:
             inp, out, res = self._fold_desc(inp, ch.fold), self._fold_desc(out, ch.fold), (self._fold_desc(res, ch.fold) if res is not None else None)
             d.cout_mod = ch.cmod
@@ -476,7 +477,7 @@ class Plan:
             assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
             return gdesc(t)
 
-        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None):
+        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None, gate=None):
             cp = self.cplans[Lr.prefix]
             wg = cp.wgrad
             xin = self._desc(x)
@@ -543,9 +544,14 @@ class Plan:
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
+                if gate is not None:  # d(x) = conv^T(dy) + d(gated) * (1 + att): the attention gate's backward rides in this launch's epilogue
+                    assert acc == 0 and relumask is None and len(cp.dgrad) == 1
+                    self._igemm(B, cp.dgrad[0], dy, gx, res=gate[0], res_mode=L.RES_GATE, gate=gate[1])
+                    return
                 for ch in cp.dgrad:
                     self._igemm(B, ch, dy_compact if ch.fold else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
+        gate_fuse: Dict[str, tuple] = {}  # relu-conv prefix -> (d(gated) descriptor, attention map pointer) of the gate fused into its data gradient
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
         folded_bias = set()  # plain convolutions whose bias gradient is produced by another kernel's reduction
@@ -581,10 +587,20 @@ class Plan:
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
                 dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and self.cplans[Lr.prefix].fold_dgrad) else None
-                conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc)
+                conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc, gate=gate_fuse.get(Lr.prefix))
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
-                acc = contribution(op.x)
+                # The gate's d(x) = d(gated) * (1 + att) and the data gradient of the attention branch's first convolution (relu
+                # conv on the same x) both flow into d(x): fused, the gate kernel skips its full-width d(x) store and the igemm
+                # launch reads d(gated) where it would have read-modify-written d(x) (one tensor pass less per level).
+                c1 = next((o for o in ops if isinstance(o, ConvPlain) and o.act == "relu" and o.x is op.x), None)
+                xs = op.x.parts if op.x.parts else (op.x,)
+                fuse = eng.gate_fuse and c1 is not None and len(self.cplans[c1.layer.prefix].dgrad) == 1 and not any(written.get(t.root.name) for t in xs)
+                if fuse:
+                    gate_fuse[c1.layer.prefix] = (gout, self._alloc(op.att, self.bufs).data_ptr())
+                    acc = 2  # att_apply_bwd: do not write d(x)
+                else:
+                    acc = contribution(op.x)
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
@@ -655,6 +671,7 @@ class Engine:
         self.dry_run = dry_run
         self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
         self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
+        self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
         self.es = 2 if dtype == "bf16" else 4

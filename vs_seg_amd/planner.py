@@ -134,7 +134,7 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
     """Mirror of igemm_prepare() in csrc/igemm.hip: tap table | epilogue constants | weights (x2 when streamed) | 2 halo buffers | aux | coordinate tables."""
     w = ksteps * nt * 64 * 8 * es
     nbuf = max(depth, 0) + 1  # depth -1: no prefetch, single buffer
-    aux = nbuf * 64 * mtw * nt * 16 * aux_es if 64 * mtw * nt * aux_es <= 8 * 256 else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread)
+    aux = nbuf * (64 * mtw * nt * 16 * aux_es + 64 * mtw * 4) if (aux_es and 64 * mtw * nt * aux_es <= 8 * 256) else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread) + gate floats
     hb = igemm_halo_bytes(tile, is_, taps, ck, es)
     tables = (2 * ((hb // 16 + 255) // 256) + 1) * 1024  # per-thread DMA offset table + coordinate tables of the boundary-tile paths
     return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * hb + aux + tables
