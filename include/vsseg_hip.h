@@ -142,6 +142,10 @@ int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, c
  * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables. */
 int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
                      vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
+/* Same with the residual computed on the fly as the 1x1x1 convolution of a ONE-channel tensor: res[v][c] = x1[v]*res_w[c] + res_b[c]
+ * (first encoder ResidualUnit, in_channels = 1, ref:params/networks/blocks/convolutions.py:241-255); x1 is [N][X][Y][Z] in y's dtype. */
+int vsseg_bn_act_fwd_res1(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
+                          const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, void* stream);
 /* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, [2][c] += dout, alpha_acc[shard] += dA*d(d<0). */
 int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
                             const float* scale, const float* shift, /* the forward's folded affine: the PReLU/dropout branch is re-decided on the SAME fp32 value */

@@ -98,7 +98,7 @@ class WgradDesc(C.Structure):
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
     "vsseg_last_error", "vsseg_version", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
-    "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
+    "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
     "vsseg_adam", "vsseg_swi_accumulate", "vsseg_swi_finalize", "vsseg_hard_dice_counts", "vsseg_argmax2",
@@ -132,6 +132,7 @@ def lib():
         L.vsseg_bn_finalize.argtypes = [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.vsseg_bn_fold_eval.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
         L.vsseg_bn_act_fwd.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, Tensor, i32, Tensor, vp]
+        L.vsseg_bn_act_fwd_res1.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, vp, vp, vp, Tensor, vp]
         L.vsseg_bn_act_bwd_reduce.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, i32, vp, vp]
         L.vsseg_bn_act_bwd_finalize.argtypes = [vp, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp, vp]
         L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp]

@@ -169,9 +169,13 @@ extern "C" int vsseg_bn_fold_eval(const float* gamma, const float* beta, const f
 // ------------------------------------------------------------------------------------------------------------
 // BN -> Dropout -> PReLU (+ residual) forward            ref:params/networks/blocks/convolutions.py:148-156, 252-255
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, bool RES>
+// RES: 0 no residual, 1 residual tensor, 2 residual = 1x1x1 convolution of a ONE-channel input computed on the fly
+// (res[v][c] = x1[v] * rw[c] + rb[c]: the ResidualUnit residual of the first encoder block, ref:.../convolutions.py:241-250 with
+// in_channels = 1 — its 16-channel output tensor is never written or read)
+template <typename T, int RES>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ alpha_p,
-                                  float p_drop, uint64_t seed, uint32_t salt, const T* __restrict__ res, int rp, T* __restrict__ out, int op, int cgs, int64_t nvox) {
+                                  float p_drop, uint64_t seed, uint32_t salt, const T* __restrict__ res, int rp, T* __restrict__ out, int op, int cgs, int64_t nvox,
+                                  const float* __restrict__ rw, const float* __restrict__ rb) {
   const int64_t total = nvox * cgs;
   const float alpha = *alpha_p, inv_keep = 1.f / (1.f - p_drop);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -180,7 +184,12 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
     f8 x = ld8(y + v * yp + c);
     unsigned keep = p_drop > 0.f ? dropout_keep8(seed, salt, (uint64_t)i, p_drop) : 0xffu;
     f8 r;
-    if (RES) r = ld8(res + v * rp + c);
+    if (RES == 1) r = ld8(res + v * rp + c);
+    if (RES == 2) {
+      const float x1 = Elem<T>::ld(res + v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r.v[j] = x1 * rw[c + j] + rb[c + j];
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float z = x.v[j] * scale[c + j] + shift[c + j];
@@ -200,9 +209,21 @@ extern "C" int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float*
   int64_t nv = tensor_voxels(y);
   int cgs = y.c / 8;
   dim3 g(grid_for(nv * cgs, 256)), b(256);
-  DISPATCH_T(y.dtype, if (has_res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, true>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)res.ptr, res.pitch, (T*)out.ptr, out.pitch, cgs, nv);
-             else hipLaunchKernelGGL((bn_act_fwd_kernel<T, false>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)nullptr, 0, (T*)out.ptr, out.pitch, cgs, nv));
+  DISPATCH_T(y.dtype, if (has_res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)res.ptr, res.pitch, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr);
+             else hipLaunchKernelGGL((bn_act_fwd_kernel<T, 0>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)nullptr, 0, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_fwd");
+  return VSSEG_OK;
+}
+extern "C" int vsseg_bn_act_fwd_res1(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
+                                     const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, void* stream) {
+  VSSEG_ONE_PART("vsseg_bn_act_fwd_res1", &y, &out);
+  VSSEG_CHECK(y.ptr && out.ptr && scale && shift && alpha && x1 && res_w && res_b && y.c % 8 == 0 && y.pitch % 8 == 0 && out.pitch % 8 == 0 && out.c == y.c && out.dtype == y.dtype, "vsseg_bn_act_fwd_res1: bad arguments");
+  VSSEG_CHECK(p_drop >= 0.f && p_drop < 1.f, "vsseg_bn_act_fwd_res1: dropout p out of range");
+  int64_t nv = tensor_voxels(y);
+  int cgs = y.c / 8;
+  dim3 g(grid_for(nv * cgs, 256)), b(256);
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, 2>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)x1, 0, (T*)out.ptr, out.pitch, cgs, nv, res_w, res_b));
+  VSSEG_LAUNCH_CHECK("vsseg_bn_act_fwd_res1");
   return VSSEG_OK;
 }
 

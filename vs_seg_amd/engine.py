@@ -402,6 +402,18 @@ class Plan:
         p_drop = float(eng.dropout_p) if self.train else 0.0
         self.bn_info = {Lr.prefix: (Lr, salt[Lr.prefix]) for Lr in bn_layers}
 
+        # First encoder ResidualUnit (in_channels = 1): its 1x1x1 residual convolution is x1[v]*w[c] + b[c]; in training it is
+        # computed inside the BN/dropout/PReLU kernel that adds it (vsseg_bn_act_fwd_res1) instead of by an igemm launch that
+        # writes a 16-channel tensor for that kernel to read back.  (Eval adds the residual in the conv epilogue and keeps the launch.)
+        plain_by_out = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}
+        res1_fused: Dict[str, ConvPlain] = {}
+        if self.train and eng.res1_fuse:
+            for op in ops:
+                if isinstance(op, ConvBnAct) and op.res is not None and op.res.name in plain_by_out:
+                    pr = plain_by_out[op.res.name]
+                    if pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None:
+                        res1_fused[pr.layer.prefix] = pr
+
         # ---- forward
         F = self.fwd
         grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
@@ -409,7 +421,8 @@ class Plan:
             if isinstance(op, ConvBnAct):
                 Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
-                res = self._desc(op.res) if op.res is not None else None
+                fused_res = plain_by_out[op.res.name] if (op.res is not None and op.res.name in plain_by_out and plain_by_out[op.res.name].layer.prefix in res1_fused) else None
+                res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
                 if self.train:
@@ -418,7 +431,11 @@ class Plan:
                         self._igemm(F, ch, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
-                    F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
+                    if fused_res is not None:
+                        x1 = self._xdesc(fused_res.x, True)  # compact 1-channel copy of the network input
+                        F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out]])
+                    else:
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
                 else:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
                     for ch in cp.fwd:
@@ -426,7 +443,7 @@ class Plan:
                                     res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
-                if Lr.prefix in self.merged:  # computed inside the convolution it is added to
+                if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
@@ -673,6 +690,7 @@ class Engine:
         self.dry_run = dry_run
         self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
         self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
+        self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
