@@ -55,3 +55,40 @@ def test_bad_spatial_size_raises():
     eng = Engine(True, "bf16", flat, torch.zeros_like(flat), torch.zeros(lay.n_buf), torch.zeros(lay.n_cnt, dtype=torch.int64), lay, dry_run=True)
     with pytest.raises(ValueError):
         eng.plan(1, (48, 32, 8), False)
+
+
+def test_shipped_tuned_plans_still_name_existing_candidates():
+    """vs_seg_amd/tuned_gfx950.json (plans measured on an MI355X for the benchmark shapes) is only useful while its entries still
+    match what `planner.candidate_plans` generates: a planner / kernel change that invalidates them must be noticed (the engine
+    would silently fall back to measuring every launch at start-up)."""
+    import ast
+    import json
+    import os
+
+    from vs_seg_amd import engine as E
+    from vs_seg_amd import planner as P
+
+    data = json.load(open(E.TUNED_DEFAULTS))
+    ig = {k: v for k, v in data.items() if not k.startswith("wgrad|")}
+    assert len(ig) > 150 and sum(1 for k in data if k.startswith("wgrad|")) >= 40
+    checked = hits = 0
+    for key, choice in list(ig.items())[::5]:
+        parts = key.split("|")
+        kind, fold = parts[0], int(parts[1][1:])
+        wshape = ast.literal_eval(parts[2][1:])
+        is_, os_, oo = (ast.literal_eval(t) for t in re.findall(r"\([^)]*\)", parts[3]))
+        q = ast.literal_eval(parts[4][1:])
+        es, kc = int(parts[6][2:]), int(parts[7][2:])
+        acc, res, two = int(parts[8][3:]), int(parts[9][3:]), parts[11][3:]
+        kernel = tuple(wshape[2:])
+        cls = next((c for s in ((1, 1, 1), (2, 2, 1), (2, 2, 2)) for c in P.lattice_classes(kind, kernel, s) if (c.is_, c.os, c.oo) == (is_, os_, oo)), None)
+        assert cls is not None, key
+        aux_es = es if (acc or res) else 0
+        if fold:
+            cands = P.folded_candidate_plans(kind, wshape, cls, (q[0], q[1], q[2] * fold), es, aux_es=aux_es)
+        else:
+            cands = P.candidate_plans(kind, wshape, cls, q, es, kc_pad=kc, aux_es=aux_es, in_split=kc // 2 if two[0] == "1" else 0)
+        checked += 1
+        want = choice if len(choice) > 4 else choice + [1]
+        hits += any([list(c.tile), c.nt, c.nsplit, c.ck, c.depth] == want for c in cands)
+    assert checked >= 30 and hits >= 0.9 * checked, (hits, checked)
