@@ -198,6 +198,14 @@ int vsseg_crop_flip(const void* jobs, int32_t njobs, float* dst, const int32_t r
  * division).  acc2 = 2 doubles of device scratch (sum, sum of squares; left filled for inspection). */
 int vsseg_normalize_intensity(const float* x, float* y, int64_t n, double* acc2, void* stream);
 
+/* Convolution of a ONE-channel tensor as a direct stencil (first encoder block with in_channels = 1: model.0.conv.unit0 3x3x1,
+ * model.0.residual 1x1x1; ref:params/networks/blocks/convolutions.py:114-146, 241-250): v = bias[c] + sum_t w[c][t]*x1[voxel+off_t],
+ * zero padding.  stats != NULL: out = v and per-channel sum / sum-of-squares of v are added to the sharded statistics (training
+ * BatchNorm, same layout as vsseg_igemm_desc.stats).  Otherwise out = act(v*scale[c] + shift[c]) with scale/shift optional (eval
+ * BatchNorm folded) and PReLU when alpha != NULL.  x1: [n][X][Y][Z] in `dtype`; w: [out.c][kx*ky] fp32 (the torch weight, flat). */
+int vsseg_conv1ch_fwd(const void* x1, int32_t dtype, int32_t n, const int32_t dims[3], const float* w, const float* bias, const int32_t kernel[3],
+                      const float* scale, const float* shift, const float* alpha, vsseg_tensor out, double* stats, int32_t stats_stride, void* stream);
+
 /* Sliding-window blend (MONAI sliding_window_inference steps 6-7; call site ref:params/VSparams.py:568-574). */
 int vsseg_swi_accumulate(const float* seg /* [rx][ry][rz][c] */, const float* imap /* [rx][ry][rz] */, const int32_t roi[3], const int32_t start[3], int32_t c,
                          float* out /* [PX][PY][PZ][c] */, float* cnt /* [PX][PY][PZ] */, const int32_t pdims[3], void* stream);

@@ -110,6 +110,7 @@ class _ConvPlans:
     wgrad: Optional[P.WgradPlan]
     fold_fwd: bool = False
     fold_dgrad: bool = False
+    direct_fwd: bool = False  # forward runs as the direct 1-channel stencil (vsseg_conv1ch_fwd), not as an igemm launch
 
 
 class _Slot:
@@ -261,7 +262,9 @@ class Plan:
                     fold_dgrad = wide_n and can_fold and Lr.cout == 1 and getattr(op, "act", "") == "sigmoid"  # dY of the sigmoid convolution is written compactly by att_apply_bwd
                     dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed, fold=fold_dgrad)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
-            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd, fold_dgrad)
+            direct = (eng.direct1 and not fold_fwd and absorbed is None and op.res is None and not Lr.transposed and Lr.cin == 1 and Lr.cout % 8 == 0 and Lr.kernel in ((3, 3, 1), (1, 1, 1))
+                      and tuple(Lr.stride) == (1, 1, 1) and dims_in[2] % 4 == 0 and op.x.root.name == eng.prog.input.name and op.out.base is None and getattr(op, "act", "none") == "none")
+            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd, fold_dgrad, direct)
 
     def _register(self, ch: _Choice, pl: P.IgemmPlan):
         """Append the chosen plan's weight gather map(s) to the step's pack list."""
@@ -425,7 +428,19 @@ class Plan:
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
-                if self.train:
+                if cp.direct_fwd:  # one-channel network input: direct stencil instead of an MFMA launch on a zero-extended K-group
+                    x1 = self._xdesc(op.x, True)
+                    dt = L.BF16 if eng.es == 2 else L.F32
+                    if self.train:
+                        yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
+                        F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None, yd, sptr(0, pre), cpad[pre]]])
+                        F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
+                                                          self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out]])
+                    else:
+                        self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
+                        F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), vptr(2, pre), vptr(3, pre), alp, out, None, 0]])
+                elif self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
                     for ch in cp.fwd:
                         self._igemm(F, ch, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
@@ -446,6 +461,11 @@ class Plan:
                 if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
+                if cp.direct_fwd:
+                    x1 = self._xdesc(op.x, True)
+                    F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, L.BF16 if eng.es == 2 else L.F32, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None,
+                                                      self._desc(op.out), None, 0]])
+                    continue
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for ch in cp.fwd:
@@ -455,7 +475,8 @@ class Plan:
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
-        if any((not self.cplans[op.layer.prefix].fold_fwd) and op.layer.prefix not in self.merged and op.x.root.name == prog.input.name for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
+        if any((not self.cplans[op.layer.prefix].fold_fwd) and (not self.cplans[op.layer.prefix].direct_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
+               and op.x.root.name == prog.input.name for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
             self.needs_padded_input = True
         self.out_logits = self._alloc(prog.logits, self.bufs)
         self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
@@ -690,6 +711,7 @@ class Engine:
         self.dry_run = dry_run
         self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
         self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
+        self.direct1 = os.environ.get("VSSEG_DIRECT1", "1") != "0"  # 1-channel-input convolutions as a direct stencil (vsseg_conv1ch_fwd)
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.attention, self.hp = attention, hp
