@@ -75,70 +75,77 @@ extern "C" int vsseg_normalize_intensity(const float* x, float* y, int64_t n, do
 //   STATS: per-channel sum / sum of squares of v into the sharded fp64 statistics (training BatchNorm), out = v
 //   else : out = act(v * scale[c] + shift[c])               (eval: BatchNorm folded; PReLU when alpha != NULL)
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, bool STATS>
-__global__ void conv1ch_fwd_kernel(const T* __restrict__ x, int N, int X, int Y, int Z, const float* __restrict__ w, const float* __restrict__ bias, int kx, int ky,
-                                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ alpha_p, T* __restrict__ out, int op, int cgs,
-                                   double* __restrict__ stats, int stats_stride) {
+template <typename T, bool STATS, int TAPS>
+__global__ __launch_bounds__(256, 3) void conv1ch_fwd_kernel(const T* __restrict__ x, int N, int X, int Y, int Z, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ alpha_p, T* __restrict__ out, int op, int cgs,
+                                                             double* __restrict__ stats, int stats_stride) {
+  // thread = (4 z-consecutive voxels, 4 output channels): 36 weights + 16 accumulators in registers (8 channels per thread needed
+  // ~230 VGPRs); TAPS = 9 (3x3x1) or 1 (1x1x1) is a compile-time constant so that the weight array is never indexed dynamically
   extern __shared__ float red[];  // STATS: [2][C]
-  const int C = cgs * 8, taps = kx * ky;
+  const int C = cgs * 4;
   if (STATS) {
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
     __syncthreads();
   }
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
-  const int cg = (int)(gt % cgs), c = cg * 8;
-  float wr[8][9], b8[8], sc[8], sh[8];
+  const int cg = (int)(gt % cgs), c = cg * 4;
+  float wr[4][TAPS], b4[4], sc[4], sh[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[j][t] = t < taps ? w[(c + j) * taps + t] : 0.f;
-    b8[j] = bias ? bias[c + j] : 0.f;
+    for (int t = 0; t < TAPS; ++t) wr[j][t] = w[(c + j) * TAPS + t];
+    b4[j] = bias ? bias[c + j] : 0.f;
     sc[j] = scale ? scale[c + j] : 1.f;
     sh[j] = scale ? shift[c + j] : 0.f;
   }
   const bool prelu = alpha_p != nullptr;
   const float alpha = prelu ? *alpha_p : 1.f;
-  const int Z4 = Z >> 2, px = kx / 2, py = ky / 2;
+  const int Z4 = Z >> 2;
   const int64_t nquads = (int64_t)N * X * Y * Z4;
-  float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   for (int64_t q = gt / cgs; q < nquads; q += nthreads / cgs) {
     int64_t r = q;
     const int z4 = (int)(r % Z4); r /= Z4;
     const int y = (int)(r % Y); r /= Y;
     const int xx = (int)(r % X);
     const int n = (int)(r / X);
-    float xin[9][4];
+    float acc[4][4];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dx = t / 3 - 1, dy = t % 3 - 1;  // 3x3 layout; a 1x1 kernel uses t == 0 only (handled below)
-      const int gx = taps == 1 ? xx : xx + dx, gy = taps == 1 ? y : y + dy;
-      const bool ok = t < taps && (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = b4[j];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int dx = t / 3 - 1, dy = t % 3 - 1;  // 3x3 layout; a 1x1 kernel has its only tap at the centre
+      const int gx = TAPS == 1 ? xx : xx + dx, gy = TAPS == 1 ? y : y + dy;
       float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v4 = ld4(x + (((int64_t)n * X + gx) * Y + gy) * Z + z4 * 4);
-      xin[t][0] = v4.x; xin[t][1] = v4.y; xin[t][2] = v4.z; xin[t][3] = v4.w;
+      if ((unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y) v4 = ld4(x + (((int64_t)n * X + gx) * Y + gy) * Z + z4 * 4);
+      const float xv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += wr[j][t] * xv[i];
     }
     const int64_t v0 = (((int64_t)n * X + xx) * Y + y) * Z + z4 * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      f8 o;
+      float o[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float a = b8[j];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) a += wr[j][t] * xin[t][i];
+      for (int j = 0; j < 4; ++j) {
+        float a = acc[i][j];
         if (STATS) { s1[j] += a; s2[j] += a * a; }
         else {
           a = a * sc[j] + sh[j];
           if (prelu) a = a > 0.f ? a : alpha * a;
         }
-        o.v[j] = a;
+        o[j] = a;
       }
-      st8(out + (v0 + i) * op + c, o);
+      st4(out + (v0 + i) * op + c, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
   if (STATS) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); }
+    for (int j = 0; j < 4; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); }
     __syncthreads();
     double* st = stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * stats_stride;
     for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&st[(i / C) * stats_stride + (i % C)], (double)red[i]);
@@ -155,18 +162,21 @@ extern "C" int vsseg_conv1ch_fwd(const void* x1, int32_t dtype, int32_t n, const
               "vsseg_conv1ch_fwd: bad arguments");
   VSSEG_CHECK(kernel[2] == 1 && ((kernel[0] == 3 && kernel[1] == 3) || (kernel[0] == 1 && kernel[1] == 1)) && dims[2] % 4 == 0, "vsseg_conv1ch_fwd: kernel must be 3x3x1 or 1x1x1 and Z a multiple of 4");
   VSSEG_CHECK(!stats || (!scale && !alpha && stats_stride >= out.c), "vsseg_conv1ch_fwd: statistics mode takes no affine / activation");
-  const int cgs = out.c / 8, blk = conv1ch_block(cgs);
+  const int cgs = out.c / 4, blk = conv1ch_block(cgs);  // 4 output channels per thread
   VSSEG_CHECK(blk > 0, "vsseg_conv1ch_fwd: unsupported channel count %d", out.c);
   const int64_t work = (int64_t)n * dims[0] * dims[1] * (dims[2] / 4) * cgs;
-  dim3 g(grid_for(work, blk, 256 * 8)), b(blk);
+  dim3 g(grid_for(work, blk, 256 * 16)), b(blk);
   hipStream_t s = as_stream(stream);
-  if (dtype == VSSEG_F32) {
-    if (stats) hipLaunchKernelGGL((conv1ch_fwd_kernel<float, true>), g, b, 2 * out.c * sizeof(float), s, (const float*)x1, n, dims[0], dims[1], dims[2], w, bias, kernel[0], kernel[1], scale, shift, alpha, (float*)out.ptr, out.pitch, cgs, stats, stats_stride);
-    else hipLaunchKernelGGL((conv1ch_fwd_kernel<float, false>), g, b, 0, s, (const float*)x1, n, dims[0], dims[1], dims[2], w, bias, kernel[0], kernel[1], scale, shift, alpha, (float*)out.ptr, out.pitch, cgs, stats, stats_stride);
-  } else {
-    if (stats) hipLaunchKernelGGL((conv1ch_fwd_kernel<bf16_t, true>), g, b, 2 * out.c * sizeof(float), s, (const bf16_t*)x1, n, dims[0], dims[1], dims[2], w, bias, kernel[0], kernel[1], scale, shift, alpha, (bf16_t*)out.ptr, out.pitch, cgs, stats, stats_stride);
-    else hipLaunchKernelGGL((conv1ch_fwd_kernel<bf16_t, false>), g, b, 0, s, (const bf16_t*)x1, n, dims[0], dims[1], dims[2], w, bias, kernel[0], kernel[1], scale, shift, alpha, (bf16_t*)out.ptr, out.pitch, cgs, stats, stats_stride);
+#define VSSEG_C1_LAUNCH(TP) \
+  if (dtype == VSSEG_F32) { \
+    if (stats) hipLaunchKernelGGL((conv1ch_fwd_kernel<float, true, TP>), g, b, 2 * out.c * sizeof(float), s, (const float*)x1, n, dims[0], dims[1], dims[2], w, bias, scale, shift, alpha, (float*)out.ptr, out.pitch, cgs, stats, stats_stride); \
+    else hipLaunchKernelGGL((conv1ch_fwd_kernel<float, false, TP>), g, b, 0, s, (const float*)x1, n, dims[0], dims[1], dims[2], w, bias, scale, shift, alpha, (float*)out.ptr, out.pitch, cgs, stats, stats_stride); \
+  } else { \
+    if (stats) hipLaunchKernelGGL((conv1ch_fwd_kernel<bf16_t, true, TP>), g, b, 2 * out.c * sizeof(float), s, (const bf16_t*)x1, n, dims[0], dims[1], dims[2], w, bias, scale, shift, alpha, (bf16_t*)out.ptr, out.pitch, cgs, stats, stats_stride); \
+    else hipLaunchKernelGGL((conv1ch_fwd_kernel<bf16_t, false, TP>), g, b, 0, s, (const bf16_t*)x1, n, dims[0], dims[1], dims[2], w, bias, scale, shift, alpha, (bf16_t*)out.ptr, out.pitch, cgs, stats, stats_stride); \
   }
+  if (kernel[0] == 3) { VSSEG_C1_LAUNCH(9) } else { VSSEG_C1_LAUNCH(1) }
+#undef VSSEG_C1_LAUNCH
   VSSEG_LAUNCH_CHECK("vsseg_conv1ch_fwd");
   return VSSEG_OK;
 }

@@ -711,7 +711,9 @@ class Engine:
         self.dry_run = dry_run
         self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
         self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
-        self.direct1 = os.environ.get("VSSEG_DIRECT1", "1") != "0"  # 1-channel-input convolutions as a direct stencil (vsseg_conv1ch_fwd)
+        # 1-channel-input convolutions as a direct VALU stencil (vsseg_conv1ch_fwd).  Off by default: measured 0.58 ms against 0.46 ms for the
+        # zero-extended MFMA launch on the full-resolution 1->16 3x3x1 layer (the stencil is issue-bound at ~16 % VALU utilisation).
+        self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.attention, self.hp = attention, hp
