@@ -103,12 +103,14 @@ __global__ __launch_bounds__(256, 3) void conv1ch_fwd_kernel(const T* __restrict
   const int Z4 = Z >> 2;
   const int64_t nquads = (int64_t)N * X * Y * Z4;
   float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  for (int64_t q = gt / cgs; q < nquads; q += nthreads / cgs) {
-    int64_t r = q;
-    const int z4 = (int)(r % Z4); r /= Z4;
-    const int y = (int)(r % Y); r /= Y;
-    const int xx = (int)(r % X);
-    const int n = (int)(r / X);
+  // 32-bit index arithmetic (the host checks that the quad count fits): six 64-bit divisions per iteration cost more than the stencil
+  const unsigned qstep = (unsigned)(nthreads / cgs);
+  for (unsigned q = (unsigned)(gt / cgs); q < (unsigned)nquads; q += qstep) {
+    unsigned r = q;
+    const int z4 = (int)(r % (unsigned)Z4); r /= (unsigned)Z4;
+    const int y = (int)(r % (unsigned)Y); r /= (unsigned)Y;
+    const int xx = (int)(r % (unsigned)X);
+    const int n = (int)(r / (unsigned)X);
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -163,6 +165,7 @@ extern "C" int vsseg_conv1ch_fwd(const void* x1, int32_t dtype, int32_t n, const
   VSSEG_CHECK(kernel[2] == 1 && ((kernel[0] == 3 && kernel[1] == 3) || (kernel[0] == 1 && kernel[1] == 1)) && dims[2] % 4 == 0, "vsseg_conv1ch_fwd: kernel must be 3x3x1 or 1x1x1 and Z a multiple of 4");
   VSSEG_CHECK(!stats || (!scale && !alpha && stats_stride >= out.c), "vsseg_conv1ch_fwd: statistics mode takes no affine / activation");
   const int cgs = out.c / 4, blk = conv1ch_block(cgs);  // 4 output channels per thread
+  VSSEG_CHECK((int64_t)n * dims[0] * dims[1] * (dims[2] / 4) < (1ll << 31) - (1ll << 24), "vsseg_conv1ch_fwd: tensor too large for 32-bit voxel indices");
   VSSEG_CHECK(blk > 0, "vsseg_conv1ch_fwd: unsupported channel count %d", out.c);
   const int64_t work = (int64_t)n * dims[0] * dims[1] * (dims[2] / 4) * cgs;
   dim3 g(grid_for(work, blk, 256 * 16)), b(blk);
