@@ -23,6 +23,7 @@ train_transforms, val_transforms, test_transforms = p.get_transforms()
 random.seed(0)
 np.random.seed(0)
 torch.manual_seed(0)
+p.check_transforms_on_first_validation_image_and_label(val_files, val_transforms)
 train_loader = p.cache_transformed_train_data(train_files, train_transforms)
 val_loader = p.cache_transformed_val_data(val_files, val_transforms)
 model = p.set_and_get_model()

@@ -168,6 +168,8 @@ int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, con
                         void* dpre1 /* optional compact [N,X,Y,Z] copy of channel 0 of dpre (x's dtype), or NULL */, void* stream);
 
 /* generic helpers */
+int vsseg_memset_zero(void* dst, int64_t bytes, void* stream);                    /* hipMemsetAsync(dst, 0, bytes) on the caller's stream */
+int vsseg_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream);    /* device-to-device hipMemcpyAsync */
 int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);
 int vsseg_add_inplace(vsseg_tensor dst, vsseg_tensor src, void* stream); /* dst += src */
 int vsseg_copy_cast(vsseg_tensor src, vsseg_tensor dst, void* stream);

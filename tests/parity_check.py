@@ -1,0 +1,79 @@
+"""Parity of the BENCHMARKED configuration (bf16, 384x128x128, tuned launch plans) against the reference's own golden.
+
+Used by `tests/test_gpu_benchmark_parity.py` and by `bench.py` (its `parity` field is computed before the timed region with
+exactly the launch plans the timed steps run).  Only fixtures under tests/golden/ are read — nothing under oracle/ and nothing
+under /root/reference (the goldens were produced there by tests/golden/make_goldens.py).
+
+Why a batch of 4 can be checked against a batch-1 golden: the golden input is replicated over the batch.  Training-mode
+BatchNorm statistics of B identical samples equal those of one sample, every per-sample output is therefore the batch-1
+output, the loss (a mean over samples) is unchanged, and so is every parameter gradient (B identical contributions, each
+scaled 1/B by the mean).
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict
+
+import numpy as np
+import torch
+
+from tests.helpers import load, synth_input, synth_label
+
+# bars for the bf16 MFMA path (bf16 storage of every activation, fp32 accumulation) against the reference's fp32 CPU run
+BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.99, grad_rel_l2_median=0.15, grad_rel_l2_worst=0.6)
+
+
+def golden_train_case(name="net_train_b1_384x128x128.npz"):
+    g = load(name)
+    return g, int(g["seed"]), tuple(int(v) for v in g["shape"])
+
+
+def train_step_metrics(model, loss_fn, batch: int = 1, golden: str = "net_train_b1_384x128x128.npz") -> Dict[str, float]:
+    """One training-mode fwd + Dice_spvPA + bwd of `model` (already on the GPU, weights = the golden's seeded state dict,
+    dropout 0) on the golden input replicated `batch` times; returns the error metrics against the reference golden."""
+    g, seed, shape = golden_train_case(golden)
+    x = synth_input(seed, shape).repeat(batch, 1, 1, 1, 1).cuda()
+    y = synth_label(seed, shape).repeat(batch, 1, 1, 1, 1).cuda()
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    logits, atts = model(x)
+    loss = loss_fn((logits, atts), y)
+    loss.backward()
+    out: Dict[str, float] = {"loss": float(loss), "loss_ref": float(g["loss"]), "loss_abs": abs(float(loss) - float(g["loss"]))}
+    meta = json.loads(str(g["logits_meta"]))
+    worst_l, worst_a = 0.0, 0.0
+    for b in sorted({0, batch - 1}):  # first and last sample (all samples are the same computation)
+        got = logits[b : b + 1].detach().float().cpu().flatten()[:: meta["stride"]].numpy()
+        want = g["logits_sub"]
+        worst_l = max(worst_l, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
+        for i, a in enumerate(atts):
+            am = json.loads(str(g[f"att{i}_meta"]))
+            ga = a[b : b + 1].detach().float().cpu().flatten()[:: am["stride"]].numpy()
+            worst_a = max(worst_a, float(np.abs(ga - g[f"att{i}_sub"]).max()))
+    out["logits_rel_l2"], out["att_max_abs"] = worst_l, worst_a
+    sums = json.loads(str(g["grad_sums"]))
+    rels, gots, wants = [], [], []
+    for k, p in model.named_parameters():
+        if k.endswith("conv.bias") and k.replace("conv.bias", "norm.weight") in sums:
+            continue  # analytically zero (bias in front of a training-mode BatchNorm)
+        gk = p.grad.double().flatten().cpu()
+        sub = gk[:: max(1, gk.numel() // 64)][:64].numpy()
+        want = g["gsub:" + k].astype(np.float64)
+        rels.append((float(np.linalg.norm(sub - want) / (np.linalg.norm(want) + 1e-30)), k))
+        # every tensor enters the direction check with unit weight (gradient magnitudes span 6 orders across layers)
+        s = np.linalg.norm(want) + 1e-30
+        gots.append(sub / s)
+        wants.append(want / s)
+    gv, wv = np.concatenate(gots), np.concatenate(wants)
+    out["grad_cos"] = float((gv * wv).sum() / (np.linalg.norm(gv) * np.linalg.norm(wv)))
+    rr = sorted(r for r, _ in rels)
+    out["grad_rel_l2_median"] = rr[len(rr) // 2]
+    out["grad_rel_l2_worst"] = rr[-1]
+    out["grad_worst_tensor"] = max(rels)[1]
+    return out
+
+
+def passes(m: Dict[str, float], bars=BARS) -> bool:
+    return (m["loss_abs"] <= bars["loss_abs"] and m["logits_rel_l2"] <= bars["logits_rel_l2"] and m["att_max_abs"] <= bars["att_max_abs"] and m["grad_cos"] >= bars["grad_cos"]
+            and m["grad_rel_l2_median"] <= bars["grad_rel_l2_median"] and m["grad_rel_l2_worst"] <= bars["grad_rel_l2_worst"])

@@ -143,8 +143,9 @@ def test_epoch_batches_shard_and_cover():
     assert sorted(i for b in e0 for i in b) == list(range(11)) and [len(b) for b in e0] == [4, 4, 3]
     r0 = T.epoch_batches(11, 2, True, np.random.RandomState(5), 0, 2)
     r1 = T.epoch_batches(11, 2, True, np.random.RandomState(5), 1, 2)
-    assert sorted(i for b in r0 + r1 for i in b) == list(range(11))
-    assert not set(i for b in r0 for i in b) & set(i for b in r1 for i in b)
+    # 11 cases over 2 ranks: padded to 12 by wrapping around (both ranks run the same number of steps), every case covered
+    assert sorted(set(i for b in r0 + r1 for i in b)) == list(range(11)) and sum(len(b) for b in r0) == sum(len(b) for b in r1) == 6
+    assert len(set(i for b in r0 for i in b) & set(i for b in r1 for i in b)) <= 1
     assert T.epoch_batches(5, 1, False, rng) == [[0], [1], [2], [3], [4]]
 
 
@@ -168,3 +169,61 @@ def test_checkpoint_normalisation(tmp_path):
     assert CK.normalise_state_dict(wrapped).keys() == sd.keys()
     with pytest.raises(ValueError):
         CK.normalise_state_dict({"epoch": 3})
+
+
+def test_epoch_batches_give_every_rank_the_same_number_of_steps():
+    """with n % world != 0 the ranks ran different numbers of training steps and paired mismatched collectives."""
+    from vs_seg_amd.data.transforms import epoch_batches
+
+    for n, world, bs in [(176, 8, 1), (10, 4, 1), (7, 2, 2), (5, 8, 1), (242, 8, 4), (3, 2, 1)]:
+        per_rank = [epoch_batches(n, bs, True, np.random.RandomState(0), r, world) for r in range(world)]
+        assert len({len(b) for b in per_rank}) == 1, (n, world, [len(b) for b in per_rank])
+        assert len({sum(len(x) for x in b) for b in per_rank}) == 1
+        seen = [i for b in per_rank for x in b for i in x]
+        assert set(seen) == set(range(n)) and len(seen) == -(-n // world) * world  # every case at least once, padded by wrap-around
+    # a single process is untouched: the reference's DataLoader order, nothing padded or dropped
+    one = epoch_batches(7, 2, False, np.random.RandomState(0))
+    assert one == [[0, 1], [2, 3], [4, 5], [6]]
+
+
+def test_seeded_weights_helper_equals_the_oracle_generator():
+    import torch
+
+    from oracle import vsseg_oracle as O
+    from tests.helpers import seeded_weights_for
+
+    ref = O.seeded_state_dict(True, 24)
+    got = seeded_weights_for({k: torch.empty(v.shape) for k, v in ref.items()}, 24)
+    assert list(got) == list(ref)
+    for k in ref:
+        assert torch.equal(got[k], ref[k]), k
+
+
+def test_split_files_ship_with_the_repo():
+    """ref:params/VSparams.py:72-75 defaults: ./params/split_TCIA.csv (242 cases) and ./params/split_debug.csv (6 cases)."""
+    import csv
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = list(csv.reader(open(os.path.join(root, "params", "split_TCIA.csv"))))
+    assert len(rows) == 242 and {r[1] for r in rows} == {"training", "validation", "test"}
+    assert [sum(1 for r in rows if r[1] == s) for s in ("training", "validation", "test")] == [176, 20, 46]
+    dbg = list(csv.reader(open(os.path.join(root, "params", "split_debug.csv"))))
+    assert [r[1] for r in dbg] == ["training", "training", "validation", "validation", "test", "test"]
+
+
+def test_make_debug_data_writes_readable_cases(tmp_path):
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import make_debug_data as M
+    from vs_seg_amd.data import nifti
+
+    M.main(["--data_root", str(tmp_path), "--size", "24", "20", "16"])
+    d = os.path.join(str(tmp_path), "input_data", "vs_gk_182")
+    img, aff, _ = nifti.read_nifti(os.path.join(d, "vs_gk_t1_refT1.nii.gz"))
+    lab, _, _ = nifti.read_nifti(os.path.join(d, "vs_gk_seg_refT1.nii.gz"))
+    assert img.shape == lab.shape == (24, 20, 16) and 0 < lab.sum() < lab.size and aff[0, 0] < 0
+    assert len(os.listdir(os.path.join(str(tmp_path), "input_data"))) == 6

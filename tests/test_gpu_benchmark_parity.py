@@ -1,0 +1,130 @@
+"""-m gpu: parity of what bench.py actually times — bf16, 384x128x128, batch 4, the shipped tuned launch plans, dropout —
+and of BASELINE config 3 at its full size (512x512x120 sliding-window volume + hard Dice).
+
+The other GPU tests run the deterministic heuristic plans (tests/conftest.py sets VSSEG_AUTOTUNE=0); the tests here switch
+the autotuner's plan cache on, so they execute the same kernels / tilings / no-prefetch variants the benchmark does.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import vs_seg_amd as V  # noqa: E402
+from oracle import vsseg_oracle as O  # noqa: E402
+from tests import parity_check as PC  # noqa: E402
+from tests.helpers import check_summary, load, synth_input, synth_label  # noqa: E402
+
+HP = O.HP
+
+
+def make_model(dtype, seed, dropout=0.0, att=True, torch_seed=None):
+    torch.manual_seed(1000 + seed if torch_seed is None else torch_seed)
+    m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, channels=HP["channels"], strides=HP["strides"], kernel_sizes=HP["kernel_sizes"], sample_kernel_sizes=HP["sample_kernel_sizes"],
+                        num_res_units=2, norm="batch", dropout=dropout, attention_module=att, compute_dtype=dtype)
+    m.load_state_dict(O.seeded_state_dict(att, seed))
+    return m.to("cuda")
+
+
+def _plan_sources(model):
+    plan = next(p for k, p in model._engine.plans.items() if k[2])
+    chs = [c for cp in plan.cplans.values() for c in cp.fwd + cp.dgrad if c.chosen is not None]
+    return plan, chs
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_bf16_train_step_tuned_plans_at_benchmark_size_vs_reference_golden(batch, monkeypatch):
+    """bf16 training step at 384x128x128 with the autotuner's plans (batch 4 = exactly the plans of vs_seg_amd/tuned_gfx950.json the
+    benchmark runs; the golden's input is replicated over the batch, see tests/parity_check.py) against the reference's own
+    fwd + Dice_spvPA + bwd golden: loss, logits, attention maps, every parameter gradient."""
+    monkeypatch.setenv("VSSEG_AUTOTUNE", "1")
+    g, seed, shape = PC.golden_train_case()
+    m = make_model("bf16", seed)
+    loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
+    met = PC.train_step_metrics(m, loss_fn, batch=batch)
+    print("bf16 benchmark-size parity", batch, json.dumps(met))
+    plan, chs = _plan_sources(m)
+    assert plan.tune, "the autotuned plans were not enabled"
+    if batch == 4:  # the benchmark's signature: every igemm launch must come from the shipped plan file, nothing measured here
+        assert all(c.cached for c in chs if len(c.cands) > 1), "a batch-4 benchmark launch is missing from vs_seg_amd/tuned_gfx950.json"
+        assert any(c.chosen.depth == -1 for c in chs) and any(c.chosen is not c.cands[0] for c in chs)
+    assert PC.passes(met), met
+
+
+def test_bf16_batch4_dropout_matches_fp32_path_with_same_masks(monkeypatch):
+    """SELF-comparison (HIP bf16 vs HIP fp32, not a reference parity claim): batch 4 of distinct samples, dropout 0.1, tuned plans
+    for bf16.  Both models derive their Philox keep-masks from (seed base, step, layer, element index) only, so they drop the
+    same elements; the fp32 path is the one pinned to the reference at this size by test_gpu_network.py."""
+    seed, shape = 83, (4, 1, 384, 128, 128)
+    x, y = synth_input(seed, shape).cuda(), synth_label(seed, shape).cuda()
+    res = {}
+    for dtype, tune in (("fp32", "0"), ("bf16", "1")):
+        monkeypatch.setenv("VSSEG_AUTOTUNE", tune)
+        m = make_model(dtype, seed, dropout=0.1, torch_seed=4242).train()
+        loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
+        logits, atts = m(x)
+        loss = loss_fn((logits, atts), y)
+        loss.backward()
+        mask0 = m.dropout_masks()["model.0.conv.unit0"]
+        assert 0.88 < float(mask0.mean()) < 0.92
+        sub = logits.detach().float().flatten()[::4099].cpu().double()
+        grads = {k: p.grad.detach().double().flatten().cpu() for k, p in m.named_parameters()}
+        res[dtype] = (float(loss), sub, grads, mask0.flatten()[::8191].cpu())
+        del m, logits, atts, loss, mask0
+        torch.cuda.empty_cache()
+    assert torch.equal(res["fp32"][3], res["bf16"][3]), "the two compute modes drew different dropout masks"
+    assert abs(res["fp32"][0] - res["bf16"][0]) < 2e-2, (res["fp32"][0], res["bf16"][0])
+    rel = float((res["bf16"][1] - res["fp32"][1]).norm() / res["fp32"][1].norm())
+    assert rel < 3e-2, rel
+    gf = torch.cat([g / (res["fp32"][2][k].norm() + 1e-30) for k, g in res["bf16"][2].items()])
+    g0 = torch.cat([g / (g.norm() + 1e-30) for k, g in res["fp32"][2].items()])
+    cos = float((gf * g0).sum() / (gf.norm() * g0.norm()))
+    print("bf16 vs fp32 with dropout: loss", res["fp32"][0], res["bf16"][0], "logits rel", rel, "grad cos", cos)
+    assert cos > 0.99, cos
+
+
+def _blob(shape, centre, radius):
+    X, Y, Z = shape
+    gx, gy, gz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
+    m = ((gx - centre[0]) / radius[0]) ** 2 + ((gy - centre[1]) / radius[1]) ** 2 + ((gz - centre[2]) / radius[2]) ** 2 <= 1.0
+    return torch.from_numpy(m.astype(np.float32))[None, None]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_c3_full_size_sliding_window_and_dice_vs_reference_golden(dtype, monkeypatch):
+    """BASELINE config 3 end to end at its own size: one 512x512x120 volume, roi 384x128x128, overlap 0.5, 14 windows through the
+    network, Gaussian blend, hard Dice — against the fixture made of the REFERENCE network per window + the oracle's blend
+    (tests/golden/make_c3_golden.py).  fp32: blended logits within 1e-3, Dice within 1e-3 (north_star).  bf16 (benchmark mode,
+    tuned plans): Dice within 1e-2, logits by relative L2."""
+    monkeypatch.setenv("VSSEG_AUTOTUNE", "1" if dtype == "bf16" else "0")
+    g = load("c3_swi_512x512x120.npz")
+    seed, shape, roi = int(g["seed"]), tuple(int(v) for v in g["shape"]), tuple(int(v) for v in g["roi"])
+    m = make_model(dtype, seed).eval()
+    x = synth_input(seed, shape).cuda()
+    with torch.no_grad():
+        out = V.sliding_window_inference(x, roi, 1, lambda w: m(w)[0], overlap=float(g["overlap"]), mode="gaussian")
+    assert tuple(out.shape) == (1, 2, *shape[2:])
+    label = _blob(shape[2:], [int(v) for v in g["label_centre"]], [int(v) for v in g["label_radius"]]).cuda()
+    dice = float(V.compute_dice_score(out, label))
+    meta = json.loads(str(g["out_meta"]))
+    got = out.float().cpu().flatten()[:: meta["stride"]].numpy()
+    rel = float(np.linalg.norm(got - g["out_sub"]) / np.linalg.norm(g["out_sub"]))
+    print(f"C3 {dtype}: dice {dice:.6f} (reference {float(g['dice']):.6f}), blended logits rel-L2 {rel:.2e}, max abs {float(np.abs(got - g['out_sub']).max()):.2e}")
+    if dtype == "fp32":
+        check_summary(out.float().cpu(), g["out_meta"], g["out_sub"], atol=1e-3)
+        assert abs(dice - float(g["dice"])) < 1e-3
+    else:
+        assert rel < 3e-2, rel
+        assert abs(dice - float(g["dice"])) < 1e-2
+
+
+def test_hard_dice_matches_reference_golden():
+    g = load("hard_dice.npz")
+    names = sorted({k.split(":")[0] for k in g.files})
+    assert len(names) >= 6
+    for n in names:
+        got = V.compute_dice_score(torch.from_numpy(g[n + ":p"]).cuda(), torch.from_numpy(g[n + ":label"]).cuda())
+        assert tuple(got.shape) == (1, 1)
+        assert abs(float(got) - float(g[n + ":dice"])) < 1e-6, (n, float(got), float(g[n + ":dice"]))

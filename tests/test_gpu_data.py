@@ -173,3 +173,47 @@ def test_vsparams_train_validate_infer_export_end_to_end(tmp_path):
         o = sliding_window_inference(data["image"], p.sliding_window_inferer_roi_size, 1, lambda x: model2(x)[0], mode="gaussian")
     want_seg = nifti.from_ras(torch.argmax(o, 1)[0].cpu().numpy().astype(np.uint8), data["label_meta_dict"]["ornt"])
     np.testing.assert_array_equal(seg, want_seg.astype(np.float32))
+
+
+def test_vs_train_debug_script_runs_end_to_end(tmp_path):
+    """BASELINE config 1 plumbing: `VS_train.py --debug` then `VS_inference.py --debug` as the user runs them, on the six synthetic
+    64^3 cases of params/split_debug.csv written by tools/make_debug_data.py (cwd = a scratch copy of the layout the scripts expect)."""
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    work = str(tmp_path)
+    os.makedirs(os.path.join(work, "params"))
+    for f in ("split_debug.csv", "split_TCIA.csv"):
+        shutil.copy(os.path.join(root, "params", f), os.path.join(work, "params", f))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), VSSEG_AUTOTUNE="0")
+    run = lambda *a: subprocess.run([sys.executable, *a], cwd=work, env=env, capture_output=True, text=True, timeout=900)  # noqa: E731
+    r = run(os.path.join(root, "tools", "make_debug_data.py"), "--data_root", "./data/VS_defaced/")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = run(os.path.join(root, "VS_train.py"), "--debug", "--num_epochs", "2", "--compute_dtype", "fp32")
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = open(os.path.join(work, "data/VS_defaced/results/debug/logs/training_log.txt")).read()
+    assert "Check the transforms on the first validation set image and label" in log and "Validation image shape = torch.Size([128, 128, 32])" in log
+    assert "epoch 2 average loss" in log and "current epoch 2 current mean dice" in log and "Train completed" in log
+    assert os.path.isfile(os.path.join(work, "data/VS_defaced/results/debug/model/best_metric_model.pth"))
+    r = run(os.path.join(root, "VS_inference.py"), "--debug", "--compute_dtype", "fp32")
+    assert r.returncode == 0, r.stderr[-3000:]
+    tlog = open(os.path.join(work, "data/VS_defaced/results/debug/logs/test_log.txt")).read()
+    assert "mean_dice_score" in tlog
+    segs = [f for _, _, fs in os.walk(os.path.join(work, "data/VS_defaced/results/debug/inferred_segmentations_nifti")) for f in fs]
+    assert len(segs) == 2
+
+
+def test_argmax_export_matches_torch_argmax_bit_exactly():
+    from vs_seg_amd.inferers import argmax_segmentation
+
+    torch.manual_seed(5)
+    out = torch.randn(2, 2, 40, 24, 12, device="cuda")
+    out[0, :, 3, 4, 5] = 0.25  # a tie: class 0, like torch.argmax
+    out[1, 1, 7] = out[1, 0, 7]
+    got = argmax_segmentation(out)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (2, 40, 24, 12)
+    assert torch.equal(got, torch.argmax(out, dim=1).to(torch.uint8))
+    cl = out.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)  # the network's channels-last logits view
+    assert torch.equal(argmax_segmentation(cl), got)

@@ -169,3 +169,15 @@ def test_adam():
     for step, gr in enumerate(g["grads"], 1):
         p, m, v = O.adam_step(p, torch.from_numpy(gr), m, v, step)
         np.testing.assert_allclose(p.numpy(), g["after"][step - 1], atol=1e-7, rtol=1e-6)
+
+
+def test_hard_dice_matches_reference_golden():
+    """`compute_dice_score` (ref:params/VSparams.py:393-408) pinned by the reference's own DiceLoss class (tests/golden/make_c3_golden.py)."""
+    g = load("hard_dice.npz")
+    names = sorted({k.split(":")[0] for k in g.files})
+    assert {"perfect", "empty_label", "empty_pred", "both_empty"} <= set(names)
+    for n in names:
+        got = O.compute_dice_score(torch.from_numpy(g[n + ":p"]), torch.from_numpy(g[n + ":label"]))
+        assert tuple(got.shape) == (1, 1)
+        assert abs(float(got) - float(g[n + ":dice"])) < 1e-6, n
+    assert abs(float(g["perfect:dice"]) - 1.0) < 1e-6 and float(g["both_empty:dice"]) == 1.0

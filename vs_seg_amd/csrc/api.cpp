@@ -1,6 +1,7 @@
 // Error reporting and version of the C ABI (include/vsseg_hip.h).
 #include <stdarg.h>
 #include <stdio.h>
+#include <hip/hip_runtime.h>
 #include "../../include/vsseg_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -13,3 +14,20 @@ extern "C" void vsseg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* vsseg_last_error(void) { return g_err; }
 extern "C" int vsseg_version(void) { return 1; }
+
+// Zero-fill / device copy on the caller's stream (replace the torch fill / clone kernels the step used to issue: per-step
+// statistics, the flat gradient buffer, gradient slices that receive their first contribution as a partial write).
+extern "C" int vsseg_memset_zero(void* dst, int64_t bytes, void* stream) {
+  if (!dst || bytes < 0) { vsseg_set_error("vsseg_memset_zero: bad arguments"); return VSSEG_EINVAL; }
+  if (bytes == 0) return VSSEG_OK;
+  hipError_t e = hipMemsetAsync(dst, 0, (size_t)bytes, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { vsseg_set_error("vsseg_memset_zero: %s", hipGetErrorString(e)); return VSSEG_ELAUNCH; }
+  return VSSEG_OK;
+}
+extern "C" int vsseg_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream) {
+  if (!src || !dst || bytes < 0) { vsseg_set_error("vsseg_copy_bytes: bad arguments"); return VSSEG_EINVAL; }
+  if (bytes == 0) return VSSEG_OK;
+  hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { vsseg_set_error("vsseg_copy_bytes: %s", hipGetErrorString(e)); return VSSEG_ELAUNCH; }
+  return VSSEG_OK;
+}

@@ -140,7 +140,14 @@ class PatchSampler:
 
 def epoch_batches(n: int, batch_size: int, shuffle: bool, rng: np.random.RandomState, rank: int = 0, world: int = 1) -> List[List[int]]:
     """Index batches of one epoch: DataLoader(shuffle=True) order (ref:params/VSparams.py:311-318), sharded over ranks
-    (rank r takes positions r, r+world, … of the shuffled list — SURVEY §8e) and cut into batches (last one may be short)."""
+    (rank r takes positions r, r+world, … of the shuffled list — SURVEY §8e) and cut into batches (last one may be short).
+
+    Every rank gets the SAME number of indices, hence of batches: when n is not a multiple of `world` the list is padded by
+    wrapping around to its own beginning (torch's DistributedSampler(drop_last=False) rule).  Each training step issues a
+    gradient all-reduce and validation all-reduces its sums, so unequal step counts would pair mismatched collectives."""
     order = rng.permutation(n) if shuffle else np.arange(n)
+    if world > 1 and n % world and n > 0:
+        pad = world - n % world
+        order = np.concatenate([order, np.resize(order, pad)])
     mine = [int(i) for i in order[rank::world]]
     return [mine[i : i + batch_size] for i in range(0, len(mine), batch_size)]

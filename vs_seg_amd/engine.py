@@ -123,11 +123,6 @@ class _Slot:
 SEED = _Slot("seed")
 
 
-def _memset(buf, _stream):
-    buf.zero_()
-    return 0
-
-
 class Plan:
     def __init__(self, eng: "Engine", n: int, dims: Tuple[int, int, int], train: bool):
         self.eng, self.n, self.dims, self.train = eng, n, tuple(dims), train
@@ -143,6 +138,7 @@ class Plan:
         self.grads: Dict[str, torch.Tensor] = {}
         self.flat_ptr = eng.flat.data_ptr()
         self.timer = None  # set to {'only': set|None, 'events': []} to time launches with HIP events
+        self.generation = 0  # bumped by every training forward: a backward belongs to exactly one forward of this plan
         self._plan_layers()
         self._lower()
         self._index_slots()
@@ -505,7 +501,8 @@ class Plan:
                 return 1
             written[root] = True
             if spec.c != spec.root.c:  # first contribution covers only a channel slice: start from zero
-                B.append([_memset, [self._alloc(spec, self.grads)]])
+                gbuf = self._alloc(spec, self.grads)
+                B.append([lib.vsseg_memset_zero, [gbuf.data_ptr(), gbuf.numel() * gbuf.element_size()]])
                 return 1
             return 0
 
@@ -666,6 +663,11 @@ class Plan:
     def set_external_grads(self, glogits: L.Tensor, gatt: Dict[str, Optional[int]]):
         for args, i, slot in self.ext_slots:
             args[i] = glogits if slot.kind == "glogits" else gatt.get(slot.name)
+
+    def zero_stats(self, stream, row=None):
+        """Zero the sharded fp64 statistics (both rows before a training forward, the backward row before a backward)."""
+        t = self.stats if row is None else self.stats[row]
+        L.check(self.eng.lib.vsseg_memset_zero(t.data_ptr(), t.numel() * t.element_size(), stream), "memset_zero")
 
     def pack_weights(self, stream):
         m2 = self.pack_map2.data_ptr() if self.pack_map2 is not None else None

@@ -150,3 +150,15 @@ def compute_dice_score(predicted_probabilities: torch.Tensor, label: torch.Tenso
     for b in range(B):  # DiceLoss(reduction="mean") averages the per-sample scores (the reference always calls it with batch 1)
         L.check(lib.vsseg_hard_dice_counts(lg.data_ptr() + 8 * b * nv, 2, lab.data_ptr() + 4 * b * nv, nv, counts.data_ptr() + 24 * b, stream), "hard_dice_counts")
     return ((2.0 * counts[:, 0] + 1e-5) / (counts[:, 1] + counts[:, 2] + 1e-5)).mean().to(torch.float32).reshape(1, 1)
+
+
+def argmax_segmentation(outputs: torch.Tensor) -> torch.Tensor:
+    """uint8 [B,X,Y,Z] = argmax over the 2 class channels of [B,2,X,Y,Z] logits / probabilities (the export path of
+    ref:params/VSparams.py:582-594); ties go to class 0 like torch.argmax."""
+    if not outputs.is_cuda:
+        raise RuntimeError("vs_seg_amd.argmax_segmentation runs on an MI355X only; there is no CPU fallback")
+    lg = _as_cl(outputs)
+    assert lg.shape[-1] == 2
+    seg = torch.empty(lg.shape[:-1], dtype=torch.uint8, device=lg.device)
+    L.check(L.lib().vsseg_argmax2(lg.data_ptr(), 2, lg.numel() // 2, seg.data_ptr(), torch.cuda.current_stream().cuda_stream), "argmax2")
+    return seg

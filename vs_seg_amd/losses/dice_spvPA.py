@@ -46,8 +46,9 @@ class _DiceFn(torch.autograd.Function):
         lg, lab = _cl_logits(logits), _c1(target)
         nvox = X * Y * Z
         nl = len(atts) if supervised else 0
-        pred_sums = torch.zeros(B * 6, dtype=torch.float64, device=dev)
-        att_sums = torch.zeros(max(nl, 1) * B * 3, dtype=torch.float64, device=dev)
+        sums = torch.empty(B * 6 + max(nl, 1) * B * 3, dtype=torch.float64, device=dev)  # [pred | att levels], zeroed through the C ABI (no ATen fill kernels on the step)
+        L.check(lib.vsseg_memset_zero(sums.data_ptr(), sums.numel() * 8, stream), "memset_zero")
+        pred_sums, att_sums = sums[: B * 6], sums[B * 6 :]
         L.check(lib.vsseg_dice_pred_sums(lg.data_ptr(), 2, lab.data_ptr(), B, nvox, int(hardness), pred_sums.data_ptr(), stream), "dice_pred_sums")
         labels: List[torch.Tensor] = []
         amaps = []
@@ -68,8 +69,8 @@ class _DiceFn(torch.autograd.Function):
                 L.check(lib.vsseg_dice_att_sums(ac.data_ptr(), g.data_ptr(), B, adims[0] * adims[1] * adims[2], att_sums.data_ptr() + 8 * level * B * 3, stream), "dice_att_sums")
                 labels.append(g)
                 amaps.append(ac)
-        loss = torch.zeros((), dtype=torch.float32, device=dev)
-        coef = torch.zeros(B * 4 + max(nl, 1) * B * 2, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)  # vsseg_dice_finalize assigns the loss and every coefficient it is asked for
+        coef = torch.empty(B * 4 + max(nl, 1) * B * 2, dtype=torch.float32, device=dev)
         L.check(lib.vsseg_dice_finalize(pred_sums.data_ptr(), att_sums.data_ptr(), B, nl, loss.data_ptr(), coef.data_ptr(), stream), "dice_finalize")
         ctx.lg, ctx.lab, ctx.labels, ctx.coef, ctx.hardness, ctx.nl, ctx.shape = lg, lab, labels, coef, int(hardness), nl, (B, X, Y, Z)
         ctx.att_shapes = [tuple(a.shape) for a in atts]

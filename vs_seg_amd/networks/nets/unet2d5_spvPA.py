@@ -179,6 +179,12 @@ class UNet2d5_spvPA(nn.Module):
         self._mode_epoch = getattr(self, "_mode_epoch", 0) + 1  # entering eval re-validates the cached eval constants (covers writes through `.data`)
         return super().train(mode)
 
+    def decorrelate_dropout(self, rank: int):
+        """Data parallel: mix the rank into the Philox seed base so that ranks seeded identically draw different keep-masks."""
+        if rank and not getattr(self, "_seed_rank_mixed", False):
+            self._seed_base = (self._seed_base + 0x9E3779B1 * int(rank)) & 0xFFFFFFFF
+            self._seed_rank_mixed = True
+
     def invalidate_cache(self):
         """Force eval plans to re-pack weights / re-fold BatchNorm on their next forward (after out-of-band parameter writes)."""
         self._mode_epoch = getattr(self, "_mode_epoch", 0) + 1
@@ -212,7 +218,8 @@ class UNet2d5_spvPA(nn.Module):
             self._step += 1
             plan.step_seed = (self._seed_base << 32) | (self._step & 0xFFFFFFFF)
             plan.set_seed(plan.step_seed)
-            plan.stats.zero_()
+            plan.generation += 1
+            plan.zero_stats(stream)
             torch.autograd.graph.increment_version(self._bflat)  # bn_finalize updates the running statistics through raw pointers
         else:
             # eval: packed weights and folded BatchNorm constants depend on parameters / buffers only — the 14 windows of a
@@ -257,14 +264,19 @@ class UNet2d5_spvPA(nn.Module):
             gatt[spec.name] = g.data_ptr()
         plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt)
         plan.set_seed(plan.step_seed)
-        plan.stats[1].zero_()
+        plan.zero_stats(stream, 1)
+        lib, nbytes = eng.lib, self._gflat.numel() * 4
         accumulate = any(p.grad is not None for p in self._params.values())
-        if accumulate:
-            prev = self._gflat.clone()
-        self._gflat.zero_()
+        if accumulate:  # gradient accumulation (no zero_grad between two backwards): this backward's gradients are added to the previous sum
+            if getattr(self, "_gprev", None) is None or self._gprev.device != self._gflat.device:
+                self._gprev = torch.empty_like(self._gflat)
+            L.check(lib.vsseg_copy_bytes(self._gflat.data_ptr(), self._gprev.data_ptr(), nbytes, stream), "copy_bytes")
+        L.check(lib.vsseg_memset_zero(self._gflat.data_ptr(), nbytes, stream), "memset_zero")
         plan.run(plan.bwd, stream)
         if accumulate:
-            self._gflat.add_(prev)
+            n4 = self._gflat.numel() // 4  # every tensor is padded to 4 elements inside the flat buffer
+            flat_desc = lambda t: L.Tensor(t.data_ptr(), L.F32, 4, 4, 1, 1, 1, n4)  # noqa: E731
+            L.check(lib.vsseg_add_inplace(flat_desc(self._gflat), flat_desc(self._gprev), stream), "add_inplace")
         for key, (off, shape) in self._layout.param_off.items():
             p = self._params[key]
             if p.grad is None or p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
@@ -291,11 +303,16 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module: UNet2d5_spvPA, x, anchor):
         plan, outs = module._run_forward(x, True)
-        ctx.module, ctx.plan = module, plan
+        ctx.module, ctx.plan, ctx.generation = module, plan, plan.generation
         return outs
 
     @staticmethod
     def backward(ctx, g_logits, *g_atts):
+        if ctx.plan.generation != ctx.generation:
+            # activations, BatchNorm statistics and the dropout seed live in the shape-keyed plan: a later training forward of the
+            # same shape has overwritten what this graph's backward needs (the reference nn.Module has no such restriction)
+            raise RuntimeError("vs_seg_amd.UNet2d5_spvPA: backward of a forward pass whose activations were overwritten by a later training forward of the same "
+                               "shape; call backward() before the next forward (two live graphs of one shape are not supported)")
         ctx.module._run_backward(ctx.plan, g_logits, g_atts)
         return None, None, torch.zeros(1, device=ctx.module._flat.device)
 

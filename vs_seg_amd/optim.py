@@ -23,26 +23,35 @@ class Adam(torch.optim.Optimizer):
             if len(group["params"]) != len(owner._params):
                 raise ValueError("pass model.parameters() (all of them) to vs_seg_amd.optim.Adam")
             self._owners.append(owner)
-        self._state = [None] * len(self.param_groups)
         self.grad_scale = 1.0  # multiplied into the gradient inside the kernel (data-parallel mean without an extra pass)
+
+    def _flat_state(self, group, flat):
+        """m / v / step of one group live in `Optimizer.state` under the group's first parameter (flat tensors spanning the whole
+        parameter buffer), so `state_dict()` / `load_state_dict()` carry them like torch.optim.Adam's per-tensor moments."""
+        st = self.state[group["params"][0]]
+        m = st.get("exp_avg")
+        if m is None or m.numel() != flat.numel():
+            st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(flat), torch.zeros_like(flat)
+        elif m.device != flat.device or m.dtype != flat.dtype:  # the model moved (or a checkpoint was loaded on another device): keep the moments
+            st["exp_avg"], st["exp_avg_sq"] = m.to(flat), st["exp_avg_sq"].to(flat)
+        if torch.is_tensor(st["step"]):
+            st["step"] = int(st["step"])
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib = L.lib()
         stream = torch.cuda.current_stream().cuda_stream
-        for gi, (group, owner) in enumerate(zip(self.param_groups, self._owners)):
+        for group, owner in zip(self.param_groups, self._owners):
             flat, gflat = owner.flat_parameters()
-            st = self._state[gi]
-            if st is None or st["m"].device != flat.device or st["flat_ptr"] != flat.data_ptr():
-                st = dict(m=torch.zeros_like(flat), v=torch.zeros_like(flat), step=0 if st is None else st["step"], flat_ptr=flat.data_ptr())
-                self._state[gi] = st
+            st = self._flat_state(group, flat)
             if all(p.grad is None for p in group["params"]):
                 continue
             st["step"] += 1
             b1, b2 = group["betas"]
             t = st["step"]
-            L.check(lib.vsseg_adam(flat.data_ptr(), gflat.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+            L.check(lib.vsseg_adam(flat.data_ptr(), gflat.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), flat.numel(), float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                    float(group["weight_decay"]), 1.0 - b1**t, 1.0 - b2**t, float(self.grad_scale), stream), "adam")
             torch.autograd.graph.increment_version(flat)  # the kernel wrote through the raw pointer: let version-keyed caches (eval weight packing) see it
         return loss

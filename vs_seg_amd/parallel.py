@@ -49,6 +49,41 @@ def init_distributed(backend: str | None = None):
     return rank, world, local
 
 
+def _via_host(x: torch.Tensor) -> bool:
+    """gloo (CPU tests, or several ranks sharing one GPU with VSSEG_SHARE_DEVICE=1) is given host tensors: its CUDA/HIP support
+    depends on the torch build, a staged copy does not.  RCCL ("nccl") always works on the device tensor directly."""
+    return x.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce_sum(x: torch.Tensor, async_op: bool = False):
+    if _via_host(x):
+        h = x.detach().cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        x.copy_(h)
+        return None
+    return dist.all_reduce(x, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def _broadcast(x: torch.Tensor, src: int):
+    if _via_host(x):
+        h = x.detach().cpu()
+        dist.broadcast(h, src)
+        x.copy_(h)
+    else:
+        dist.broadcast(x, src)
+
+
+def _all_gather(x: torch.Tensor) -> List[torch.Tensor]:
+    if _via_host(x):
+        h = x.detach().cpu()
+        out = [torch.empty_like(h) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, h)
+        return [o.to(x.device) for o in out]
+    out = [torch.empty_like(x) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, x)
+    return out
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
 
@@ -66,20 +101,29 @@ def shard_indices(n: int, rank: int | None = None, world: int | None = None) -> 
 
 def broadcast_parameters(flat: torch.Tensor, src: int = 0):
     if world_size() > 1:
-        dist.broadcast(flat, src)
+        _broadcast(flat, src)
+
+
+def broadcast_buffers(model, src: int = 0):
+    """BatchNorm running statistics / batch counters of rank `src` to every rank (per-rank batch statistics make them drift apart;
+    validation and checkpoints must describe ONE model).  No-op in a single process."""
+    if world_size() > 1:
+        model.flat_parameters()
+        _broadcast(model._bflat, src)
+        _broadcast(model._cflat, src)
 
 
 def allreduce_gradients(gflat: torch.Tensor, async_op: bool = False):
     """Sum the flat gradient buffer over ranks (single bucket).  The mean is applied by Adam's `grad_scale`."""
     if world_size() > 1:
-        return dist.all_reduce(gflat, op=dist.ReduceOp.SUM, async_op=async_op)
+        return _all_reduce_sum(gflat, async_op)
     return None
 
 
 def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
     if world_size() > 1:
         x = x.clone()
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(x)
         x /= world_size()
     return x
 
@@ -87,7 +131,7 @@ def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
 def allreduce_sum(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (identity in a single process); returns x."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(x, op=dist.ReduceOp.SUM)
+        _all_reduce_sum(x)
     return x
 
 
@@ -99,8 +143,7 @@ def all_gather_scalars(values: Sequence[float], total: int, device="cpu") -> Lis
     per = (total + W - 1) // W
     buf = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
     buf[: len(values)] = torch.tensor(list(values), dtype=torch.float64, device=device)
-    out = [torch.empty_like(buf) for _ in range(W)]
-    dist.all_gather(out, buf)
+    out = _all_gather(buf)
     res = [float("nan")] * total
     for rr in range(W):
         for j, idx in enumerate(shard_indices(total, rr, W)):
@@ -133,8 +176,7 @@ def sharded_window_logits(inputs: torch.Tensor, roi_size, predictor: Callable, o
     local = local.contiguous()
     if W == 1:
         return windows, local[: len(windows)], (roi, padded, pad_before)
-    gathered = [torch.empty_like(local) for _ in range(W)]
-    dist.all_gather(gathered, local)
+    gathered = _all_gather(local)
     out = torch.empty((len(windows), *local.shape[1:]), dtype=torch.float32, device=local.device)
     for rr in range(W):
         idx = shard_indices(len(windows), rr, W)
@@ -175,8 +217,11 @@ class DataParallelTrainer:
         self.world = world_size()
         flat, _ = model.flat_parameters()
         broadcast_parameters(flat, 0)
-        if hasattr(optimizer, "grad_scale"):
-            optimizer.grad_scale = 1.0 / self.world
+        self.fused_mean = hasattr(optimizer, "grad_scale")
+        if self.fused_mean:
+            optimizer.grad_scale = 1.0 / self.world  # the fused Adam kernel multiplies the summed gradient by 1/world
+        if self.world > 1 and hasattr(model, "decorrelate_dropout"):
+            model.decorrelate_dropout(get_rank())  # every rank seeds torch identically (VS_train.py): give each its own keep-masks
 
     def step(self, inputs, labels, sync: bool = True):
         """Returns the loss tensor (device scalar).  `sync` is accepted for symmetry with the reference loop, which reads
@@ -187,5 +232,7 @@ class DataParallelTrainer:
         loss.backward()
         _, gflat = self.model.flat_parameters()
         allreduce_gradients(gflat)
+        if self.world > 1 and not self.fused_mean:
+            gflat.div_(self.world)  # any other optimizer (torch.optim.Adam / SGD ...) must see the mean, not the sum over ranks
         self.opt.step()
         return loss.detach()

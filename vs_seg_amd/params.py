@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import Adam, Dice_spvPA, UNet2d5_spvPA, compute_dice_score, sliding_window_inference
+from .inferers import argmax_segmentation
 from . import parallel as DP
 from .data import nifti
 from .data.transforms import PatchSampler, epoch_batches, load_case
@@ -48,9 +49,10 @@ class CachedLoader:
 
     def __init__(self, cases: List[Dict], roi: Optional[Sequence[int]], batch_size: int, shuffle: bool, flip_prob: Optional[float], seed: int = 0):
         self.cases, self.batch_size, self.shuffle = cases, batch_size, shuffle
-        self.sampler = PatchSampler(cases, roi, flip_prob, seed) if roi is not None else None
-        self._order = np.random.RandomState(seed)
         self.rank, self.world = DP.get_rank(), DP.world_size()
+        # every rank shuffles with the SAME stream (the shards must partition one permutation) but draws its own flips / crops
+        self.sampler = PatchSampler(cases, roi, flip_prob, seed + 7919 * self.rank) if roi is not None else None
+        self._order = np.random.RandomState(seed)
 
     def __len__(self):
         return len(self.cases)
@@ -111,7 +113,9 @@ class VSparams:
         self.figures_path = os.path.join(self.results_folder_path, "figures")
         rank, world, local = DP.init_distributed()
         self.rank, self.world = rank, world
-        self.device = torch.device("cuda", local) if torch.cuda.is_available() else torch.device(self.torch_device_arg)
+        if not torch.cuda.is_available():
+            raise RuntimeError("vs_seg_amd.VSparams: no GPU visible — this implementation has no CPU path (the reference falls back to whatever torch.device('cuda:0') does)")
+        self.device = torch.device("cuda", local)
         self.logger = logging.getLogger()
 
     # ------------------------------------------------------------------ housekeeping
@@ -176,10 +180,30 @@ class VSparams:
         # left-to-right Python sum, as the reference accumulates it: for an empty 10-slice label that is 4.500000000000001 -> 5
         return int(sum(w * np.arange(n)).round())
 
+    def check_transforms_on_first_validation_image_and_label(self, val_files, val_transforms):
+        """ref:params/VSparams.py:266-297 (called at ref:VS_train.py:36): run the validation chain on the first validation case and
+        log what came out.  The PNG of the centre-of-mass slice is out of scope; the slice index is still logged."""
+        logger = self.logger
+        case = load_case(val_files[0], val_transforms["pad"], self.device)
+        sampler = PatchSampler([case], val_transforms["roi"], val_transforms["flip_prob"], seed=0)
+        img, lab = sampler.sample([0])
+        check_data = {"image": img, "label": lab, "image_meta_dict": case["image_meta"], "label_meta_dict": case["label_meta"]}
+        image, label = check_data["image"][0][0], check_data["label"][0][0]
+        logger.info("-" * 10)
+        logger.info("Check the transforms on the first validation set image and label")
+        logger.info("Length of check_data = {}".format(len(check_data)))
+        logger.info("check_data['image'].shape = {}".format(check_data["image"].shape))
+        logger.info("Validation image shape = {}".format(image.shape))
+        logger.info("Validation label shape = {}".format(label.shape))
+        slice_idx = self.get_center_of_mass_slice(label)
+        logger.info("-" * 10)
+        logger.info("image shape: {}, label shape: {}, slice = {}".format(image.shape, label.shape, slice_idx))
+        return check_data
+
     def _cache(self, files, tf, batch_size, shuffle, what):
         self.logger.info(f"Caching {what} data set...")
         cases = [load_case(fd, tf["pad"], self.device) for fd in files]
-        return CachedLoader(cases, tf["roi"], batch_size, shuffle, tf["flip_prob"], seed=0)
+        return CachedLoader(cases, tf["roi"], batch_size, shuffle, tf["flip_prob"], seed=0)  # the crop/flip stream is decorrelated per rank inside CachedLoader
 
     def cache_transformed_train_data(self, train_files, train_transforms):
         return self._cache(train_files, train_transforms, self.train_batch_size, True, "training")
@@ -262,6 +286,7 @@ class VSparams:
     def validate(self, model, loss_function, val_loader):
         """N1: one validation pass without per-case host reads.  Returns (mean Dice, validation loss in the reference's
         accounting).  Multi-GPU: cases are sharded by the loader, sums are all-reduced."""
+        DP.broadcast_buffers(model)  # data parallel: every rank validates (and rank 0 saves) rank 0's BatchNorm running statistics
         model.eval()
         dice_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         loss_sum = torch.zeros((), dtype=torch.float64, device=self.device)
@@ -323,7 +348,7 @@ class VSparams:
     def export_segmentation(self, outputs, label_meta):
         """N3: argmax → uint8 NIfTI in the label's original orientation / affine, under
         results/inferred_segmentations_nifti/<case folder>/ like MONAI's NiftiSaver(output_postfix='')."""
-        seg = torch.argmax(outputs, dim=1)[0].to(torch.uint8).cpu().numpy()
+        seg = argmax_segmentation(outputs)[0].cpu().numpy()  # vsseg_argmax2: ties -> class 0, like torch.argmax
         seg = nifti.from_ras(seg, label_meta["ornt"])
         src = label_meta["filename_or_obj"]
         folder = os.path.basename(os.path.dirname(src))
