@@ -110,7 +110,8 @@ typedef struct {
   float* scratch;          /* partial-sum slabs: >= ceil(ch_valid/16) * ntaps * ntp*16 * 16 floats per workgroup */
   int64_t scratch_elems;   /* capacity in floats; the number of persistent workgroups is clamped to what fits */
   int32_t single_buffer;   /* 1: no prefetch, one LDS tile buffer (half the LDS, more resident workgroups); 0: double-buffered */
-  int32_t reserved;
+  int32_t hgroup;          /* 16-channel chunks of H one workgroup multiplies with the P tile it fetched (1..4; 0 = 1): P is read ceil(chunks/hgroup) times.
+                            * Clamped by the library to a divisor of the chunk count that fits registers / LDS. */
   float* dbias_p;          /* optional: dbias_p[cP] += sum_q P[q][cP] (bias gradient of a convolution without BatchNorm, P = dY) or NULL */
 } vsseg_wgrad_desc;
 

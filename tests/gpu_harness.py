@@ -79,9 +79,10 @@ def run_lattice_op(kind, w, x_cl, out_cl, stride, **epi):
     es = x0.element_size()
     odims = (xout.x, xout.y, xout.z)
     keep = []
+    mtw = epi.pop("mtw", None)
     for cls in P.lattice_classes(kind, kernel, stride):
         q = odims if kind in ("conv_fwd", "convT_dgrad") else tuple((o + s - 1) // s for o, s in zip(odims, stride))
-        plan = P.plan_igemm(kind, tuple(w.shape), cls, q, es, kc_pad=xin.c, in_split=xin.csplit if xin.ptr2 else 0, **({"lds_budget": epi.pop("lds_budget")} if "lds_budget" in epi else {}))
+        plan = P.plan_igemm(kind, tuple(w.shape), cls, q, es, kc_pad=xin.c, in_split=xin.csplit if xin.ptr2 else 0, mtw=mtw, aux_es=((4 if (epi.get("res") is not None and epi["res"].dtype == L.F32) else es) if (epi.get("accumulate") or epi.get("res_mode")) else 0) if mtw else 4, **({"lds_budget": epi.pop("lds_budget")} if "lds_budget" in epi else {}))
         wp = pack(plan, w, x0.dtype)
         d = igemm_desc(plan, wp, xin, xout, **epi)
         keep.append((wp, d))
@@ -90,7 +91,7 @@ def run_lattice_op(kind, w, x_cl, out_cl, stride, **epi):
     return keep
 
 
-def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid):
+def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid, hgroup=0, single_buffer=0):
     lib = L.lib()
     es = p_cl.element_size()
     wp = P.plan_wgrad(transposed, wshape, kernel, stride, tuple(p_cl.shape[1:4]), es)
@@ -105,6 +106,7 @@ def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid
     d.dw = dw.data_ptr()
     d.stride_p, d.stride_h, d.stride_tap = wp.stride_p, wp.stride_h, wp.stride_tap
     d.persistent_blocks = wp.blocks
+    d.hgroup, d.single_buffer = hgroup, single_buffer
     scr = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device="cuda")
     d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
     L.check(lib.vsseg_wgrad(C.byref(d), stream()), "wgrad")

@@ -131,6 +131,62 @@ def test_wgrad(k, s, cin, cout, dims, tr, dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("hg,sb", [(1, 1), (2, 0), (2, 1), (4, 0), (4, 1), (3, 1)])
+def test_wgrad_h_chunk_groups(hg, sb, dt):
+    """One workgroup multiplies its P tile with `hgroup` 16-channel chunks of H (incl. a two-part H whose split lies inside a group,
+    and a request that does not divide the chunk count: the library clamps it)."""
+    torch.manual_seed(14)
+    k, s, cin, cout, dims = (3, 3, 1), (1, 1, 1), 64, 32, (16, 12, 8)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, padding=P.same_pad(k))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    ref = w.grad.float()
+    xcl, gcl = H.to_cl(x, H.DT[dt]), H.to_cl(gy, H.DT[dt])
+    tol = (5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max())
+    dw = H.run_wgrad(False, tuple(w.shape), k, s, gcl, xcl, cout, cin, hgroup=hg, single_buffer=sb)
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=tol)
+    # two-part H (the skip-connection concat, both parts 32 channels wide): the split lies inside the 64-channel group of hgroup 4
+    dw = H.run_wgrad(False, tuple(w.shape), k, s, gcl, H._split_cl(xcl, 32), cout, cin, hgroup=hg, single_buffer=sb)
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=tol)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dims", [(16, 16, 16), (12, 10, 8)])
+def test_igemm_512_voxel_tiles(dims, dt):
+    """MTW = 8 (512-voxel tiles, the MFMA-bound configurations): forward with statistics, data gradient with accumulation (the
+    auxiliary tile needs 12 DMA pieces per thread) — whole and ragged tiles."""
+    torch.manual_seed(15)
+    k, s, cin, cout = (3, 3, 3), (1, 1, 1), 32, 48
+    x = _round(torch.randn(2, cin, *dims), dt).requires_grad_(True)
+    w = _round(torch.randn(cout, cin, *k) / (cin * 27) ** 0.5, dt)
+    b = torch.randn(cout)
+    y = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    out = torch.zeros(2, *dims, cout, dtype=H.DT[dt], device="cuda")
+    stats = torch.zeros(L.STAT_SHARDS * 2 * 48, dtype=torch.float64, device="cuda")
+    bias = b.cuda()
+    keep = H.run_lattice_op("conv_fwd", w, H.to_cl(x, H.DT[dt]), out, s, bias=bias.data_ptr(), stats=stats.data_ptr(), stats_stride=48, mtw=8)
+    assert keep[0][1].mtw == 8 and keep[0][1].nt == 3
+    np.testing.assert_allclose(H.from_cl(out).numpy(), y.detach().float().numpy(), atol=_tol(dt, y))
+    st = stats.cpu().view(L.STAT_SHARDS, 2, 48).sum(0)
+    np.testing.assert_allclose(st[0].numpy(), y.detach().sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=2e-2)
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    prev = _round(torch.randn(2, cin, *dims), dt)
+    dx = H.to_cl(prev, H.DT[dt]).clone()
+    w96 = _round(torch.randn(cout, 48, *k) / (48 * 27) ** 0.5, dt)  # data gradient with 48 output channels (NT 3)
+    x96 = torch.randn(2, 48, *dims, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x96, w96.double(), padding=1).backward(gy.double())
+    prev96 = _round(torch.randn(2, 48, *dims), dt)
+    dx96 = H.to_cl(prev96, H.DT[dt]).clone()
+    keep = H.run_lattice_op("conv_dgrad", w96, H.to_cl(gy, H.DT[dt]), dx96, s, accumulate=1, mtw=8)
+    assert keep[0][1].mtw == 8
+    want = x96.grad.float() + prev96
+    np.testing.assert_allclose(H.from_cl(dx96).numpy(), want.numpy(), atol=_tol(dt, want) * 1.5)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     """Training-mode BN -> Dropout -> PReLU (+residual): statistics, running stats, forward and all gradients vs the oracle

@@ -23,9 +23,12 @@ def bench_name(short_name):
     m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+), \d+>", short_name)  # the MODE variants of one (type, NT, MTW) share a bench name
     if m:
         return f"igemm<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(2)},{m.group(3)}>"
-    m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)>", short_name)
+    m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)(, \d+)?>", short_name)  # MAXT / H-group variants of one (type, NTP) share a bench name
     if m:
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
+    m = re.match(r"(bn_act_fwd|bn_act_bwd_reduce|bn_act_bwd_apply|att_apply_fwd|att_apply_bwd)_kernel<", short_name)  # streaming kernels: bench.py's group names
+    if m:
+        return m.group(1)
     return short_name
 
 

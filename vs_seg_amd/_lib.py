@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libvsseg_hip.so")
+SO_PATH = os.environ.get("VSSEG_LIB_PATH") or os.path.join(_HERE, "libvsseg_hip.so")  # VSSEG_LIB_PATH: tuning builds (tools/prof_phases.sh)
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -90,7 +90,7 @@ class WgradDesc(C.Structure):
         ("scratch", C.c_void_p),
         ("scratch_elems", C.c_int64),
         ("single_buffer", C.c_int32),
-        ("reserved", C.c_int32),
+        ("hgroup", C.c_int32),
         ("dbias_p", C.c_void_p),
     ]
 

@@ -131,7 +131,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
     const int aes = k.aux.dtype == VSSEG_F32 ? 4 : 2;
     const int row = d->nt * 16 * aes;
     const int beyond = d->nsplit * d->nt * 16 - (k.aux.ptr2 ? k.aux.csplit : 0);  // channels the DMA rows touch in the last part
-    const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && beyond <= k.aux.pitch && 64 * d->mtw * (row / 16) <= AMAX * 256 && ((uintptr_t)k.aux.ptr2 % 16) == 0 &&
+    const bool ok = (k.aux.pitch % 8) == 0 && (d->out.c % 4) == 0 && beyond <= k.aux.pitch && 64 * d->mtw * (row / 16) <= amax_for(d->mtw) * 256 && ((uintptr_t)k.aux.ptr2 % 16) == 0 &&
                     ((uintptr_t)k.aux.ptr % 16) == 0 && k.aux.c >= d->out.c;
     if (ok) k.aux_bytes = 64 * d->mtw * row; else k.aux_mode = 0;
     // the gate map of a gated add is DMA-prefetched with the tile when 4 z-consecutive tile voxels are 16 contiguous, aligned bytes
@@ -149,10 +149,12 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.depth = d->depth < 0 ? 0 : (d->depth == 0 ? 1 : (d->depth > 3 ? 3 : d->depth));  // -1: no prefetch (single buffer); 0: default = 1
   const int nbuf = k.depth + 1;
   k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? nbuf : 1);
-  k.lds_h = off; off += nbuf * k.h_bytes;
-  k.lds_aux = off; off += nbuf * k.aux_bytes;
+  k.h_stride = (k.h_bytes + 1023) / 1024 * 1024;      // ring buffers padded to whole 1 KiB DMA instructions (igemm_kernel.h: unconditional lanes)
+  k.aux_stride = (k.aux_bytes + 1023) / 1024 * 1024;
+  k.lds_h = off; off += nbuf * k.h_stride;
+  k.lds_aux = off; off += nbuf * k.aux_stride;
   k.npu = (k.h_bytes / 16 + 255) / 256;
-  k.lds_pinfo = off; off += (2 * k.npu + 1) * 1024;  // per-thread DMA offset table + slow-path coordinate tables (boundary / partial tiles)
+  k.lds_pinfo = off; off += (2 * k.npu + (64 * d->mtw + 255) / 256) * 1024;  // per-thread DMA offset table + slow-path coordinate tables (boundary / partial tiles)
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }
@@ -172,5 +174,22 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   k.tiles = tile_table(k, as_stream(stream));
   VSSEG_CHECK(k.tiles, "vsseg_igemm: could not allocate the tile table");
   dim3 grid(1, (unsigned)d->nsplit);  // grid.x is set to the resident workgroup count by launch<>()
+#ifdef VSSEG_IG_PROF
+  static unsigned long long* prof = nullptr;
+  if (!prof) hipMalloc(&prof, 16 * 8);
+  hipMemset(prof, 0, 16 * 8);
+  k.prof = prof;
+  int rc = launch_nt(d->in.dtype == VSSEG_F32, k, grid, lds, as_stream(stream));
+  if (getenv("VSSEG_IG_PROF_PRINT")) {
+    unsigned long long h[16];
+    hipStreamSynchronize(as_stream(stream));
+    hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+    const double n = h[8] ? (double)h[8] : 1.0;
+    fprintf(stderr, "igemm prof (workgroup 8, wave 0; cycles per stage over %llu stages): wait-others %.0f | dma-issue %.0f | dma-wait %.0f | barrier %.0f | k-loop %.0f | epilogue %.0f\n", h[8], h[0] / n, h[1] / n, h[2] / n,
+            h[3] / n, h[4] / n, h[5] / n);
+  }
+  return rc;
+#else
   return launch_nt(d->in.dtype == VSSEG_F32, k, grid, lds, as_stream(stream));
+#endif
 }

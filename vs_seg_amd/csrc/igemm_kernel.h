@@ -24,7 +24,8 @@
 #include <stdlib.h>
 
 constexpr int PMAX = 8;  // 16-byte halo pieces per thread per stage (halo chunk <= 32 KiB)
-constexpr int AMAX = 8;  // 16-byte pieces per thread of the auxiliary (residual / accumulate) output tile
+constexpr int AMAX = 8;  // 16-byte pieces per thread of the auxiliary (residual / accumulate) output tile (12 for the 512-voxel tiles, MTW = 8)
+constexpr int amax_for(int mtw) { return mtw == 8 ? 12 : AMAX; }
 
 struct IgemmK {
   vsseg_igemm_desc d;
@@ -34,6 +35,8 @@ struct IgemmK {
   int cgs;      // 8-channel groups per chunk
   int w_bytes;  // packed weights per chunk
   int h_bytes;  // halo chunk
+  int h_stride, aux_stride;  // LDS bytes between consecutive ring buffers: h_bytes / aux_bytes rounded up to 1 KiB, so that the lanes of the last (partial)
+                             // DMA instruction of a buffer land in its own padding — every lane of every DMA instruction is then issued unconditionally
   int lds_ktab, lds_epi, lds_w, lds_h, lds_aux, lds_pinfo;
   int npu;        // 16-byte halo pieces per thread and stage = rows of the per-thread coordinate table in LDS
   int aux_mode;   // 0 none, 1 accumulate (aux = out), 2 residual add, 3 ReLU mask, 4 gated add (aux * (1 + gate[voxel])): the aux tile is prefetched by DMA like the halo
@@ -44,6 +47,9 @@ struct IgemmK {
   int64_t total_tiles;
   const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
   const struct TileDesc* tiles;
+#ifdef VSSEG_IG_PROF
+  unsigned long long* prof;  // tuning build only: per-phase shader-cycle sums of workgroup 0 / wave 0
+#endif
 };
 
 // Per-tile descriptor, computed once per (geometry) by a setup kernel and cached: the main kernel fetches it with one scalar
@@ -88,6 +94,27 @@ __device__ __forceinline__ void mma(f32x4& acc, const Frag<float>& w, const Frag
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.hi.w, a.hi.w, acc, 0, 0, 0);
 }
 
+// Tile descriptors are read through the constant address space: with a wave-uniform address that is a scalar load (s_load_dwordx16)
+// into SGPRs.  Through a plain global pointer hipcc emitted VECTOR loads + `s_waitcnt vmcnt(0)` + v_readfirstlane for every
+// descriptor (it cannot prove that the kernel's own stores leave the table alone), and that wait drained the whole LDS-DMA /
+// store queue twice per tile (tools/prof_phases.sh: ~2000 of ~7800 cycles per stage on the HBM-bound layers).
+__device__ __forceinline__ TileDesc load_tile(const TileDesc* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const long long c64_t;
+  typedef __attribute__((address_space(4))) const int c32_t;
+  c64_t* q = reinterpret_cast<c64_t*>(reinterpret_cast<unsigned long long>(p));
+  c32_t* r = reinterpret_cast<c32_t*>(reinterpret_cast<unsigned long long>(p) + 16);
+  TileDesc t;
+  t.in_vox = q[0]; t.out_vox = q[1];
+  t.g0[0] = r[0]; t.g0[1] = r[1]; t.g0[2] = r[2];
+  t.q0[0] = r[3]; t.q0[1] = r[4]; t.q0[2] = r[5];
+  t.n = r[6]; t.flags = r[7];
+  return t;
+#else
+  return *p;
+#endif
+}
+
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 // 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
@@ -114,6 +141,11 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 // 189-256 VGPRs, spills in <2,4>): 0 plain, 1 +BatchNorm statistics (training forward), 2 +auxiliary tile (residual add /
 // gradient accumulation / ReLU mask fetched by DMA).
 enum { IG_PLAIN = 0, IG_STATS = 1, IG_AUX = 2 };
+#ifdef VSSEG_IG_PROF
+#define IG_TICK(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof_acc[i] += t_ - prof_t; prof_t = t_; }
+#else
+#define IG_TICK(i)
+#endif
 template <typename T, int NT, int MTW, int MODE>
 __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3 : 2) : 1)) void igemm_kernel(const IgemmK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +160,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   char* Hl = smem + k.lds_h;
   char* Al = smem + k.lds_aux;
   unsigned* pinfo_l = reinterpret_cast<unsigned*>(smem + k.lds_pinfo);  // [u][256] packed halo coordinates of this thread's pieces (boundary tiles only)
-  unsigned* vxyz_l = pinfo_l + k.npu * 256;                             // [64*MTW] packed tile coordinates of the tile's voxels (partial tiles only)
+  unsigned* vxyz_l = pinfo_l + k.npu * 256;                             // [64*MTW] packed tile coordinates of the tile's voxels (partial tiles only): VROWS rows of 256
+  constexpr int VROWS = (64 * MTW + 255) / 256;
+  constexpr int AM = amax_for(MTW);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int split = blockIdx.y;
@@ -171,7 +205,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   //      and was issue-bound at 1.7 TB/s on the HBM-bound layers).
   const int X = d.in.x, Y = d.in.y, Z = d.in.z;
   const unsigned in_vox_bytes = (unsigned)d.in.pitch * ES;
-  unsigned* prel_l = pinfo_l + (k.npu + 1) * 256;  // [npu][256] byte offset of each piece relative to the halo origin voxel (interior tiles); 0xffffffff: no piece
+  unsigned* prel_l = pinfo_l + (k.npu + VROWS) * 256;  // [npu][256] byte offset of each piece relative to the halo origin voxel (interior tiles); 0xffffffff: no piece
   unsigned p2mask = 0;   // bit u: piece u lies in part 1 of a two-part input (single-chunk case, see below)
   const bool in_two = d.in.ptr2 != nullptr;
   const int in_csplit = in_two ? d.in.csplit : 0x7fffffff;
@@ -187,7 +221,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       rel = (unsigned)((hx * Y + hy) * Z + hz) * in_vox_bytes + (unsigned)c16 * 16u;
       if (in_two && nch == 1 && c16 * EPP >= in_csplit) p2mask |= 1u << u;
     }
-    if (u < k.npu) { pinfo_l[u * 256 + tid] = info; prel_l[u * 256 + tid] = rel; }
+    if (u < k.npu) { pinfo_l[u * 256 + tid] = info; prel_l[u * 256 + tid] = rel == 0xffffffffu ? 0u : rel; }  // padding lanes copy the tile's first 16 bytes into the buffer's padding
   }
   // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  prel/pinfo keep the channel offset of the
   // virtual concatenated row; part 1's base is biased by -csplit channels so the same offsets address it.  A chunk never
@@ -213,9 +247,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   const int aux_row = NT * 16 * (int)aux_es;  // LDS bytes per voxel
   const int ppa = aux_row >> 4;
   const int apieces = aux_on ? 64 * MTW * ppa : 0;
-  unsigned arel[AUXM ? AMAX : 1];
+  unsigned arel[AUXM ? AM : 1];
 #pragma unroll
-  for (int u = 0; u < (AUXM ? AMAX : 1); ++u) {
+  for (int u = 0; u < (AUXM ? AM : 1); ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
     unsigned rel = 0xffffffffu;
     if (j < apieces) {
@@ -231,7 +265,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   unsigned a2mask = 0;
   if (aux_two) {
 #pragma unroll
-    for (int u = 0; u < (AUXM ? AMAX : 1); ++u) {
+    for (int u = 0; u < (AUXM ? AM : 1); ++u) {
       const int j = (u * 4 + wave) * 64 + lane;
       if (j < apieces && split * NT * 16 + (j % ppa) * (16 / (int)aux_es) >= k.aux.csplit) a2mask |= 1u << u;
     }
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
 
   const TileDesc* tiles = k.tiles + (t_first + slot);  // this workgroup's tiles: tiles[i * S]
   // descriptors are fetched (scalar loads) one tile ahead of their first use, so their latency never sits in front of a DMA issue
-  TileDesc td_next = tiles[0];  // descriptor of the next tile to be issued
+  TileDesc td_next = load_tile(tiles);  // descriptor of the next tile to be issued
   int ti_issue = 0, ti_cur = 0;
   int ch_issue = 0, ch_cur = 0;
   const int D = k.depth, nbuf = D + 1;
@@ -286,7 +320,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
 #pragma unroll
   for (int u = 0; u < PMAX; ++u) nh += ((u * 4 + wave) * 64 < pieces) ? 1 : 0;
 #pragma unroll
-  for (int u = 0; u < (AUXM ? AMAX : 0); ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
+  for (int u = 0; u < (AUXM ? AM : 0); ++u) na += ((u * 4 + wave) * 64 < apieces) ? 1 : 0;
   if (gate_dma && wave == 0) ++na;
   if (nch > 1)
     for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
@@ -304,29 +338,34 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     if (++ch_issue == nch) {
       ch_issue = 0;
       ++ti_issue;
-      if (ti_issue < my_tiles) td_next = tiles[(int64_t)ti_issue * S];  // uniform address: scalar loads, consumed a whole stage later
+      if (ti_issue < my_tiles) td_next = load_tile(tiles + (int64_t)ti_issue * S);  // uniform address: scalar loads, consumed a whole stage later
     }
     const int c0 = ch * CK;
-    char* Hdst = Hl + buf_issue * k.h_bytes;
+    char* Hdst = Hl + buf_issue * k.h_stride;
     const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
     if (interior) {
+      // Interior tile: every DMA source is origin + a per-thread constant.  The constants are fetched from the LDS table in one
+      // batch (one wait instead of one per piece) and every lane of every instruction is issued — lanes beyond the last piece
+      // re-read the tile's first bytes into the buffer's padding — so the loop below is straight-line code: no exec masking.
       const int64_t ooff = td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
       const char* origin = in_base + ooff;
-      if (!in_two) {
+      unsigned rel[PMAX];
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u)
+        if (u < k.npu) rel[u] = prel_l[u * 256 + tid];
+      if (!in_two || nch > 1) {  // one source tensor for the whole chunk
+        const char* org = (in_two && c0 >= in_csplit) ? in_base1 + ooff : origin;
 #pragma unroll
         for (int u = 0; u < PMAX; ++u) {
-          if ((u * 4 + wave) * 64 >= pieces) break;  // wave-uniform
-          const unsigned rel = prel_l[u * 256 + tid];
-          if (rel != 0xffffffffu) dma16(origin + rel, Hdst + (u * 4 + wave) * 1024);
+          if (u >= nh) break;  // wave-uniform
+          dma16(org + rel[u], Hdst + (u * 4 + wave) * 1024);
         }
-      } else {
+      } else {  // the only chunk spans both parts of a two-part input: static per-thread choice per piece
         const char* origin1 = in_base1 + ooff;
-        const unsigned m2 = nch == 1 ? p2mask : (c0 >= in_csplit ? 0xffffffffu : 0u);
 #pragma unroll
         for (int u = 0; u < PMAX; ++u) {
-          if ((u * 4 + wave) * 64 >= pieces) break;
-          const unsigned rel = prel_l[u * 256 + tid];
-          if (rel != 0xffffffffu) dma16(((m2 >> u) & 1u ? origin1 : origin) + rel, Hdst + (u * 4 + wave) * 1024);
+          if (u >= nh) break;
+          dma16(((p2mask >> u) & 1u ? origin1 : origin) + rel[u], Hdst + (u * 4 + wave) * 1024);
         }
       }
     } else {
@@ -334,17 +373,19 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       const int64_t soff = (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
       const char* sample = in_base + soff;
       const char* sample1 = in_base1 + soff;
+      unsigned inf[PMAX];
+#pragma unroll
+      for (int u = 0; u < PMAX; ++u)
+        if (u < k.npu) inf[u] = pinfo_l[u * 256 + tid];
 #pragma unroll
       for (int u = 0; u < PMAX; ++u) {
-        if ((u * 4 + wave) * 64 >= pieces) break;
-        const unsigned info = pinfo_l[u * 256 + tid];
-        if (info != 0xffffffffu) {
-          const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
-          const int c = c0 + (int)(info >> 24) * EPP;
-          const bool ok = (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
-          const void* src = ok ? (const void*)((c >= in_csplit ? sample1 : sample) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
-          dma16(src, Hdst + (u * 4 + wave) * 1024);
-        }
+        if (u >= nh) break;
+        const unsigned info = inf[u];
+        const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
+        const int c = c0 + (int)(info >> 24) * EPP;
+        const bool ok = info != 0xffffffffu && (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
+        const void* src = ok ? (const void*)((c >= in_csplit ? sample1 : sample) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
+        dma16(src, Hdst + (u * 4 + wave) * 1024);
       }
     }
     if constexpr (AUXM) if (ch == 0) {
@@ -353,11 +394,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       const bool whole = (td.flags & 2) != 0;
       const char* aorigin = aux_base + td.out_vox * aux_vox_bytes;
       const char* aorigin1 = aux_base1 + td.out_vox * aux_vox_bytes;
-      char* Adst = Al + abuf_issue * k.aux_bytes;
+      char* Adst = Al + abuf_issue * k.aux_stride;
 #pragma unroll
-      for (int u = 0; u < (AUXM ? AMAX : 0); ++u) {
+      for (int u = 0; u < (AUXM ? AM : 0); ++u) {
         if ((u * 4 + wave) * 64 >= apieces) break;
-        if (arel[u] != 0xffffffffu) dma16(whole ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);
+        dma16(whole && arel[u] != 0xffffffffu ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);  // padding lanes: zeros into the padding
       }
       if (gate_dma && wave == 0) {
         if (lane < 16 * MTW) dma16(whole ? (const void*)(d.gate + td.out_vox + grel) : k.zeros, Adst + k.aux_gate_off);
@@ -367,8 +408,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     if (nch > 1) {
       const char* wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
       char* Wdst = Wl + buf_issue * k.w_bytes;
-      for (int j0 = wave * 64; j0 < wpieces; j0 += 256)
-        if (j0 + lane < wpieces) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);
+      for (int j0 = wave * 64; j0 < wpieces; j0 += 256) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);  // w_bytes is a multiple of 1 KiB: no partial instruction
     }
     if (++buf_issue == nbuf) buf_issue = 0;
   };
@@ -381,8 +421,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     for (int r = 0; r < 4; ++r) ssum[t][r] = ssq[t][r] = 0.f;
 
   __syncthreads();  // tables / resident weights / epilogue constants written above are visible before the pipeline starts
+#ifdef VSSEG_IG_PROF
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
+#endif
   for (int j = 0; j < D && j < nstages; ++j) issue(j);  // stages 0..D-1 in flight
   for (int s = 0; s < nstages; ++s) {
+    IG_TICK(5)
     // Stage s has landed once at most the DMAs of the younger stages s+1..s+D-1 remain (VMEM ops complete in issue order).  The
     // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
     // Also younger than stage s's DMAs, and still allowed to be in flight: the output stores of the last D stages (vmcnt retires
@@ -394,8 +438,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous stage's tile
       }
+      IG_TICK(0)
       issue(s);
+      IG_TICK(1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      IG_TICK(2)
     } else if (D == 1) {
       wait_vmcnt(st_h0);
     } else {
@@ -408,8 +455,9 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring
+    IG_TICK(3)
     if (D > 0 && s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
-    const TileDesc tc = tiles[(int64_t)ti_cur * S];  // this stage's tile (scalar load, consumed in the epilogue)
+    const TileDesc tc = load_tile(tiles + (int64_t)ti_cur * S);  // this stage's tile (scalar load, consumed in the epilogue)
     const int ch = ch_cur;
     if (ch == 0) {
 #pragma unroll
@@ -417,15 +465,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const char* Hs = Hl + buf_cur * k.h_bytes;
+    const char* Hs = Hl + buf_cur * k.h_stride;
     const char* Ws = nch > 1 ? Wl + buf_cur * k.w_bytes : Wl;
     if (++buf_cur == nbuf) buf_cur = 0;
     if constexpr (NT <= 2) {
       // HBM-bound configurations (<= 32 output channels per workgroup): plain K loop — two resident workgroups per CU hide the
       // LDS latency, and the registers of a second fragment set would cost that second workgroup
       const char* Wlane = Ws + lane * GB;
-      for (int ks = 0; ks < d.ksteps; ++ks) {
-        const int koff = ktab[ks * 4 + g];
+      const int nks = d.ksteps;
+      int koff_next = ktab[g];
+      for (int ks = 0; ks < nks; ++ks) {
+        const int koff = koff_next;
+        koff_next = ktab[(ks + 1 < nks ? ks + 1 : ks) * 4 + g];  // the next step's tap offset is read while this step's fragments / MFMAs are in flight
         Frag<T> w[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) w[t] = Frag<T>::ld(Wlane + (ks * NT + t) * 64 * GB);
@@ -478,6 +529,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       }
     }
     st_h2 = st_h1; st_h1 = st_h0; st_h0 = 0;  // store instructions of the last three stages (this stage's are added below)
+    IG_TICK(4)
     if (++ch_cur != nch) continue;
     ch_cur = 0;
 
@@ -486,7 +538,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     const bool whole = (tc.flags & 2) != 0;
     char* out_tile = out_base + tc.out_vox * out_vox_bytes;
     const int64_t out_delta = out_base1 - out_base;  // 0 for an ordinary tensor
-    const char* Aux = Al + abuf_cur * k.aux_bytes;
+    const char* Aux = Al + abuf_cur * k.aux_stride;
     if (++abuf_cur == nbuf) abuf_cur = 0;
     if (whole && fast_store) {  // interior tile, plain store: bias (+stats) (+affine) + activation, 4 channels per lane
       st_h0 = nst_fast;
@@ -607,6 +659,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     }  // slow epilogue
   }
 
+#ifdef VSSEG_IG_PROF
+  if (k.prof && blockIdx.x == 8 && blockIdx.y == 0 && tid == 0) {
+    for (int i = 0; i < 8; ++i) k.prof[i] = prof_acc[i];
+    k.prof[8] = (unsigned long long)nstages;
+  }
+#endif
   if constexpr (STATS) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics
     __syncthreads();
     float* red = epi;  // reuse [2][NT*16]
@@ -647,6 +705,10 @@ template <typename T, int NT, int MTW, int MODE> static int launch_mode(const Ig
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW, MODE>, 256, lds) != hipSuccess || n < 1) n = 1;
     cached_per_cu = n > 6 ? 6 : n;
     cached_lds = lds;
+    if (const char* e = getenv("VSSEG_IG_PERCU")) {  // tuning aid: cap the resident workgroups per CU (occupancy scaling experiments)
+      const int cap = atoi(e);
+      if (cap > 0 && cap < cached_per_cu) cached_per_cu = cap;
+    }
   }
   int64_t gx = 256ll * cached_per_cu;
   if (gx > k.total_tiles) gx = k.total_tiles;
@@ -665,7 +727,11 @@ template <typename T, int NT> static int launch_mtw(const IgemmK& k, dim3 grid, 
     case 1: return launch<T, NT, 1>(k, grid, lds, s);
     case 2: return launch<T, NT, 2>(k, grid, lds, s);
     case 4: return launch<T, NT, 4>(k, grid, lds, s);
+    case 8:  // 512-voxel tiles: only the MFMA-bound configurations (>= 48 output channels per workgroup) — the packed weights of a channel
+             // chunk are then streamed once per 512 voxels instead of once per 128-256
+      if constexpr (NT >= 3) return launch<T, NT, 8>(k, grid, lds, s);
+      break;
   }
-  vsseg_set_error("vsseg_igemm: mtw must be 1, 2 or 4 (got %d)", k.d.mtw);
+  vsseg_set_error("vsseg_igemm: mtw must be 1, 2, 4 (or 8 with nt >= 3), got mtw %d nt %d", k.d.mtw, k.d.nt);
   return VSSEG_EINVAL;
 }

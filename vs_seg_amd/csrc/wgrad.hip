@@ -8,7 +8,9 @@
 // the LDS transpose read ds_read_b64_tr_b16 from [voxel][channel] tiles (bf16); the f32 path uses v_mfma_f32_16x16x4_f32
 // whose operands are single elements and need no transpose.
 //
-// Work split: blockIdx.y = 16-channel chunk of H (only those channels of the halo tile are staged), blockIdx.x = persistent
+// Work split: blockIdx.y = group of HG 16-channel chunks of H (only those channels of the halo tile are staged; one workgroup
+// multiplies the P tile it fetched with all HG chunks, so P is read ceil(chunks / HG) times instead of once per chunk — the
+// per-chunk split of round 1 moved 1.7x the algorithmic bytes on the 32/64-channel layers), blockIdx.x = persistent
 // workgroup striding over lattice tiles; accumulators live in registers across all tiles of a workgroup and are flushed
 // once as a partial-sum slab (plain coalesced stores; fp32 atomics measured ~18 G/s and dominated the kernel); a tiny
 // second kernel sums the slabs of all workgroups into the weight gradient.  The 4 waves of a workgroup split the taps (wave w owns taps t = w mod WT) and, for 1x1x1
@@ -26,6 +28,7 @@ struct WgradK {
   int lds_hbase, lds_p, lds_h, lds_tab;
   int npp, nph;   // rows of the per-thread coordinate tables (P pieces, H pieces) kept in LDS for the boundary-tile path
   int nbuf;       // 2: tile s+1 streams in while tile s is multiplied; 1: no prefetch, half the LDS, more resident workgroups
+  int hchunks;    // 16-channel chunks of H in total (slab layout); a workgroup owns HG consecutive ones
   int64_t total_tiles;
   const void* zeros;  // >= 16 zero bytes in global memory (source of out-of-bounds pieces)
   float* slab;     // [gridDim.x][hchunks][ntaps][ntp*16][16] partial sums
@@ -38,14 +41,15 @@ __device__ __forceinline__ void wg_dma16(const void* gsrc, char* lds_wave_base) 
   __builtin_amdgcn_global_load_lds((wg_gvoid_t*)gsrc, (wg_lvoid_t*)lds_wave_base, 16, 0, 0);
 }
 constexpr int WPP = 12;  // 16-byte pieces of the P tile per thread  (P tile <= 48 KiB)
-constexpr int WPH = 8;   // ... of the H halo tile per thread         (halo    <= 32 KiB)
+constexpr int WPH = 16;  // ... of the H halo tile per thread         (halo    <= 64 KiB)
 
-template <typename T, int MAXT, int NTP>
+template <typename T, int MAXT, int NTP, int HG>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = sizeof(T);
   constexpr int EPP = 16 / ES;
-  constexpr int HROW = 16 * ES;  // bytes per halo row (16 channels)
+  constexpr int HROW = HG * 16 * ES;  // bytes per halo row (HG chunks of 16 channels)
+  constexpr int HPP = HROW / 16;      // 16-byte pieces per halo voxel
   const vsseg_wgrad_desc& d = k.d;
   int* hbase = reinterpret_cast<int*>(smem + k.lds_hbase);
   char* Pl = smem + k.lds_p;
@@ -56,7 +60,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   const int wt = wave % k.wt, wv = wave / k.wt;
   const int HX = k.halo[0], HY = k.halo[1], HZ = k.halo[2];
   const int hvox = HX * HY * HZ;
-  const int chunk = blockIdx.y;
+  const int chunk0 = blockIdx.y * HG;  // first 16-channel chunk of H this workgroup owns
   const int p_bytes = k.tvox * k.p_row, h_bytes = hvox * HROW;
 
   for (int v = tid; v < k.tvox; v += 256) {
@@ -70,19 +74,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     int t = wt + i * k.wt;
     toff[i] = t < d.ntaps ? (((d.tap_off[t][0] - k.off_min[0]) * HY + (d.tap_off[t][1] - k.off_min[1])) * HZ + (d.tap_off[t][2] - k.off_min[2])) * HROW : -1;
   }
-  f32x4 acc[MAXT][NTP];
+  f32x4 acc[MAXT][HG][NTP];
 #pragma unroll
   for (int i = 0; i < MAXT; ++i)
 #pragma unroll
-    for (int p = 0; p < NTP; ++p) acc[i][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < HG; ++h)
+#pragma unroll
+      for (int p = 0; p < NTP; ++p) acc[i][h][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- per-thread constants of the two DMA tiles (same scheme as igemm.hip: tile-independent part precomputed once) ----
   const int PX = d.p.x, PY = d.p.y, PZ = d.p.z, QX = d.h.x, QY = d.h.y, QZ = d.h.z;
   const unsigned p_vox_bytes = (unsigned)d.p.pitch * ES, h_vox_bytes = (unsigned)d.h.pitch * ES;
   const int ppp = k.p_row >> 4;   // 16-byte pieces per P voxel row (NTP*16 channels)
   const int ppieces = k.tvox * ppp;
-  const int hpieces = hvox * ES;  // 16 channels = ES pieces of 16 B
+  const int hpieces = hvox * HPP;
   unsigned prel[WPP], hrel[WPH];  // 0xffffffff: no piece
+  unsigned h2mask = 0;            // bit u: halo piece u lies in part 1 of a two-part H (static per thread)
 #pragma unroll
   for (int u = 0; u < WPP; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
@@ -103,21 +110,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     const int j = (u * 4 + wave) * 64 + lane;
     unsigned info = 0xffffffffu, rel = 0xffffffffu;
     if (j < hpieces) {
-      const int hv = j / ES, c16 = j - hv * ES;
+      const int hv = j / HPP, c16 = j - hv * HPP;
       int hz = hv % HZ, r = hv / HZ;
       int hy = r % HY, hx = r / HY;
-      const bool cok = chunk * 16 + c16 * EPP + EPP <= d.h.c;
+      const int ch = chunk0 * 16 + c16 * EPP;  // first channel of the piece inside H
+      const bool cok = ch + EPP <= d.h.c;
       info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
       rel = (unsigned)((hx * QY + hy) * QZ + hz) * h_vox_bytes + (unsigned)c16 * 16u;
+      if (d.h.ptr2 != nullptr && ch >= d.h.csplit) h2mask |= 1u << u;
     }
     if (u < k.nph) hinfo_l[u * 256 + tid] = info;
     hrel[u] = rel;
   }
-  const bool p_chan_ok = NTP * 16 <= d.p.c, h_chan_ok = chunk * 16 + 16 <= d.h.c;  // every piece has real channels (fast path)
+  const bool p_chan_ok = NTP * 16 <= d.p.c, h_chan_ok = chunk0 * 16 + HG * 16 <= d.h.c;  // every piece has real channels (fast path)
   const char* p_base = reinterpret_cast<const char*>(d.p.ptr);
-  // two-part H (the skip-connection concat as the convolution input): a 16-channel chunk lies in one part (csplit % 16 == 0)
-  const bool h_part1 = d.h.ptr2 != nullptr && chunk * 16 >= d.h.csplit;
-  const char* h_base = h_part1 ? reinterpret_cast<const char*>(d.h.ptr2) + (int64_t)(chunk * 16 - d.h.csplit) * ES : reinterpret_cast<const char*>(d.h.ptr) + (int64_t)chunk * 16 * ES;
+  // two-part H (the skip-connection concat as the convolution input): a 16-byte piece lies in one part (csplit % 16 == 0); part 1's
+  // base is biased by -csplit channels so that the same per-piece offsets address it
+  const char* h_base = reinterpret_cast<const char*>(d.h.ptr) + (int64_t)chunk0 * 16 * ES;
+  const char* h_base1 = d.h.ptr2 != nullptr ? reinterpret_cast<const char*>(d.h.ptr2) + ((int64_t)chunk0 * 16 - d.h.csplit) * ES : h_base;
   const int64_t p_sample = (int64_t)PX * PY * PZ * p_vox_bytes, h_sample = (int64_t)QX * QY * QZ * h_vox_bytes;
 
   struct TileIdx { int tz, ty, tx, n; };
@@ -173,14 +183,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     }
     {
       const char* sample = h_base + (int64_t)n * h_sample;
+      const char* sample1 = h_base1 + (int64_t)n * h_sample;
       const int gx0 = q0x * d.hs[0] + k.off_min[0], gy0 = q0y * d.hs[1] + k.off_min[1], gz0 = q0z * d.hs[2] + k.off_min[2];
       const bool interior = gx0 >= 0 && gy0 >= 0 && gz0 >= 0 && gx0 + HX <= QX && gy0 + HY <= QY && gz0 + HZ <= QZ && h_chan_ok;
       if (interior) {
-        const char* origin = sample + (int64_t)((gx0 * QY + gy0) * QZ + gz0) * h_vox_bytes;
+        const int64_t ooff = (int64_t)((gx0 * QY + gy0) * QZ + gz0) * h_vox_bytes;
+        const char* origin = sample + ooff;
+        const char* origin1 = sample1 + ooff;
 #pragma unroll
         for (int u = 0; u < WPH; ++u) {
           if ((u * 4 + wave) * 64 >= hpieces) break;
-          if (hrel[u] != 0xffffffffu) wg_dma16(origin + hrel[u], Hdst + (u * 4 + wave) * 1024);
+          if (hrel[u] != 0xffffffffu) wg_dma16(((h2mask >> u) & 1u ? origin1 : origin) + hrel[u], Hdst + (u * 4 + wave) * 1024);
         }
       } else {
 #pragma unroll
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
             const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
             const unsigned c16 = info >> 24;
             const bool ok = (unsigned)gx < (unsigned)QX && (unsigned)gy < (unsigned)QY && (unsigned)gz < (unsigned)QZ && c16 != 255u;
-            const void* src = ok ? (const void*)(sample + (int64_t)((gx * QY + gy) * QZ + gz) * h_vox_bytes + c16 * 16u) : k.zeros;
+            const void* src = ok ? (const void*)(((h2mask >> u) & 1u ? sample1 : sample) + (int64_t)((gx * QY + gy) * QZ + gz) * h_vox_bytes + c16 * 16u) : k.zeros;
             wg_dma16(src, Hdst + (u * 4 + wave) * 1024);
           }
         }
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 
   // optional bias gradient dbias[cP] += sum_q P[q][cP] (P = dY of a convolution without BatchNorm): one extra MFMA per K-step
   // against an all-ones operand in the workgroups of H-chunk 0 — replaces a separate pass over dY (vsseg_channel_sum)
-  const bool do_bias = d.dbias_p != nullptr && chunk == 0 && wt == 0;
+  const bool do_bias = d.dbias_p != nullptr && chunk0 == 0 && wt == 0;
   f32x4 accb[NTP];
 #pragma unroll
   for (int p = 0; p < NTP; ++p) accb[p] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -242,11 +255,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
         for (int i = 0; i < MAXT; ++i) {
           if (toff[i] < 0) continue;
           typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-          bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h0 + toff[i]));
-          bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h1 + toff[i]));
-          bf16x8 hb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int p = 0; p < NTP; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[p], hb, acc[i][p], 0, 0, 0);
+          for (int h = 0; h < HG; ++h) {
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h0 + toff[i] + h * 32));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(Hs + h1 + toff[i] + h * 32));
+            bf16x8 hb = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int p = 0; p < NTP; ++p) acc[i][h][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[p], hb, acc[i][h][p], 0, 0, 0);
+          }
         }
       } else {
 #pragma unroll 2
@@ -263,9 +279,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
           for (int i = 0; i < MAXT; ++i) {
             if (toff[i] < 0) continue;
-            const float hb = *reinterpret_cast<const float*>(Hs + hb0 + toff[i]);
 #pragma unroll
-            for (int p = 0; p < NTP; ++p) acc[i][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[p], hb, acc[i][p], 0, 0, 0);
+            for (int h = 0; h < HG; ++h) {
+              const float hb = *reinterpret_cast<const float*>(Hs + hb0 + toff[i] + h * 64);
+#pragma unroll
+              for (int p = 0; p < NTP; ++p) acc[i][h][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[p], hb, acc[i][h][p], 0, 0, 0);
+            }
           }
         }
       }
@@ -282,23 +301,28 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
       }
   }
   // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) -> this workgroup's slab [tap][cP][16]
-  float* slab = k.slab + ((int64_t)blockIdx.x * gridDim.y + chunk) * k.slab_chunk;
 #pragma unroll
-  for (int i = 0; i < MAXT; ++i) {
-    const int t = wt + i * k.wt;
-    if (t >= d.ntaps) continue;
+  for (int h = 0; h < HG; ++h) {
+    if (chunk0 + h >= k.hchunks) break;  // the last group may be short
+    float* slab = k.slab + ((int64_t)blockIdx.x * k.hchunks + chunk0 + h) * k.slab_chunk;
 #pragma unroll
-    for (int p = 0; p < NTP; ++p)
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = wt + i * k.wt;
+      if (t >= d.ntaps) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cp = p * 16 + g * 4 + r;
-        float* dst = slab + ((int64_t)t * (NTP * 16) + cp) * 16 + l15;
-        if (k.wv == 1) *dst = acc[i][p][r];
-        else atomicAdd(dst, acc[i][p][r]);  // K-steps split over waves (1x1x1 kernels): slab pre-zeroed by the host wrapper
-      }
+      for (int p = 0; p < NTP; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cp = p * 16 + g * 4 + r;
+          float* dst = slab + ((int64_t)t * (NTP * 16) + cp) * 16 + l15;
+          if (k.wv == 1) *dst = acc[i][h][p][r];
+          else atomicAdd(dst, acc[i][h][p][r]);  // K-steps split over waves (1x1x1 kernels): slab pre-zeroed by the host wrapper
+        }
+    }
   }
 }
 
+#ifndef WG_INST
 // dw[cp][ch][tap] += sum over workgroups of their slabs
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
   const int total = hchunks * slab_chunk;
@@ -322,47 +346,68 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, in
   }
 }
 
-template <typename T, int MAXT, int NTP> static int wg_launch(WgradK& k, dim3& grid, int lds, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, MAXT, NTP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
+#endif  // WG_INST
+
+template <typename T, int MAXT, int NTP, int HG> static int wg_launch(WgradK& k, dim3& grid, int lds, hipStream_t s) {
+  if constexpr (MAXT * NTP * HG > 42) {  // accumulators beyond ~170 VGPRs are never planned (vsseg_wgrad clamps HG): keep the instantiation count down
+    vsseg_set_error("vsseg_wgrad: maxt %d x ntp %d x hgroup %d accumulator tiles exceed the register budget", MAXT, NTP, HG);
+    return VSSEG_EINVAL;
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, MAXT, NTP, HG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    // persistent grid: never more workgroups than are resident at once (a late workgroup would be a serial tail)
+    static int cached_lds = -1, cached_per_cu = 1;
+    if (cached_lds != lds) {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<T, MAXT, NTP, HG>, 256, lds) != hipSuccess || n < 1) n = 1;
+      cached_per_cu = n > 4 ? 4 : n;
+      cached_lds = lds;
+    }
+    unsigned cap = (unsigned)(256 * cached_per_cu) / grid.y;
+    if (cap < 1) cap = 1;
+    if (grid.x > cap) grid.x = cap;
+    hipLaunchKernelGGL((wgrad_kernel<T, MAXT, NTP, HG>), grid, dim3(256), lds, s, k);
+    VSSEG_LAUNCH_CHECK("vsseg_wgrad");
+    return VSSEG_OK;
   }
-  // persistent grid: never more workgroups than are resident at once (a late workgroup would be a serial tail)
-  static int cached_lds = -1, cached_per_cu = 1;
-  if (cached_lds != lds) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, wgrad_kernel<T, MAXT, NTP>, 256, lds) != hipSuccess || n < 1) n = 1;
-    cached_per_cu = n > 4 ? 4 : n;
-    cached_lds = lds;
-  }
-  unsigned cap = (unsigned)(256 * cached_per_cu) / grid.y;
-  if (cap < 1) cap = 1;
-  if (grid.x > cap) grid.x = cap;
-  hipLaunchKernelGGL((wgrad_kernel<T, MAXT, NTP>), grid, dim3(256), lds, s, k);
-  VSSEG_LAUNCH_CHECK("vsseg_wgrad");
-  return VSSEG_OK;
 }
-template <typename T, int MAXT> static int wg_ntp(WgradK& k, dim3& grid, int lds, hipStream_t s) {
+template <typename T, int MAXT, int NTP> static int wg_hg(WgradK& k, int hg, dim3& grid, int lds, hipStream_t s) {
+  switch (hg) {
+    case 1: return wg_launch<T, MAXT, NTP, 1>(k, grid, lds, s);
+    case 2: return wg_launch<T, MAXT, NTP, 2>(k, grid, lds, s);
+    case 3: return wg_launch<T, MAXT, NTP, 3>(k, grid, lds, s);
+    case 4: return wg_launch<T, MAXT, NTP, 4>(k, grid, lds, s);
+  }
+  vsseg_set_error("vsseg_wgrad: hgroup must be 1..4 (got %d)", hg);
+  return VSSEG_EINVAL;
+}
+template <typename T, int MAXT> static int wg_ntp(WgradK& k, int hg, dim3& grid, int lds, hipStream_t s) {
   switch (k.d.ntp) {
-    case 1: return wg_launch<T, MAXT, 1>(k, grid, lds, s);
-    case 2: return wg_launch<T, MAXT, 2>(k, grid, lds, s);
-    case 3: return wg_launch<T, MAXT, 3>(k, grid, lds, s);
-    case 4: return wg_launch<T, MAXT, 4>(k, grid, lds, s);
-    case 5: return wg_launch<T, MAXT, 5>(k, grid, lds, s);
-    case 6: return wg_launch<T, MAXT, 6>(k, grid, lds, s);
+    case 1: return wg_hg<T, MAXT, 1>(k, hg, grid, lds, s);
+    case 2: return wg_hg<T, MAXT, 2>(k, hg, grid, lds, s);
+    case 3: return wg_hg<T, MAXT, 3>(k, hg, grid, lds, s);
+    case 4: return wg_hg<T, MAXT, 4>(k, hg, grid, lds, s);
+    case 5: return wg_hg<T, MAXT, 5>(k, hg, grid, lds, s);
+    case 6: return wg_hg<T, MAXT, 6>(k, hg, grid, lds, s);
   }
   vsseg_set_error("vsseg_wgrad: ntp must be 1..6 (got %d)", k.d.ntp);
   return VSSEG_EINVAL;
 }
-template <typename T> static int wg_maxt(WgradK& k, int maxt, dim3& grid, int lds, hipStream_t s) {
-  if (maxt <= 1) return wg_ntp<T, 1>(k, grid, lds, s);
-  if (maxt <= 3) return wg_ntp<T, 3>(k, grid, lds, s);
-  if (maxt <= 7) return wg_ntp<T, 7>(k, grid, lds, s);
+template <typename T> static int wg_maxt(WgradK& k, int maxt, int hg, dim3& grid, int lds, hipStream_t s) {
+  if (maxt <= 1) return wg_ntp<T, 1>(k, hg, grid, lds, s);
+  if (maxt <= 3) return wg_ntp<T, 3>(k, hg, grid, lds, s);
+  if (maxt <= 7) return wg_ntp<T, 7>(k, hg, grid, lds, s);
   vsseg_set_error("vsseg_wgrad: too many taps per wave (%d)", maxt);
   return VSSEG_EINVAL;
 }
+// instantiated per element type in wgrad_inst.hip (two translation units that build in parallel)
+int vsseg_wgrad_launch_f32(WgradK& k, int maxt, int hg, dim3& grid, int lds, hipStream_t s);
+int vsseg_wgrad_launch_bf16(WgradK& k, int maxt, int hg, dim3& grid, int lds, hipStream_t s);
 
+#ifndef WG_INST
 extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   VSSEG_CHECK(d && d->p.ptr && d->h.ptr && d->dw, "vsseg_wgrad: null pointer");
   VSSEG_CHECK(d->p.dtype == d->h.dtype, "vsseg_wgrad: dtype mismatch");
@@ -393,12 +438,21 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   int off = 0;
   k.lds_hbase = off; off += ((k.tvox * 4 + 15) / 16) * 16;
   k.nbuf = d->single_buffer ? 1 : 2;
+  const int hchunks = (d->ch_valid + 15) / 16;
+  const int hvox = k.halo[0] * k.halo[1] * k.halo[2];
+  // H-chunk group per workgroup: the requested one (0 = 1), clamped to what the accumulators (maxt*ntp*hg <= 42 tiles), the DMA piece
+  // budget and the LDS allow; a divisor of the chunk count so that every group is whole (partial groups take the slow boundary path)
+  int hg = d->hgroup < 1 ? 1 : (d->hgroup > 4 ? 4 : d->hgroup);
+  const int maxt_t = maxt <= 1 ? 1 : (maxt <= 3 ? 3 : 7);
+  auto lds_need = [&](int g) { return ((k.tvox * 4 + 15) / 16) * 16 + k.nbuf * (k.tvox * k.p_row + hvox * g * 16 * es) + ((k.tvox * (k.p_row >> 4) + 255) / 256 + (hvox * g * es + 255) / 256) * 1024; };
+  while (hg > 1 && (hchunks % hg != 0 || maxt_t * d->ntp * hg > 42 || hvox * hg * 16 * es > WPH * 256 * 16 || lds_need(hg) > 160 * 1024)) --hg;
+  k.hchunks = hchunks;
   k.lds_p = off; off += k.nbuf * k.tvox * k.p_row;                     // double-buffered: tile s+1 streams in by LDS-DMA while tile s is multiplied
-  k.lds_h = off; off += k.nbuf * k.halo[0] * k.halo[1] * k.halo[2] * 16 * es;
+  k.lds_h = off; off += k.nbuf * hvox * hg * 16 * es;
   k.npp = (k.tvox * (k.p_row >> 4) + 255) / 256;
-  k.nph = (k.halo[0] * k.halo[1] * k.halo[2] * es + 255) / 256;
+  k.nph = (hvox * hg * es + 255) / 256;
   k.lds_tab = off; off += (k.npp + k.nph) * 1024;
-  VSSEG_CHECK(k.tvox * k.p_row <= WPP * 256 * 16 && k.halo[0] * k.halo[1] * k.halo[2] * 16 * es <= WPH * 256 * 16, "vsseg_wgrad: tile too large for the DMA piece budget");
+  VSSEG_CHECK(k.tvox * k.p_row <= WPP * 256 * 16 && hvox * hg * 16 * es <= WPH * 256 * 16, "vsseg_wgrad: tile too large for the DMA piece budget");
   for (int a = 0; a < 3; ++a) VSSEG_CHECK(k.halo[a] <= 255 && d->tile[a] <= 255, "vsseg_wgrad: tile/halo extent > 255");
   {
     static void* z = nullptr;
@@ -408,7 +462,6 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   }
   VSSEG_CHECK(k.total_tiles < (1ll << 31), "vsseg_wgrad: too many tiles");
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_wgrad: needs %d bytes of LDS (> 160 KiB); reduce the tile", off);
-  const int hchunks = (d->ch_valid + 15) / 16;
   k.slab_chunk = d->ntaps * d->ntp * 16 * 16;
   VSSEG_CHECK(d->scratch && d->scratch_elems >= (int64_t)hchunks * k.slab_chunk, "vsseg_wgrad: scratch too small (%lld < %lld floats)", (long long)d->scratch_elems, (long long)hchunks * k.slab_chunk);
   int64_t gx = d->persistent_blocks > 0 ? d->persistent_blocks : 256;
@@ -417,11 +470,12 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   if (gx > cap) gx = cap;
   k.slab = d->scratch;
   if (k.wv != 1) hipMemsetAsync(d->scratch, 0, sizeof(float) * gx * hchunks * k.slab_chunk, as_stream(stream));
-  dim3 grid((unsigned)gx, (unsigned)hchunks);
-  int rc = d->p.dtype == VSSEG_F32 ? wg_maxt<float>(k, maxt, grid, off, as_stream(stream)) : wg_maxt<bf16_t>(k, maxt, grid, off, as_stream(stream));
+  dim3 grid((unsigned)gx, (unsigned)(hchunks / hg));
+  int rc = d->p.dtype == VSSEG_F32 ? vsseg_wgrad_launch_f32(k, maxt, hg, grid, off, as_stream(stream)) : vsseg_wgrad_launch_bf16(k, maxt, hg, grid, off, as_stream(stream));
   if (rc) return rc;
   const int total = hchunks * k.slab_chunk;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)d->scratch, (int)grid.x, hchunks, d->ntaps, d->ntp * 16, k.slab_chunk, *d);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
   return VSSEG_OK;
 }
+#endif  // WG_INST

@@ -376,6 +376,12 @@ class Plan:
                     bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
+    def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:
+        """Launch metadata of a streaming kernel: algorithmic bytes = (channels read + written per voxel, summed over its tensor
+        passes) x voxels x element size.  `passes_c` = that per-voxel channel count."""
+        es = self.eng.es if dtype_es is None else dtype_es
+        return dict(name=name, kind="hbm", flops=0.0, bytes=float(self._vox(level)) * passes_c * es, tag=f"L{level} {passes_c} ch/voxel")
+
     # ------------------------------------------------------------------ lowering
     def _lower(self):
         eng, prog, lib, dev = self.eng, self.eng.prog, self.eng.lib, self.eng.device
@@ -432,7 +438,7 @@ class Plan:
                         F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None, yd, sptr(0, pre), cpad[pre]]])
                         F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                           self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
-                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out]])
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out], self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout)])
                     else:
                         self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
                         F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), vptr(2, pre), vptr(3, pre), alp, out, None, 0]])
@@ -444,9 +450,11 @@ class Plan:
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     if fused_res is not None:
                         x1 = self._xdesc(fused_res.x, True)  # compact 1-channel copy of the network input
-                        F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out]])
+                        F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out],
+                                  self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout + 1)])
                     else:
-                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out]])
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out],
+                                  self._ew_meta("bn_act_fwd", Lr.out_level, (3 if res is not None else 2) * Lr.cout)])
                 else:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
                     for ch in cp.fwd:
@@ -468,7 +476,7 @@ class Plan:
                     self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
                                 res_mode=L.RES_ADD if res is not None else L.RES_NONE)
             elif isinstance(op, AttGate):
-                F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)]])
+                F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)], self._ew_meta("att_apply_fwd", op.x.level, 2 * op.x.c + 2)])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
         if any((not self.cplans[op.layer.prefix].fold_fwd) and (not self.cplans[op.layer.prefix].direct_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
@@ -537,16 +545,26 @@ class Plan:
             for a in range(3):
                 tiles *= -(-wg.q[a] // wg.tile[a])
             # few persistent workgroups with many tiles each: the per-workgroup flush is as large as the weight gradient itself
-            d.persistent_blocks = max(1, min(tiles // 4, 1024 // hch))
             scr = self.eng.wgrad_scratch()
             d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
             self.keep.append(d)
             tuned = ""
-            if self.tune:  # double-buffered DMA pipeline vs one buffer and more resident workgroups: measured per launch
-                key = f"wgrad|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}"
+            # H-chunk group: one workgroup multiplies the P tile it fetched with `hgroup` 16-channel chunks of H (P is then read
+            # ceil(chunks / hgroup) times instead of once per chunk); the library clamps the request to a divisor of the chunk count
+            # that fits registers and LDS.  Heuristic: as large as allowed.
+            hgs = [g for g in (4, 3, 2, 1) if hch % g == 0]
+            d.hgroup = hgs[0]
+
+            def set_blocks(wpc):  # persistent workgroups = wpc per CU over all H-chunk groups (the library clamps to what is resident)
+                d.persistent_blocks = max(1, min(tiles, (256 * wpc) // max(1, hch // max(1, d.hgroup))))
+
+            wpc = 4
+            if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU
+                key = f"wgrad2|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}"
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
-                    d.single_buffer, tuned = int(cache[key]), " tuned[cache]"
+                    d.single_buffer, d.hgroup, wpc = (int(v) for v in cache[key])
+                    tuned = " tuned[cache]"
                 else:
                     stream = torch.cuda.current_stream().cuda_stream
                     # measured launches accumulate into a scratch copy of the gradient buffer, never into the live one
@@ -556,25 +574,29 @@ class Plan:
                     live_dw, live_db = d.dw, d.dbias_p
                     d.dw = live_dw + delta
                     d.dbias_p = (live_db + delta) if live_db else None
-                    ms = []
-                    for sb in (0, 1):
-                        d.single_buffer = sb
-                        best = float("inf") if not lib.vsseg_wgrad(C.byref(d), stream) else None
-                        for _ in range(3 if best is not None else 0):
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            lib.vsseg_wgrad(C.byref(d), stream)
-                            e1.record()
-                            e1.synchronize()
-                            best = min(best, e0.elapsed_time(e1))
-                        ms.append(float("inf") if best is None else best)
+                    ms = {}
+                    for hg in hgs:
+                        for sb in (0, 1):
+                            for w in (2, 3, 4):
+                                d.single_buffer, d.hgroup = sb, hg
+                                set_blocks(w)
+                                best = float("inf") if not lib.vsseg_wgrad(C.byref(d), stream) else None
+                                for _ in range(3 if best is not None else 0):
+                                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                    e0.record()
+                                    lib.vsseg_wgrad(C.byref(d), stream)
+                                    e1.record()
+                                    e1.synchronize()
+                                    best = min(best, e0.elapsed_time(e1))
+                                ms[(sb, hg, w)] = float("inf") if best is None else best
                     d.dw, d.dbias_p = live_dw, live_db
-                    d.single_buffer = 1 if ms[1] < 0.97 * ms[0] else 0
-                    cache[key] = d.single_buffer
+                    d.single_buffer, d.hgroup, wpc = min(ms, key=ms.get)
+                    cache[key] = [d.single_buffer, d.hgroup, wpc]
                     _tune_cache.dirty = True
-                    tuned = f" tuned[{ms[0]:.3f}/{ms[1]:.3f}ms]"
+                    tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
+            set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -598,7 +620,8 @@ class Plan:
                 yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
-                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)]])
+                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)],
+                          self._ew_meta("bn_act_bwd_reduce", Lr.out_level, 2 * Lr.cout)])
                 dres_bias = None
                 if op.res is not None and op.res.name in producer:  # residual conv: d(out)/d(res) = 1, its bias gradient is sum(dA) (reduced above)
                     dres_bias = self._gp(producer[op.res.name].layer.bkey)
@@ -606,12 +629,13 @@ class Plan:
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
                 dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd]])
+                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd],
+                          self._ew_meta("bn_act_bwd_apply", Lr.out_level, 3 * Lr.cout)])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
                     if contribution(op.res):
-                        B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA]])
+                        B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA], self._ew_meta("grad_add/copy", Lr.out_level, 3 * Lr.cout)])
                     else:
-                        B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)]])
+                        B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)], self._ew_meta("grad_add/copy", Lr.out_level, 2 * Lr.cout)])
                 conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
             elif isinstance(op, ConvPlain):
                 Lr = op.layer
@@ -642,7 +666,8 @@ class Plan:
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
                 dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if self.cplans[sig.prefix].fold_dgrad else None
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1]])
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
+                          self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + 8 + 4)])
         self._finish_pack()
 
     def _index_slots(self):
