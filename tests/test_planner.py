@@ -169,7 +169,7 @@ def test_z_folded_plans_compute_the_same_convolution(cin, cout, kind):
     # fold: [N,X,Y,Z,C] -> [N,X,Y,Z/8,8*C] is a pure reinterpretation of the channels-last memory
     src_f = _cl(src).reshape(2, dims[0], dims[1], dims[2] // 8, 8 * cs)
     cands = P.folded_candidate_plans(kind, tuple(w.shape), cls, dims, es=2)
-    assert len(cands) >= 2
+    assert len(cands) >= (2 if cands[0].nt <= 2 else 1)  # nt >= 3 (the narrow-input fold: 128 folded output channels) always prefetches: no single-buffer twins
     for pl in cands:
         assert pl.kc == 8 * cs and pl.nc == 8 * cd and pl.q == (8, 8, 2)
         ident = dataclasses.replace(pl)  # simulate_igemm gathers the weights through pack_map itself

@@ -281,12 +281,23 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const 
   const int cg = (int)(gt % cgs);
   const int c = cg * 8;
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
-  for (int64_t v = gt / cgs; v < nvox; v += nthreads / cgs) {
-    f8 yy = ld8(y + v * yp + c), da = ld8(dout + v * dp + c), dz, xh;
+  // two voxels per iteration: four independent 16-byte loads in flight per thread (one pair measured 3.0 TB/s: the kernel is bound by the
+  // bytes in flight, ~90 VGPRs allow 5 waves per SIMD)
+  const int64_t vstep = nthreads / cgs;
+  auto one = [&](const f8& yy, const f8& da, int64_t v) {
+    f8 dz, xh;
     dal += bn_bwd_elem8(yy, da, c, v * cgs + cg, a, alpha, dz, xh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] += dz.v[j]; s2[j] += dz.v[j] * xh.v[j]; s3[j] += da.v[j]; }
+  };
+  int64_t v = gt / cgs;
+  for (; v + vstep < nvox; v += 2 * vstep) {
+    const f8 y0 = ld8(y + v * yp + c), d0 = ld8(dout + v * dp + c);
+    const f8 y1 = ld8(y + (v + vstep) * yp + c), d1 = ld8(dout + (v + vstep) * dp + c);
+    one(y0, d0, v);
+    one(y1, d1, v + vstep);
   }
+  if (v < nvox) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
 #pragma unroll
   for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
@@ -304,7 +315,7 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
   int64_t nv = tensor_voxels(y);
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
-  int grid = grid_for(nv * cgs, blk, 256 * 8);
+  int grid = grid_for((nv * cgs + 1) / 2, blk, 256 * 8);
   size_t lds = (3 * y.c + 1) * sizeof(float);
   DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");

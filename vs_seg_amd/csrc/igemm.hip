@@ -147,6 +147,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.lds_ktab = off; off += ((d->ksteps * 4 * 4 + 15) / 16) * 16;
   k.lds_epi = off; off += 3 * d->nt * 16 * 4;
   k.depth = d->depth < 0 ? 0 : (d->depth == 0 ? 1 : (d->depth > 3 ? 3 : d->depth));  // -1: no prefetch (single buffer); 0: default = 1
+  if (d->nt >= 3 && k.depth < 1) k.depth = 1;  // producer / consumer wave specialisation (igemm_kernel.h) always prefetches
   const int nbuf = k.depth + 1;
   k.lds_w = off; off += k.w_bytes * (d->nchunks > 1 ? nbuf : 1);
   k.h_stride = (k.h_bytes + 1023) / 1024 * 1024;      // ring buffers padded to whole 1 KiB DMA instructions (igemm_kernel.h: unconditional lanes)
@@ -154,7 +155,13 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   k.lds_h = off; off += nbuf * k.h_stride;
   k.lds_aux = off; off += nbuf * k.aux_stride;
   k.npu = (k.h_bytes / 16 + 255) / 256;
-  k.lds_pinfo = off; off += (2 * k.npu + (64 * d->mtw + 255) / 256) * 1024;  // per-thread DMA offset table + slow-path coordinate tables (boundary / partial tiles)
+  {
+    auto magic = [](int dv) { return dv <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)dv - 1) / (unsigned)dv); };  // exact floor(n / dv) = umulhi(n, magic) for n * dv < 2^32; 0 = divisor 1
+    k.mg_ppv = magic(d->ck * es / 16);
+    k.mg_hyz = magic(k.halo[1] * k.halo[2]);
+    k.mg_hz = magic(k.halo[2]);
+  }
+  k.lds_pinfo = off; off += ((d->nt >= 3 ? 0 : 2 * k.npu) + (64 * d->mtw + 255) / 256) * 1024;  // nt >= 3: the DMA pieces are decoded arithmetically, no per-thread tables  // per-thread tables of the DMA pieces (packed halo coordinates, interior byte offsets) + tile-voxel coordinates (partial tiles)
   VSSEG_CHECK(off <= 160 * 1024, "vsseg_igemm: needs %d bytes of LDS (> 160 KiB); reduce ck or the tile", off);
   return off;
 }

@@ -35,6 +35,7 @@ struct IgemmK {
   int cgs;      // 8-channel groups per chunk
   int w_bytes;  // packed weights per chunk
   int h_bytes;  // halo chunk
+  unsigned mg_ppv, mg_hyz, mg_hz;  // ceil(2^32 / d) for d = pieces per halo voxel, HY*HZ, HZ: exact quotients by one v_mul_hi_u32 (piece index -> halo coordinates)
   int h_stride, aux_stride;  // LDS bytes between consecutive ring buffers: h_bytes / aux_bytes rounded up to 1 KiB, so that the lanes of the last (partial)
                              // DMA instruction of a buffer land in its own padding — every lane of every DMA instruction is then issued unconditionally
   int lds_ktab, lds_epi, lds_w, lds_h, lds_aux, lds_pinfo;
@@ -146,8 +147,16 @@ enum { IG_PLAIN = 0, IG_STATS = 1, IG_AUX = 2 };
 #else
 #define IG_TICK(i)
 #endif
-template <typename T, int NT, int MTW, int MODE>
-__global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3 : 2) : 1)) void igemm_kernel(const IgemmK k) {
+// KS > 0: the number of K-steps per chunk is a compile-time constant (the MFMA-bound configurations: 27 taps x 8 / 16 channels): the K loop
+// is fully unrolled, every LDS offset of the weight fragments and of the tap table becomes an instruction immediate and the address /
+// loop-counter arithmetic that cost ~6 VALU + SALU issues per MFMA in the run-time loop disappears.
+// NT >= 3 (the MFMA-bound configurations) run with 8 waves: waves 0-3 are the consumers (fragments + MFMAs + epilogue, exactly the 4-wave
+// tile mapping of the other configurations), waves 4-7 are producers that only issue the LDS-DMA of the stages ahead and wait for it.
+// One consumer and one producer share each SIMD, so the ~100-200 issue cycles of every DMA instruction, its address arithmetic and
+// the DMA latency never sit in the consumer's instruction stream, and the consumer's K loop is one straight block of ds_read / MFMA.
+constexpr bool ig_spec(int nt) { return nt >= 3; }
+template <typename T, int NT, int MTW, int MODE, int KS = 0>
+__global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3 : 2) : 2)) void igemm_kernel(const IgemmK k) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool STATS = MODE == IG_STATS, AUXM = MODE == IG_AUX;
   constexpr int ES = sizeof(T);
@@ -159,12 +168,19 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   char* Wl = smem + k.lds_w;
   char* Hl = smem + k.lds_h;
   char* Al = smem + k.lds_aux;
-  unsigned* pinfo_l = reinterpret_cast<unsigned*>(smem + k.lds_pinfo);  // [u][256] packed halo coordinates of this thread's pieces (boundary tiles only)
+  unsigned* pinfo_l = reinterpret_cast<unsigned*>(smem + k.lds_pinfo);  // [u][256] packed halo coordinates (hx | hy<<8 | hz<<16 | 16-byte piece of the voxel row <<24) of this thread's DMA pieces
   unsigned* vxyz_l = pinfo_l + k.npu * 256;                             // [64*MTW] packed tile coordinates of the tile's voxels (partial tiles only): VROWS rows of 256
   constexpr int VROWS = (64 * MTW + 255) / 256;
   constexpr int AM = amax_for(MTW);
+  // MFMA-bound configurations: the halo coordinates of a DMA piece are recomputed from its index (three multiply-high divisions, ~12 VALU)
+  // instead of being read from a per-thread LDS table: no table (8-16 KiB of LDS that the second weight / halo buffer needs), and no LDS
+  // read — hence no `s_waitcnt lgkmcnt(0)` that would drain the fragment prefetch — when pieces are issued between the MFMAs of the K loop.
+  constexpr bool ARITH = NT >= 3;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
+  constexpr bool SPEC = ig_spec(NT);
+  // `wave` is the index inside the role: consumers 0-3 own voxel tiles (and, without specialisation, DMA pieces), producers 0-3 own DMA pieces
+  const int tid = threadIdx.x & 255, lane = tid & 63, raw_wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), wave = raw_wave & 3, g = lane >> 4, l15 = lane & 15;
+  const bool producer = SPEC && raw_wave >= 4;
   const int split = blockIdx.y;
   const int HY = k.halo[1], HZ = k.halo[2], CK = d.ck;
   const int hvox = k.halo[0] * HY * HZ;
@@ -205,27 +221,29 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   //      and was issue-bound at 1.7 TB/s on the HBM-bound layers).
   const int X = d.in.x, Y = d.in.y, Z = d.in.z;
   const unsigned in_vox_bytes = (unsigned)d.in.pitch * ES;
-  unsigned* prel_l = pinfo_l + (k.npu + VROWS) * 256;  // [npu][256] byte offset of each piece relative to the halo origin voxel (interior tiles); 0xffffffff: no piece
-  unsigned p2mask = 0;   // bit u: piece u lies in part 1 of a two-part input (single-chunk case, see below)
   const bool in_two = d.in.ptr2 != nullptr;
   const int in_csplit = in_two ? d.in.csplit : 0x7fffffff;
+  unsigned* prel_l = pinfo_l + (k.npu + VROWS) * 256;  // [npu][256] interior-tile byte offsets of the same pieces (not ARITH)
+  if (ARITH) vxyz_l = pinfo_l;  // no piece tables: the voxel coordinates are the only rows
 #pragma unroll
   for (int u = 0; u < PMAX; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
-    unsigned info = 0xffffffffu, rel = 0xffffffffu;
+    unsigned info = 0xffffffffu;  // no piece: the lane copies 16 harmless bytes into the padding of the LDS buffer
     if (j < pieces) {
       int hv = j / ppv, c16 = j - hv * ppv;
       int hz = hv % HZ, r = hv / HZ;
       int hy = r % HY, hx = r / HY;
       info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)c16 << 24);
-      rel = (unsigned)((hx * Y + hy) * Z + hz) * in_vox_bytes + (unsigned)c16 * 16u;
-      if (in_two && nch == 1 && c16 * EPP >= in_csplit) p2mask |= 1u << u;
     }
-    if (u < k.npu) { pinfo_l[u * 256 + tid] = info; prel_l[u * 256 + tid] = rel == 0xffffffffu ? 0u : rel; }  // padding lanes copy the tile's first 16 bytes into the buffer's padding
+    if (!ARITH && u < k.npu) {
+      pinfo_l[u * 256 + tid] = info;
+      // interior tiles: byte offset of the piece relative to the halo origin voxel (0 for padding lanes: a valid, harmless source)
+      prel_l[u * 256 + tid] = info == 0xffffffffu ? 0u : (unsigned)((int)(info & 255u) * Y + (int)((info >> 8) & 255u)) * (unsigned)Z * in_vox_bytes + ((info >> 16) & 255u) * in_vox_bytes + (info >> 24) * 16u;
+    }
   }
-  // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  prel/pinfo keep the channel offset of the
+  // Two-part input (skip-connection concat): channels >= csplit come from in.ptr2.  pinfo keeps the channel offset of the
   // virtual concatenated row; part 1's base is biased by -csplit channels so the same offsets address it.  A chunk never
-  // straddles the split unless it is the only chunk (checked on the host), so the per-piece choice is static per thread.
+  // straddles the split unless it is the only chunk (checked on the host): then the part is chosen per piece.
   const int OX = d.out.x, OY = d.out.y, OZ = d.out.z;
   int vb[MTW];
   unsigned ovrel[MTW];  // output voxel index relative to the tile's first output voxel
@@ -324,15 +342,25 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   if (gate_dma && wave == 0) ++na;
   if (nch > 1)
     for (int j0 = wave * 64; j0 < wpieces; j0 += 256) ++nw;
+  if (SPEC && !producer) nh = na = nw = 0;  // consumers issue no DMA
   // store instructions a wave issues in the fast epilogue of one tile (exactly one 8/16-byte store per valid 16-channel
   // block and M tile; the scalar-store variant and the slow epilogue count as 0 = their stores are simply waited for)
   int nst_fast = 0;
-  if (vec_store) {
+  if (vec_store && !producer) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) nst_fast += (split * NT * 16 + t * 16 < cout) ? MTW : 0;
   }
   int st_h0 = 0, st_h1 = 0, st_h2 = 0;
-  auto issue = [&](int s) {  // LDS-DMA of stage s (halo chunk, and the weight chunk when weights are not resident)
+  // ---- LDS-DMA of one stage (halo chunk, auxiliary tile, weight chunk when the weights are not resident) ----
+  // issue_setup() fixes the stage's wave-uniform addresses; halo_piece() / weight_piece() issue one 1 KiB instruction each; issue() =
+  // all of a stage.  In the specialised kernels only the producer waves call it (tools/prof_phases.sh measured 2 800 of 7 900 cycles per
+  // stage spent issuing DMAs in front of the K loop when every wave did both jobs).
+  const char *pi_org = nullptr, *pi_org1 = nullptr, *pi_wsrc = nullptr;
+  char *pi_hdst = nullptr, *pi_wdst = nullptr;
+  int pi_g0x = 0, pi_g0y = 0, pi_g0z = 0, pi_c0 = 0;
+  bool pi_interior = false;
+  const bool piece_select = in_two && nch == 1;  // the only chunk spans both parts of a two-part input: the part is chosen per piece
+  auto issue_setup = [&]() {
     const int ch = ch_issue;
     const TileDesc td = td_next;
     if (++ch_issue == nch) {
@@ -341,52 +369,19 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       if (ti_issue < my_tiles) td_next = load_tile(tiles + (int64_t)ti_issue * S);  // uniform address: scalar loads, consumed a whole stage later
     }
     const int c0 = ch * CK;
-    char* Hdst = Hl + buf_issue * k.h_stride;
-    const bool interior = (td.flags & 1) && c0 + CK <= d.in.c;
-    if (interior) {
-      // Interior tile: every DMA source is origin + a per-thread constant.  The constants are fetched from the LDS table in one
-      // batch (one wait instead of one per piece) and every lane of every instruction is issued — lanes beyond the last piece
-      // re-read the tile's first bytes into the buffer's padding — so the loop below is straight-line code: no exec masking.
+    pi_c0 = c0;
+    pi_hdst = Hl + buf_issue * k.h_stride;
+    pi_interior = (td.flags & 1) && c0 + CK <= d.in.c;
+    if (pi_interior) {  // every source is origin + a per-thread constant derived from the packed halo coordinates
       const int64_t ooff = td.in_vox * in_vox_bytes + (int64_t)c0 * ES;
-      const char* origin = in_base + ooff;
-      unsigned rel[PMAX];
-#pragma unroll
-      for (int u = 0; u < PMAX; ++u)
-        if (u < k.npu) rel[u] = prel_l[u * 256 + tid];
-      if (!in_two || nch > 1) {  // one source tensor for the whole chunk
-        const char* org = (in_two && c0 >= in_csplit) ? in_base1 + ooff : origin;
-#pragma unroll
-        for (int u = 0; u < PMAX; ++u) {
-          if (u >= nh) break;  // wave-uniform
-          dma16(org + rel[u], Hdst + (u * 4 + wave) * 1024);
-        }
-      } else {  // the only chunk spans both parts of a two-part input: static per-thread choice per piece
-        const char* origin1 = in_base1 + ooff;
-#pragma unroll
-        for (int u = 0; u < PMAX; ++u) {
-          if (u >= nh) break;
-          dma16(((p2mask >> u) & 1u ? origin1 : origin) + rel[u], Hdst + (u * 4 + wave) * 1024);
-        }
-      }
+      pi_org = in_base + ooff;
+      pi_org1 = in_base1 + ooff;
+      if (in_two && nch > 1 && c0 >= in_csplit) pi_org = pi_org1;  // the whole chunk lies in part 1
     } else {
-      const int gx0 = td.g0[0], gy0 = td.g0[1], gz0 = td.g0[2];
+      pi_g0x = td.g0[0]; pi_g0y = td.g0[1]; pi_g0z = td.g0[2];
       const int64_t soff = (int64_t)td.n * in_sample_bytes + (int64_t)c0 * ES;
-      const char* sample = in_base + soff;
-      const char* sample1 = in_base1 + soff;
-      unsigned inf[PMAX];
-#pragma unroll
-      for (int u = 0; u < PMAX; ++u)
-        if (u < k.npu) inf[u] = pinfo_l[u * 256 + tid];
-#pragma unroll
-      for (int u = 0; u < PMAX; ++u) {
-        if (u >= nh) break;
-        const unsigned info = inf[u];
-        const int gx = gx0 + (int)(info & 255u), gy = gy0 + (int)((info >> 8) & 255u), gz = gz0 + (int)((info >> 16) & 255u);
-        const int c = c0 + (int)(info >> 24) * EPP;
-        const bool ok = info != 0xffffffffu && (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
-        const void* src = ok ? (const void*)((c >= in_csplit ? sample1 : sample) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + (info >> 24) * 16u) : k.zeros;
-        dma16(src, Hdst + (u * 4 + wave) * 1024);
-      }
+      pi_org = in_base + soff;
+      pi_org1 = in_base1 + soff;
     }
     if constexpr (AUXM) if (ch == 0) {
       // partial tiles use the slow epilogue (ordinary loads) but still issue the same number of DMAs (from the zero page),
@@ -406,13 +401,60 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
       if (++abuf_issue == nbuf) abuf_issue = 0;
     }
     if (nch > 1) {
-      const char* wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
-      char* Wdst = Wl + buf_issue * k.w_bytes;
-      for (int j0 = wave * 64; j0 < wpieces; j0 += 256) dma16(wsrc + (int64_t)(j0 + lane) * 16, Wdst + j0 * 16);  // w_bytes is a multiple of 1 KiB: no partial instruction
+      pi_wsrc = reinterpret_cast<const char*>(d.wpack) + ((int64_t)split * nch + ch) * k.w_bytes;
+      pi_wdst = Wl + buf_issue * k.w_bytes;
     }
     if (++buf_issue == nbuf) buf_issue = 0;
   };
-
+  // `word` = the piece's entry of the table the stage uses: the byte offset (interior tiles) or the packed coordinates (boundary tiles)
+  auto halo_piece = [&](int u, unsigned word) {  // every lane issues: lanes beyond the last piece copy 16 harmless bytes into the buffer's padding
+    char* dst = pi_hdst + (u * 4 + wave) * 1024;
+    if constexpr (ARITH) {  // word is ignored: packed coordinates from the piece index
+      const unsigned j = (unsigned)((u * 4 + wave) * 64 + lane);
+      auto divm = [](unsigned n, unsigned mg) { return mg ? __umulhi(n, mg) : n; };  // mg == 0: divisor 1
+      const unsigned hv = divm(j, k.mg_ppv), c16 = j - hv * (unsigned)ppv;
+      const unsigned hx = divm(hv, k.mg_hyz), r = hv - hx * (unsigned)(HY * HZ);
+      const unsigned hy = divm(r, k.mg_hz), hz = r - hy * (unsigned)HZ;
+      word = (int)j < pieces ? (hx | (hy << 8) | (hz << 16) | (c16 << 24)) : 0xffffffffu;
+      if (pi_interior && !piece_select) {
+        dma16(pi_org + (word == 0xffffffffu ? 0u : ((hx * (unsigned)Y + hy) * (unsigned)Z + hz) * in_vox_bytes + c16 * 16u), dst);
+        return;
+      }
+    }
+    if (pi_interior && !piece_select) {
+      dma16(pi_org + word, dst);  // scalar base + 32-bit per-lane byte offset
+    } else if (pi_interior) {  // the only chunk spans both parts of a two-part input: the part is chosen per piece from its packed coordinates
+      const unsigned c16 = word >> 24;
+      const unsigned rel = word == 0xffffffffu ? 0u : (((word & 255u) * (unsigned)Y + ((word >> 8) & 255u)) * (unsigned)Z + ((word >> 16) & 255u)) * in_vox_bytes + c16 * 16u;
+      dma16(((int)(c16 * EPP) >= in_csplit && word != 0xffffffffu ? pi_org1 : pi_org) + rel, dst);
+    } else {
+      const unsigned hx = word & 255u, hy = (word >> 8) & 255u, hz = (word >> 16) & 255u, c16 = word >> 24;
+      const int gx = pi_g0x + (int)hx, gy = pi_g0y + (int)hy, gz = pi_g0z + (int)hz;
+      const int c = pi_c0 + (int)c16 * EPP;
+      const bool ok = word != 0xffffffffu && (unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z && c + EPP <= d.in.c;
+      const void* src = ok ? (const void*)((c >= in_csplit ? pi_org1 : pi_org) + (int64_t)((gx * Y + gy) * Z + gz) * in_vox_bytes + c16 * 16u) : k.zeros;
+      dma16(src, dst);
+    }
+  };
+  auto weight_piece = [&](int i) {  // w_bytes is a multiple of 1 KiB: no partial instruction
+    const int j0 = wave * 64 + i * 256;
+    dma16(pi_wsrc + (int64_t)(j0 + lane) * 16, pi_wdst + j0 * 16);
+  };
+  auto issue = [&]() {  // the whole stage at once; the packed coordinates of piece u+1 are read from the LDS table while piece u is issued
+    issue_setup();
+    if constexpr (ARITH) {
+      for (int u = 0; u < nh; ++u) halo_piece(u, 0u);
+    } else {
+      const unsigned* tab = (pi_interior && !piece_select) ? prel_l : pinfo_l;
+      unsigned word = nh > 0 ? tab[tid] : 0u;
+      for (int u = 0; u < nh; ++u) {  // wave-uniform trip count
+        const unsigned nxt = tab[(u + 1 < nh ? u + 1 : u) * 256 + tid];
+        halo_piece(u, word);
+        word = nxt;
+      }
+    }
+    for (int i = 0; i < nw; ++i) weight_piece(i);
+  };
   f32x4 acc[MTW][NT];
   float ssum[STATS ? NT : 1][4], ssq[STATS ? NT : 1][4];
 #pragma unroll
@@ -424,14 +466,17 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
 #ifdef VSSEG_IG_PROF
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_amdgcn_s_memtime();
 #endif
-  for (int j = 0; j < D && j < nstages; ++j) issue(j);  // stages 0..D-1 in flight
+  if (!SPEC || producer)
+    for (int j = 0; j < D && j < nstages; ++j) issue();  // stages 0..D-1 in flight
   for (int s = 0; s < nstages; ++s) {
     IG_TICK(5)
     // Stage s has landed once at most the DMAs of the younger stages s+1..s+D-1 remain (VMEM ops complete in issue order).  The
     // epilogue stores issued after those DMAs are ignored in the count, which only makes the wait conservative.
     // Also younger than stage s's DMAs, and still allowed to be in flight: the output stores of the last D stages (vmcnt retires
     // loads and stores of a wave in issue order).  Waiting for them too would put a write-acknowledge latency into every stage.
-    if (D == 0) {
+    if (SPEC && !producer) {
+      // consumer: nothing of its own to wait for — the producers wait for the stage's DMA before the barrier below
+    } else if (D == 0) {
       // No prefetch, one LDS buffer: the workgroup is half the LDS size, so twice as many share a CU and overlap each other's
       // load and compute phases instead (what the streaming kernels do with plain occupancy).
       if (s > 0) {
@@ -439,7 +484,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
         __builtin_amdgcn_s_barrier();  // every wave is done reading the previous stage's tile
       }
       IG_TICK(0)
-      issue(s);
+      issue();
       IG_TICK(1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       IG_TICK(2)
@@ -456,7 +501,11 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would drain the DMA queue (vmcnt(0)) and serialise the ring
     IG_TICK(3)
-    if (D > 0 && s + D < nstages) issue(s + D);  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
+    if ((!SPEC || producer) && D > 0 && s + D < nstages) issue();  // refill the ring slot everybody finished reading before this barrier (stage s-1's)
+    if (producer) {  // on to the next stage's wait (one barrier per stage in both roles)
+      if (++ch_cur == nch) ch_cur = 0;
+      continue;
+    }
     const TileDesc tc = load_tile(tiles + (int64_t)ti_cur * S);  // this stage's tile (scalar load, consumed in the epilogue)
     const int ch = ch_cur;
     if (ch == 0) {
@@ -488,44 +537,49 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
         }
       }
     } else
-    {  // K loop, software-pipelined by hand with two fragment sets (no register moves): the fragments of K-step ks+1 are
-       // read from LDS before the MFMAs of ks issue (with 1-2 waves per SIMD nothing else hides the ds_read -> MFMA latency)
-      Frag<T> w0[NT], a0[MTW], w1[NT], a1[MTW];
+    {  // K loop of the MFMA-bound configurations.  ONE set of voxel (A) fragments, rotated in place: right after the NT MFMAs that use
+       // a[m] its registers are reloaded with the next K-step's fragment, whose LDS latency is then covered by the MFMAs of the other
+       // MTW-1 voxel tiles; the weight (W) fragments are used by every voxel tile of a step, so those alternate between two sets.
+       // (Two full A sets cost 4*MTW more VGPRs — MTW 8 spilled — and hipcc collapsed them into one quad anyway.)
+      Frag<T> wa[NT], wb[NT], a[MTW];
       const char* Wlane = Ws + lane * GB;
-      const int nks = d.ksteps;
+      const int nks = KS > 0 ? KS : d.ksteps;
+      int ko1 = ktab[(nks > 1 ? 1 : 0) * 4 + g], ko2 = ktab[(nks > 2 ? 2 : 0) * 4 + g];  // tap offsets a whole step ahead of the reads that need them
       {
         const int koff = ktab[g];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + t * 64 * GB);
+        for (int t = 0; t < NT; ++t) wa[t] = Frag<T>::ld(Wlane + t * 64 * GB);
 #pragma unroll
-        for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
+        for (int m = 0; m < MTW; ++m) a[m] = Frag<T>::ld(Hs + vb[m] + koff);
       }
-      for (int ks = 0; ks < nks; ks += 2) {
-        const bool has1 = ks + 1 < nks;
-        if (has1) {
-          const int koff = ktab[(ks + 1) * 4 + g];
+      // one K-step: MFMAs with the current W set `wc`, reloading a[m] (offset `kon`) and filling the other W set `wn` for step ks+1
+      auto kstep = [&](const Frag<T>(&wc)[NT], Frag<T>(&wn)[NT], int ks, int kon) {
+        const bool more = ks + 1 < nks;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) w1[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
+        for (int m = 0; m < MTW; ++m) {
+          if (more && m < NT) wn[m] = Frag<T>::ld(Wlane + ((ks + 1) * NT + m) * 64 * GB);  // the next step's weights, one fragment per voxel tile (MTW >= NT is not required: see below)
 #pragma unroll
-          for (int m = 0; m < MTW; ++m) a1[m] = Frag<T>::ld(Hs + vb[m] + koff);
-        }
-#pragma unroll
-        for (int m = 0; m < MTW; ++m)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) mma(acc[m][t], w0[t], a0[m]);
-        if (has1) {
-          if (ks + 2 < nks) {
-            const int koff = ktab[(ks + 2) * 4 + g];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) w0[t] = Frag<T>::ld(Wlane + ((ks + 2) * NT + t) * 64 * GB);
-#pragma unroll
-            for (int m = 0; m < MTW; ++m) a0[m] = Frag<T>::ld(Hs + vb[m] + koff);
+          for (int t = 0; t < NT; ++t) mma(acc[m][t], wc[t], a[m]);
+          if (more) a[m] = Frag<T>::ld(Hs + vb[m] + kon);
+#ifdef VSSEG_IG_SGB
+          if constexpr (sizeof(T) == 2) {  // pin the interleave
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           }
-#pragma unroll
-          for (int m = 0; m < MTW; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) mma(acc[m][t], w1[t], a1[m]);
+#endif
         }
+        if (more && MTW < NT) {
+#pragma unroll
+          for (int t = MTW; t < NT; ++t) wn[t] = Frag<T>::ld(Wlane + ((ks + 1) * NT + t) * 64 * GB);
+        }
+      };
+#pragma unroll(KS > 0 ? 16 : 1)
+      for (int ks = 0; ks < nks; ks += 2) {
+        const int ko1n = ktab[(ks + 3 < nks ? ks + 3 : 0) * 4 + g], ko2n = ktab[(ks + 4 < nks ? ks + 4 : 0) * 4 + g];
+        kstep(wa, wb, ks, ko1);
+        if (ks + 1 < nks) kstep(wb, wa, ks + 1, ko2);
+        ko1 = ko1n; ko2 = ko2n;
       }
     }
     st_h2 = st_h1; st_h1 = st_h0; st_h0 = 0;  // store instructions of the last three stages (this stage's are added below)
@@ -677,14 +731,14 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
         float s = ssum[t][r], q = ssq[t][r];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l15 == 0) {
+        if (l15 == 0 && !producer) {
           atomicAdd(&red[t * 16 + g * 4 + r], s);
           atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
         }
       }
     __syncthreads();
     double* st = d.stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * d.stats_stride;
-    for (int i = tid; i < 2 * NT * 16; i += 256) {
+    for (int i = tid + (producer ? 1 << 20 : 0); i < 2 * NT * 16; i += 256) {  // consumers only (the producer half would add the sums a second time)
       int which = i / (NT * 16), cc = i - which * NT * 16;
       int c = split * NT * 16 + cc;
       if (c < cout) atomicAdd(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)red[i]);
@@ -692,17 +746,21 @@ __global__ __launch_bounds__(256, NT == 1 ? 4 : (NT == 2 ? (MODE == IG_PLAIN ? 3
   }
 }
 
-template <typename T, int NT, int MTW, int MODE> static int launch_mode(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
+template <typename T, int NT, int MTW, int MODE, int KS = 0> static int launch_mode(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
+  if constexpr (KS == 0 && NT >= 3 && NT <= 4 && MODE != IG_AUX) {  // unrolled K loops of the hot MFMA-bound shapes (3x3x3 taps, 8 / 16-channel chunks)
+    if (k.d.ksteps == 14) return launch_mode<T, NT, MTW, MODE, 14>(k, grid, lds, s);
+    if (k.d.ksteps == 7) return launch_mode<T, NT, MTW, MODE, 7>(k, grid, lds, s);
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, MTW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, MTW, MODE, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   // persistent grid = resident workgroups only (registers AND LDS), otherwise the late workgroups form a tail
   static int cached_lds = -1, cached_per_cu = 1;
   if (cached_lds != lds) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW, MODE>, 256, lds) != hipSuccess || n < 1) n = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW, MODE, KS>, ig_spec(NT) ? 512 : 256, lds) != hipSuccess || n < 1) n = 1;
     cached_per_cu = n > 6 ? 6 : n;
     cached_lds = lds;
     if (const char* e = getenv("VSSEG_IG_PERCU")) {  // tuning aid: cap the resident workgroups per CU (occupancy scaling experiments)
@@ -713,7 +771,7 @@ template <typename T, int NT, int MTW, int MODE> static int launch_mode(const Ig
   int64_t gx = 256ll * cached_per_cu;
   if (gx > k.total_tiles) gx = k.total_tiles;
   grid.x = (unsigned)gx;
-  hipLaunchKernelGGL((igemm_kernel<T, NT, MTW, MODE>), grid, dim3(256), lds, s, k);
+  hipLaunchKernelGGL((igemm_kernel<T, NT, MTW, MODE, KS>), grid, dim3(ig_spec(NT) ? 512 : 256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_igemm");
   return VSSEG_OK;
 }

@@ -136,7 +136,7 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
     nbuf = max(depth, 0) + 1  # depth -1: no prefetch, single buffer
     aux = nbuf * round_up(64 * mtw * nt * 16 * aux_es + 64 * mtw * 4, 1024) if (aux_es and 64 * mtw * nt * aux_es <= (12 if mtw == 8 else 8) * 256) else 0  # DMA-prefetched residual / accumulate tile (AMAX pieces per thread) + gate floats
     hb = igemm_halo_bytes(tile, is_, taps, ck, es)
-    tables = (2 * ((hb // 16 + 255) // 256) + (64 * mtw + 255) // 256) * 1024  # per-thread DMA offset table + coordinate tables of the boundary-tile paths
+    tables = ((0 if nt >= 3 else 2 * ((hb // 16 + 255) // 256)) + (64 * mtw + 255) // 256) * 1024  # per-thread tables of the DMA pieces (nt <= 2 only) + tile-voxel coordinates
     return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * round_up(hb, 1024) + aux + tables  # ring buffers padded to whole 1 KiB DMA instructions
 
 
@@ -201,13 +201,11 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
         for nsplit in sorted({nsplit0, min(nt_total, 2 * nsplit0), min(nt_total, 3 * nsplit0)}):  # fewer channel tiles per workgroup when the weights do not fit
             nt = (nt_total + nsplit - 1) // nsplit
             for mtw_ in mtws:  # a smaller voxel tile when even the smallest channel chunk does not fit (stride-2 3x3x3 halos in fp32)
-                if (nt >= 5 and mtw_ >= 4) or (mtw_ == 8 and nt < 3):  # the kernel instantiates 512-voxel tiles for 3-4 channel tiles per workgroup only
+                if (nt >= 5 and mtw_ >= 4) or (mtw_ == 8 and (nt < 3 or aux_es)):  # 512-voxel tiles: 3-4 channel tiles per workgroup, no auxiliary tile (it would not fit twice)
                     continue
                 tile = choose_tile(q, cls.taps, 64 * mtw_)
                 for ck in cands:
                     pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw_, nt, nsplit, ck, aux_es)
-                    if pl is None and mtw_ == 8 and budget > lds_budget:  # 512-voxel tiles: a single LDS buffer (no prefetch) when two do not fit
-                        pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw_, nt, nsplit, ck, aux_es, depth=-1)
                     if pl is not None and pl.lds <= budget:
                         best = pl
                         break
@@ -244,7 +242,7 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
         if nt > 6:
             continue
         for mtw in (8, 4, 2):
-            if (nt >= 5 and mtw >= 4) or nvox < 512 * (mtw // 2) or (mtw == 8 and (nt < 3 or nvox < 512 * 256)):  # 512-voxel tiles: MFMA-bound layers with >= one tile per CU
+            if (nt >= 5 and mtw >= 4) or nvox < 512 * (mtw // 2) or (mtw == 8 and (nt < 3 or aux_es or nvox < 512 * 256)):  # 512-voxel tiles: MFMA-bound layers with >= one tile per CU
                 continue
             tile = choose_tile(q, cls.taps, 64 * mtw)
             for ck in cks:
@@ -252,8 +250,6 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
                 if key in seen:
                     continue
                 pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw, nt, nsplit, ck, aux_es)
-                if pl is None and mtw == 8:  # 512-voxel tiles with a large channel chunk only fit with one LDS buffer (no prefetch)
-                    pl = _mk_plan(kind, wshape, cls, q, es, kc, nreal, kreal, tile, mtw, nt, nsplit, ck, aux_es, depth=-1)
                 if pl is None:
                     continue
                 seen.add(key)
@@ -264,7 +260,7 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     # workgroup: 32->16 full-res 0.85 -> 0.78 ms, 64->32 half-res 0.86 -> 0.61 ms (tools/sweep_depth0.sh)
     twins = []
     for pl in [default] + rest:
-        if pl.depth == -1:
+        if pl.depth == -1 or pl.nt >= 3:  # nt >= 3 runs producer / consumer waves: always at least double-buffered
             continue
         if pl.nt <= 2 or pl.mtw <= 2 or pl.mtw == 8:  # register budget allows a second resident workgroup (512-voxel tiles: one buffer is all that fits)
             lds = igemm_lds_bytes(pl.tile, cls.is_, cls.taps, pl.ck, pl.ksteps, pl.nt, pl.mtw, es, pl.nchunks, aux_es, -1)
