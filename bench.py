@@ -247,20 +247,27 @@ def main():
         model.eval()
         vol = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal((1, 1, 512, 512, 120), dtype=np.float32)).to(dev)
         pred = lambda w: model(w)[0]  # noqa: E731
-        with torch.no_grad():
-            V.sliding_window_inference(vol, PATCH, 1, pred, overlap=0.5, mode="gaussian")
-            barrier()
-            s0 = time.perf_counter()
-            for _ in range(args.swi_volumes):
-                out = V.sliding_window_inference(vol, PATCH, 1, pred, overlap=0.5, mode="gaussian")
-            barrier()
-            sdt = time.perf_counter() - s0
-        if world > 1:
-            t = torch.tensor([sdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            sdt = float(t)
+        def time_swi(swb):
+            with torch.no_grad():
+                V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian")
+                barrier()
+                s0 = time.perf_counter()
+                for _ in range(args.swi_volumes):
+                    V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian")
+                barrier()
+                sdt = time.perf_counter() - s0
+            if world > 1:
+                t = torch.tensor([sdt], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                sdt = float(t)
+            return sdt
+
+        sdt = time_swi(1)  # the reference's setting (ref:params/VSparams.py:571)
         swi = dict(volumes_per_sec=args.swi_volumes * world / sdt, ms_per_volume=1e3 * sdt / args.swi_volumes, volume="512x512x120", roi="384x128x128", overlap=0.5, windows=14, sw_batch_size=1,
                    mode="gaussian", sharding="volumes round-robin over ranks")
+        for swb in (2, 4):  # the same blend with 2 / 4 windows per predictor call (identical result: eval-mode BatchNorm has no cross-sample term)
+            t = time_swi(swb)
+            swi[f"sw_batch_size_{swb}"] = dict(volumes_per_sec=args.swi_volumes * world / t, ms_per_volume=1e3 * t / args.swi_volumes)
         model.train()
 
     # ---- BASELINE config 5: a TCIA-shaped synthetic T2 set, cases sharded over ranks, Dice scores all-gathered (timed with the gather)

@@ -36,6 +36,8 @@ extern "C" {
 #define VSSEG_RES_GATE 3     /* out = acc + res * (1 + gate[voxel])     (backward of AttentionBlock2 `att*x + x`, ref:.../attentionblock.py:43-47, fused
                               *  into the data gradient of the attention branch's first convolution: both flow into d(x))                          */
 
+#define VSSEG_SEED_INDIRECT 0x80000000u /* OR-ed into a dropout `salt`: the `seed` argument is then the DEVICE ADDRESS of the 64-bit seed */
+
 #define VSSEG_MAX_TAPS 27
 #define VSSEG_STAT_SHARDS 256
 
@@ -140,7 +142,8 @@ int vsseg_bn_finalize(const double* stats, int32_t stride, int32_t c, double cou
 int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int32_t c, void* stream);
 
 /* out = PReLU(dropout(y*scale+shift)) [+ res]   (ref:.../convolutions.py:148-156; residual add :252-255).
- * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables. */
+ * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables.  salt | VSSEG_SEED_INDIRECT: `seed` holds the
+ * device address of the seed (every dropout entry point), so that a launch list with fixed arguments can be replayed with a new seed. */
 int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
                      vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
 /* Same with the residual computed on the fly as the 1x1x1 convolution of a ONE-channel tensor: res[v][c] = x1[v]*res_w[c] + res_b[c]
@@ -169,6 +172,7 @@ int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, con
                         void* dpre1 /* optional compact [N,X,Y,Z] copy of channel 0 of dpre (x's dtype), or NULL */, void* stream);
 
 /* generic helpers */
+int vsseg_store_u64(uint64_t* dst, uint64_t value, void* stream);                 /* *dst = value by a one-thread kernel (the per-step dropout seed of a replayed launch list) */
 int vsseg_memset_zero(void* dst, int64_t bytes, void* stream);                    /* hipMemsetAsync(dst, 0, bytes) on the caller's stream */
 int vsseg_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream);    /* device-to-device hipMemcpyAsync */
 int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);

@@ -20,7 +20,7 @@ def short(name):
 def bench_name(short_name):
     """rocprof kernel name -> the name bench.py uses for its roofline block (igemm<bf16,NT,MTW>, wgrad<bf16,NTP>)."""
     import re
-    m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+), \d+>", short_name)  # the MODE variants of one (type, NT, MTW) share a bench name
+    m = re.match(r"igemm_kernel<(bf16|float), (\d+), (\d+), \d+(, \d+)?>", short_name)  # the MODE / unrolled-K variants of one (type, NT, MTW) share a bench name
     if m:
         return f"igemm<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(2)},{m.group(3)}>"
     m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)(, \d+)?>", short_name)  # MAXT / H-group variants of one (type, NTP) share a bench name
@@ -69,9 +69,35 @@ def pmc(fetch_db, write_db):
     return res
 
 
+def sq(dbs):
+    """Per-kernel-group averages of the SQ counters (MFMA busy fraction, instruction mix per MFMA, wave-cycle breakdown, LDS bank conflicts)."""
+    agg = {}
+    for db in dbs:
+        cur = sqlite3.connect(db).cursor()
+        for n, cn, c, v in cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+            a = agg.setdefault(bench_name(short(n)), {})
+            a[cn] = a.get(cn, 0.0) + v
+            a["launches:" + cn] = a.get("launches:" + cn, 0) + c
+    rows = []
+    for k, a in agg.items():
+        busy = a.get("SQ_BUSY_CU_CYCLES", 0.0)
+        mf = a.get("SQ_INSTS_MFMA", 0.0)
+        wc = a.get("SQ_WAVE_CYCLES", 0.0)
+        rows.append((busy, k, a, mf, wc))
+    print(f"{'kernel group':34s} {'launches':>8s} {'MFMA busy / (4 SIMD x CU busy)':>32s} {'VALU/MFMA':>10s} {'SALU/MFMA':>10s} {'LDS/MFMA':>9s} {'wait%':>7s} {'stall%':>7s} {'issue%':>7s} {'LDS conflict%':>14s}")
+    for busy, k, a, mf, wc in sorted(rows, key=lambda r: -r[0])[:40]:
+        frac = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * busy) if busy else 0.0
+        per = lambda c: (a.get(c, 0.0) / mf) if mf else float("nan")  # noqa: E731
+        pc = lambda c: (100.0 * a.get(c, 0.0) / wc) if wc else float("nan")  # noqa: E731
+        conf = 100.0 * a.get("SQ_LDS_BANK_CONFLICT", 0.0) / a["SQ_LDS_IDX_ACTIVE"] if a.get("SQ_LDS_IDX_ACTIVE") else float("nan")
+        print(f"{k[:34]:34s} {a.get('launches:SQ_BUSY_CU_CYCLES', 0):8d} {frac:32.3f} {per('SQ_INSTS_VALU') - (1 if mf else 0):10.2f} {per('SQ_INSTS_SALU'):10.2f} {per('SQ_INSTS_LDS'):9.2f} {pc('SQ_WAIT_ANY'):7.1f} {pc('SQ_WAIT_INST_ANY'):7.1f} {pc('SQ_ACTIVE_INST_ANY'):7.1f} {conf:14.1f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel_stats(sys.argv[2])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2:])
     else:
         r = pmc(sys.argv[2], sys.argv[3])
         if len(sys.argv) > 4:

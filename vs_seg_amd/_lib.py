@@ -15,6 +15,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELUMASK, RES_GATE = 0, 1, 2, 3
 MAX_TAPS = 27
 STAT_SHARDS = 256
+SEED_INDIRECT = 0x80000000
 EINVAL, ELAUNCH = -1, -2
 
 
@@ -97,7 +98,7 @@ class WgradDesc(C.Structure):
 
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_conv1ch_fwd", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_conv1ch_fwd", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -121,6 +122,7 @@ def lib():
                 fn.restype = C.c_int
         vp, i32, i64, f32, f64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_uint32
         I3 = C.POINTER(C.c_int32)
+        L.vsseg_store_u64.argtypes = [vp, u64, vp]
         L.vsseg_memset_zero.argtypes = [vp, i64, vp]
         L.vsseg_copy_bytes.argtypes = [vp, vp, i64, vp]
         L.vsseg_crop_flip.argtypes = [vp, i32, vp, I3, vp]

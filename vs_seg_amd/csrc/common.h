@@ -101,7 +101,13 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
 }
 // keep-mask for the 8 elements [8*i8, 8*i8+8) of a layer's activation tensor (logical [voxel][c] order, pitch-free):
 // one Philox call = 128 random bits = eight 16-bit draws, keep iff draw >= round(p * 2^16)
+// salt | VSSEG_SEED_INDIRECT: `seed` is the device address of the 64-bit seed instead of its value (a launch list with fixed kernel
+// arguments — a captured hipGraph — then draws new masks every step from a seed the host stores with vsseg_store_u64)
 __device__ __forceinline__ unsigned dropout_keep8(uint64_t seed, uint32_t salt, uint64_t i8, float p) {
+  if (salt & VSSEG_SEED_INDIRECT) {
+    seed = *reinterpret_cast<const uint64_t*>(seed);
+    salt &= ~VSSEG_SEED_INDIRECT;
+  }
   uint4 r = philox4x32_10(make_uint4((unsigned)i8, (unsigned)(i8 >> 32), salt, 0u), make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
   const unsigned thr = (unsigned)(p * 65536.0f + 0.5f);
   unsigned m = 0;

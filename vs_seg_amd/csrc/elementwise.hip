@@ -50,6 +50,14 @@ extern "C" int vsseg_gather_cast(const float* src, const int32_t* map, const int
   return VSSEG_OK;
 }
 
+__global__ void store_u64_kernel(uint64_t* dst, uint64_t value) { *dst = value; }
+extern "C" int vsseg_store_u64(uint64_t* dst, uint64_t value, void* stream) {
+  VSSEG_CHECK(dst, "vsseg_store_u64: null pointer");
+  hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, as_stream(stream), dst, value);
+  VSSEG_LAUNCH_CHECK("vsseg_store_u64");
+  return VSSEG_OK;
+}
+
 template <typename T> __global__ void stage_input_kernel(const float* __restrict__ src, int n, int sx, int sy, int sz, int ox, int oy, int oz, vsseg_tensor dst) {
   const int64_t per = (int64_t)dst.x * dst.y * dst.z, total = per * n;
   T* out = reinterpret_cast<T*>(dst.ptr);

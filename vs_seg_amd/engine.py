@@ -120,7 +120,6 @@ class _Slot:
         self.kind, self.name = kind, name
 
 
-SEED = _Slot("seed")
 
 
 class Plan:
@@ -139,6 +138,15 @@ class Plan:
         self.flat_ptr = eng.flat.data_ptr()
         self.timer = None  # set to {'only': set|None, 'events': []} to time launches with HIP events
         self.generation = 0  # bumped by every training forward: a backward belongs to exactly one forward of this plan
+        # The launch lists have FIXED kernel arguments (the dropout seed is read from `seed_dev`, external gradients are staged into
+        # plan-owned buffers), so after two eager warm-up runs each list is captured in a hipGraph and replayed: one host call per list
+        # instead of ~100-230 ctypes launches (VSSEG_GRAPHS=0 keeps the eager loop; the event-timed profiling mode always runs eagerly).
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
+        self.gatt_buf: Dict[str, torch.Tensor] = {}
+        self._gatt_set: Dict[str, bool] = {}
+        self.bwd_pre: List[list] = []  # backward launches that read caller-owned memory (the loss' gradient of the logits): never captured
+        self._graphs: Dict[str, object] = {}
+        self._graph_runs: Dict[str, int] = {}
         self._plan_layers()
         self._lower()
         self._index_slots()
@@ -403,9 +411,10 @@ class Plan:
         sptr = lambda which, pre: self.stats.data_ptr() + 8 * (which * row + st_off[pre])
         aptr = lambda pre: self.stats.data_ptr() + 8 * (row + a_off[pre])
         vptr = lambda r, pre: self.vec.data_ptr() + 4 * (r * tot_c + v_off[pre])
-        salt = {Lr.prefix: i + 1 for i, Lr in enumerate(bn_layers)}
+        salt = {Lr.prefix: (i + 1) | L.SEED_INDIRECT for i, Lr in enumerate(bn_layers)}  # the kernels read the seed through seed_dev
+        SEED = self.seed_dev.data_ptr()
         p_drop = float(eng.dropout_p) if self.train else 0.0
-        self.bn_info = {Lr.prefix: (Lr, salt[Lr.prefix]) for Lr in bn_layers}
+        self.bn_info = {Lr.prefix: (Lr, salt[Lr.prefix] & ~L.SEED_INDIRECT) for Lr in bn_layers}
 
         # First encoder ResidualUnit (in_channels = 1): its 1x1x1 residual convolution is x1[v]*w[c] + b[c]; in training it is
         # computed inside the BN/dropout/PReLU kernel that adds it (vsseg_bn_act_fwd_res1) instead of by an igemm launch that
@@ -493,7 +502,7 @@ class Plan:
         written: Dict[str, bool] = {}
         dlog8 = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
         x0, y0, z0 = self.lv[0]
-        B.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0)]])
+        self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0)]])
 
         def gdesc(spec: TensorSpec) -> L.Tensor:
             return self._desc(spec, self.grads)
@@ -666,28 +675,41 @@ class Plan:
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
                 dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if self.cplans[sig.prefix].fold_dgrad else None
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, _Slot("gatt", op.att.name), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
+                gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
                           self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + 8 + 4)])
         self._finish_pack()
 
     def _index_slots(self):
-        self.seed_slots, self.ext_slots = [], []
-        for lst in (self.fwd, self.bwd):
+        self.ext_slots = []
+        for lst in (self.fwd, self.bwd, self.bwd_pre):
             for rec in lst:
                 for i, a in enumerate(rec[1]):
-                    if a is SEED:
-                        self.seed_slots.append((rec[1], i))
-                    elif isinstance(a, _Slot):
+                    if isinstance(a, _Slot):
+                        assert lst is self.bwd_pre, "a captured launch list may not depend on caller-owned memory"
                         self.ext_slots.append((rec[1], i, a))
 
     # ------------------------------------------------------------------ run
-    def set_seed(self, seed: int):
-        for args, i in self.seed_slots:
-            args[i] = seed
+    def set_seed(self, seed: int, stream=None):
+        stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        L.check(self.eng.lib.vsseg_store_u64(self.seed_dev.data_ptr(), int(seed) & 0xFFFFFFFFFFFFFFFF, stream), "store_u64")
 
-    def set_external_grads(self, glogits: L.Tensor, gatt: Dict[str, Optional[int]]):
+    def set_external_grads(self, glogits: L.Tensor, gatt: Dict[str, Optional[int]], stream=None):
+        """glogits: descriptor of the loss' fp32 gradient of the logits (read by the eager prelude); gatt: device address of the fp32
+        gradient of each attention map (or None), copied into the plan-owned buffers the captured backward reads."""
+        stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        lib = self.eng.lib
         for args, i, slot in self.ext_slots:
-            args[i] = glogits if slot.kind == "glogits" else gatt.get(slot.name)
+            args[i] = glogits
+        for name, buf in self.gatt_buf.items():
+            src = gatt.get(name)
+            nbytes = buf.numel() * 4
+            if src is not None:
+                L.check(lib.vsseg_copy_bytes(src, buf.data_ptr(), nbytes, stream), "copy_bytes")
+                self._gatt_set[name] = True
+            elif self._gatt_set.get(name):  # no external gradient this time: back to zeros
+                L.check(lib.vsseg_memset_zero(buf.data_ptr(), nbytes, stream), "memset_zero")
+                self._gatt_set[name] = False
 
     def zero_stats(self, stream, row=None):
         """Zero the sharded fp64 statistics (both rows before a training forward, the backward row before a backward)."""
@@ -698,9 +720,31 @@ class Plan:
         m2 = self.pack_map2.data_ptr() if self.pack_map2 is not None else None
         L.check(self.eng.lib.vsseg_gather_cast(self.eng.flat.data_ptr(), self.pack_map.data_ptr(), m2, self.wpack.data_ptr(), self.pack_map.numel(), L.BF16 if self.eng.es == 2 else L.F32, stream), "gather_cast")
 
-    def run(self, lst, stream):
+    def run(self, lst, stream, graph_key: Optional[str] = None):
         if self.timer is not None:
             return self._run_timed(lst, stream)
+        if graph_key is not None and self.eng.use_graphs:
+            g = self._graphs.get(graph_key)
+            if g is not None:
+                g.replay()
+                return
+            runs = self._graph_runs[graph_key] = self._graph_runs.get(graph_key, 0) + 1
+            if runs > 2:  # two eager runs first: plan measurement, tile-descriptor tables, function attributes are all settled
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._run_eager(lst, torch.cuda.current_stream().cuda_stream)
+                    self._graphs[graph_key] = g
+                    g.replay()  # the capture recorded the launches without executing them
+                    return
+                except Exception as e:  # capture is an optimisation of HOW the same kernels are launched: fall back to the eager loop, loudly
+                    import warnings
+
+                    warnings.warn(f"vs_seg_amd: hipGraph capture of the {graph_key} launch list failed ({e}); launching eagerly")
+                    self.eng.use_graphs = False
+        self._run_eager(lst, stream)
+
+    def _run_eager(self, lst, stream):
         for rec in lst:
             rc = rec[0](*rec[1], stream)
             if rc:
@@ -743,6 +787,7 @@ class Engine:
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
+        self.use_graphs = os.environ.get("VSSEG_GRAPHS", "1") != "0" and not dry_run  # replay the launch lists as hipGraphs after two eager runs
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
         self.es = 2 if dtype == "bf16" else 4

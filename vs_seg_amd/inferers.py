@@ -94,6 +94,24 @@ def crop_windows(vol: torch.Tensor, b_and_starts, roi, pad_before) -> torch.Tens
     return out
 
 
+def crop_all_windows(vol: torch.Tensor, b_and_starts, roi, pad_before) -> torch.Tensor:
+    """Every window of the (virtually zero-padded) volumes in ONE launch (`vsseg_crop_flip` with one job per window, no flip):
+    [n_windows,1,rx,ry,rz] fp32.  The per-group predictor inputs are then views of this buffer."""
+    lib = L.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    B, _, X, Y, Z = vol.shape
+    n = len(b_and_starts)
+    jobs = (L.CropJob * n)()
+    for i, (b, s) in enumerate(b_and_starts):
+        j = jobs[i]
+        j.src, j.sdims, j.origin, j.flip_x = vol.data_ptr() + 4 * b * X * Y * Z, L.i3((X, Y, Z)), L.i3(tuple(si - pb for si, pb in zip(s, pad_before))), 0
+    jbuf = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(vol.device)
+    out = torch.empty((n, 1, *roi), dtype=torch.float32, device=vol.device)
+    L.check(lib.vsseg_crop_flip(jbuf.data_ptr(), n, out.data_ptr(), L.i3(roi), stream), "crop_flip")
+    jbuf.record_stream(torch.cuda.current_stream())
+    return out
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable, overlap: float = 0.25, mode: str = "constant", padding_mode: str = "constant",
                              cval: float = 0.0, device=None) -> torch.Tensor:
     if not inputs.is_cuda:
@@ -114,9 +132,12 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     slices = [(b, s) for b in range(B) for s in starts]
     out = cnt = None
     stream = torch.cuda.current_stream().cuda_stream
+    per_win = roi[0] * roi[1] * roi[2] * 4
+    windows = crop_all_windows(vol, slices, roi, pad_before) if len(slices) * per_win <= (8 << 30) else None  # one crop launch per call (<= 8 GB of windows), else per group
     for g in range(0, len(slices), sw_batch_size):
         grp = slices[g : g + sw_batch_size]
-        seg = _as_cl(predictor(crop_windows(vol, grp, roi, pad_before)))  # [n,rx,ry,rz,C]
+        win = windows[g : g + len(grp)] if windows is not None else crop_windows(vol, grp, roi, pad_before)
+        seg = _as_cl(predictor(win))  # [n,rx,ry,rz,C]
         C = seg.shape[-1]
         if out is None:
             out = torch.zeros((B, *padded, C), dtype=torch.float32, device=inputs.device)

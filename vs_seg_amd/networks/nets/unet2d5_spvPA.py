@@ -217,7 +217,7 @@ class UNet2d5_spvPA(nn.Module):
             plan.pack_weights(stream)
             self._step += 1
             plan.step_seed = (self._seed_base << 32) | (self._step & 0xFFFFFFFF)
-            plan.set_seed(plan.step_seed)
+            plan.set_seed(plan.step_seed, stream)
             plan.generation += 1
             plan.zero_stats(stream)
             torch.autograd.graph.increment_version(self._bflat)  # bn_finalize updates the running statistics through raw pointers
@@ -237,7 +237,7 @@ class UNet2d5_spvPA(nn.Module):
             L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), inp, stream), "stage_input")
         if plan.compact_input is not None:  # 1-channel copy in the compute dtype for the z-folded first-layer launches
             L.check(eng.lib.vsseg_stage_input(xin.data_ptr(), n, L.i3((X, Y, Z)), L.i3((0, 0, 0)), plan._tdesc(plan.compact_input, 0), stream), "stage_input")
-        plan.run(plan.fwd, stream)
+        plan.run(plan.fwd, stream, "fwd")
         logits = plan.out_logits.permute(0, 4, 1, 2, 3)  # [B,2,X,Y,Z] view of channels-last storage (torch.channels_last_3d strides)
         atts = [a.permute(0, 4, 1, 2, 3) for a in plan.out_atts]
         if not self.reuse_output_buffers:
@@ -262,8 +262,8 @@ class UNet2d5_spvPA(nn.Module):
             g = g.to(torch.float32).contiguous() if (g.dtype != torch.float32 or not g.is_contiguous()) else g
             keep.append(g)
             gatt[spec.name] = g.data_ptr()
-        plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt)
-        plan.set_seed(plan.step_seed)
+        plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt, stream)
+        plan.set_seed(plan.step_seed, stream)
         plan.zero_stats(stream, 1)
         lib, nbytes = eng.lib, self._gflat.numel() * 4
         accumulate = any(p.grad is not None for p in self._params.values())
@@ -272,7 +272,8 @@ class UNet2d5_spvPA(nn.Module):
                 self._gprev = torch.empty_like(self._gflat)
             L.check(lib.vsseg_copy_bytes(self._gflat.data_ptr(), self._gprev.data_ptr(), nbytes, stream), "copy_bytes")
         L.check(lib.vsseg_memset_zero(self._gflat.data_ptr(), nbytes, stream), "memset_zero")
-        plan.run(plan.bwd, stream)
+        plan.run(plan.bwd_pre, stream)  # reads the caller's gradient tensor: always eager
+        plan.run(plan.bwd, stream, "bwd")
         if accumulate:
             n4 = self._gflat.numel() // 4  # every tensor is padded to 4 elements inside the flat buffer
             flat_desc = lambda t: L.Tensor(t.data_ptr(), L.F32, 4, 4, 1, 1, 1, n4)  # noqa: E731
