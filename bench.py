@@ -41,11 +41,11 @@ def synth_batch(batch, patch, seed, device):
     return img.to(device), torch.from_numpy(lab).to(device)
 
 
-def build_model(dtype, device, attention=True):
+def build_model(dtype, device, attention=True, dropout=0.1):
     import vs_seg_amd as V
 
     torch.manual_seed(0)
-    m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, num_res_units=2, norm="batch", dropout=0.1, attention_module=attention, compute_dtype=dtype, **HP)
+    m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, num_res_units=2, norm="batch", dropout=dropout, attention_module=attention, compute_dtype=dtype, **HP)
     return m.to(device)
 
 
@@ -170,6 +170,7 @@ def main():
     ap.add_argument("--swi-volumes", type=int, default=2, help="sliding-window volumes per GPU timed after the training steps (0 = skip)")
     ap.add_argument("--swi-cases", type=int, default=0, help="BASELINE config 5: N synthetic T2-shaped cases (448x448x80 -> 12 windows at roi 384x128x128 / overlap 0.5) sharded over the ranks, "
                     "hard Dice per case, scores all-gathered; 242 = the size of params/split_TCIA.csv (0 = skip)")
+    ap.add_argument("--dropout", type=float, default=0.1, help="dropout probability of the timed network (reference: 0.1; other values are experiments and are named in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked configuration against the reference golden")
     ap.add_argument("--profile", action="store_true", help="print the per-kernel HIP-event breakdown of one step to stderr")
@@ -190,7 +191,7 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity and args.batch >= 1:
         parity = parity_block(args, dev)  # before the timed region, same launch-plan signatures (dtype, batch) as the timed steps
-    model = build_model(args.dtype, dev)
+    model = build_model(args.dtype, dev, dropout=args.dropout)
     model.reuse_output_buffers = True
     loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
     opt = V.Adam(model.parameters(), lr=1e-4, weight_decay=1e-7)
@@ -350,7 +351,7 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"BASELINE config 2: 2.5D attention-UNet fwd + Dice_spvPA(attention+hardness) + bwd + Adam on random 384x128x128 patches, batch {args.batch} per GPU, dropout 0.1, random-init weights",
+        "config": {"workload": f"BASELINE config 2: 2.5D attention-UNet fwd + Dice_spvPA(attention+hardness) + bwd + Adam on random 384x128x128 patches, batch {args.batch} per GPU, dropout {args.dropout:g}, random-init weights",
                    "global_batch": args.batch * world, "patch": "384x128x128", "parallelism": f"dp{world}"},
         "conv_stack_mfma_frac": FWD_BWD_GFLOP_PER_PATCH * patches_per_s / world / 1e3 / peak,
         "loss": loss_val,

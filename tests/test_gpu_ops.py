@@ -331,6 +331,104 @@ def test_every_candidate_plan_gives_the_same_convolution(kind, k, cin, cout, dim
                 np.testing.assert_allclose(st[0].numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2, err_msg=tag)
 
 
+STREAM_CASES = [
+    # kind, kernel, cin, cout, dims, input split
+    ("conv_fwd", (3, 3, 1), 16, 16, (16, 24, 8), 0),
+    ("conv_fwd", (3, 3, 1), 32, 16, (16, 16, 8), 16),  # skip-connection concat read as a two-part tensor
+    ("conv_fwd", (3, 3, 1), 32, 2, (16, 16, 4), 0),    # logits: 2 fp32 channels, scalar stores
+    ("conv_fwd", (3, 3, 1), 1, 16, (16, 16, 8), 0),    # network input, zero-extended to 8 channels
+    ("conv_fwd", (3, 3, 1), 32, 32, (24, 16, 8), 0),
+    ("conv_dgrad", (3, 3, 1), 32, 16, (16, 16, 8), 0),  # K = 16, N = 32
+    ("conv_dgrad", (3, 3, 1), 64, 32, (16, 16, 8), 0),  # K = 32, N = 64: four 16-channel tiles per workgroup
+    ("conv_dgrad", (1, 1, 1), 64, 32, (16, 8, 8), 0),
+    ("conv_fwd", (1, 1, 1), 32, 16, (8, 16, 4), 0),
+]
+
+
+@pytest.mark.parametrize("kind,k,cin,cout,dims,split", STREAM_CASES)
+def test_streaming_kernel_equals_general_kernel(kind, k, cin, cout, dims, split):
+    """depth -2 selects the compile-time-geometry streaming kernel (csrc/sconv.hip).  Same packed weights, K order and fp32
+    accumulation as the general kernel: outputs must be IDENTICAL bit for bit in every epilogue mode (and match the fp64
+    definition within the bf16 output rounding); BatchNorm statistics agree up to the order of the fp32 partial sums."""
+    lib = L.lib()
+    dt = "bf16"
+    torch.manual_seed(5)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k)) ** 0.5, dt)
+    b = torch.randn(cout)
+    xd = x.double().requires_grad_(True)
+    y = F.conv3d(xd, w.double(), b.double(), padding=P.same_pad(k))
+    if kind == "conv_fwd":
+        inp_cl, want, nout, bias = H.to_cl(x, H.DT[dt], cpad=P.round_up(cin, 8)), y.detach(), cout, b.cuda()
+    else:
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        inp_cl, want, nout, bias = H.to_cl(gy, H.DT[dt], cpad=P.round_up(cout, 8)), xd.grad, cin, None
+    cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
+    kc = inp_cl.shape[-1]
+    gen = P.plan_igemm(kind, tuple(w.shape), cls, dims, 2, kc_pad=kc, in_split=split, aux_es=2)
+    gen.pack_map = P.pack_map(gen, tuple(w.shape))
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    sp = P.stream_plan(kind, tuple(w.shape), cls, dims, 2, kc, nreal, kreal)
+    assert sp is not None and sp.depth == -2
+    sp.pack_map = P.pack_map(sp, tuple(w.shape))
+    parts = H._split_cl(inp_cl, split) if split else None
+    odt = torch.float32 if nout == 2 else H.DT[dt]
+    res_t = H.to_cl(_round(torch.randn(2, nout, *dims), dt), H.DT[dt])
+    gate_t = torch.rand(2, *dims, device="cuda")
+    alpha = torch.tensor([0.25], device="cuda")
+    modes = ["plain", "stats", "prelu"] + (["accumulate", "res_add", "relu_mask", "gate"] if nout % 4 == 0 else [])
+    for mode in modes:
+        outs = []
+        for pl in (gen, sp):
+            out = torch.zeros(2, *dims, nout, dtype=odt, device="cuda")
+            kw, stats = {}, None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "prelu":
+                kw = dict(act=L.ACT_PRELU, alpha=alpha.data_ptr())
+            elif mode == "accumulate":
+                out = res_t.clone()
+                kw = dict(accumulate=1)
+            elif mode in ("res_add", "relu_mask", "gate"):
+                kw = dict(res=H.tdesc(res_t), res_mode={"res_add": L.RES_ADD, "relu_mask": L.RES_RELUMASK, "gate": L.RES_GATE}[mode])
+                if mode == "gate":
+                    kw["gate"] = gate_t.data_ptr()
+            if bias is not None:
+                kw["bias"] = bias.data_ptr()
+            wp = H.pack(pl, w, inp_cl.dtype)
+            d = H.igemm_desc(pl, wp, H.two_part(*parts) if parts else H.tdesc(inp_cl), H.tdesc(out), **kw)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm D={pl.depth} {mode}")
+            torch.cuda.synchronize()
+            outs.append((out, stats))
+        (og, sg), (os_, ss) = outs
+        assert torch.equal(og, os_), f"{mode}: streaming kernel differs from the general kernel (max {float((og.float() - os_.float()).abs().max())})"
+        if mode == "plain":
+            np.testing.assert_allclose(H.from_cl(os_).numpy(), want.float().numpy(), atol=_tol(dt, want))
+        if mode == "stats":
+            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), ss.view(L.STAT_SHARDS, 2, -1).sum(0)
+            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
+
+
+def test_streaming_kernel_rejects_what_it_does_not_cover():
+    """depth -2 on a launch outside the streaming kernel's domain is an error (no silent fallback to the general kernel)."""
+    lib = L.lib()
+    k, cin, cout, dims = (3, 3, 1), 16, 16, (12, 16, 8)  # 12 is not a multiple of the 8-voxel tile
+    w = torch.randn(cout, cin, *k)
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    assert P.stream_plan("conv_fwd", tuple(w.shape), cls, dims, 2, cin, cout, cin) is None
+    pl = P.plan_igemm("conv_fwd", tuple(w.shape), cls, dims, 2, kc_pad=cin, mtw=4)
+    pl.pack_map = P.pack_map(pl, tuple(w.shape))
+    x = torch.zeros(1, *dims, cin, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, *dims, cout, dtype=torch.bfloat16, device="cuda")
+    d = H.igemm_desc(pl, H.pack(pl, w, x.dtype), H.tdesc(x), H.tdesc(out))
+    d.depth = -2
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL
+    assert b"streaming kernel" in lib.vsseg_last_error()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # two-part tensors: the skip-connection concat cat([skip, up], 1) (MONAI SkipConnection) addressed as a pair of dense
 # tensors.  Every kernel that accepts one must give exactly what it gives on the materialised concatenation.

@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_network.py -q -x -p no:cacheprovider -k "graph_replay or adam_step or eval_cache or dropout_mask" > gpurun_out/g1.log 2>&1; tail -5 gpurun_out/g1.log
-for G in 0 1; do echo "== VSSEG_GRAPHS=$G"; VSSEG_GRAPHS=$G python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2> gpurun_out/bg$G.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print({k:d[k] for k in ('value','ms_per_step','loss')}); print(d['sliding_window'])"; done
+mkdir -p gpurun_out
+timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "streaming" -p no:cacheprovider 2>&1 | tail -5
+for p in 3 4 5; do echo "== per CU $p"; VSSEG_SCONV_PERCU=$p timeout 300 python tools/bench_sconv.py 2>&1 | grep streaming | sed 's/(. GB.s, /(/; s/ (. GB.s)//'; done > gpurun_out/sconv_sweep.log 2>&1
+cat gpurun_out/sconv_sweep.log

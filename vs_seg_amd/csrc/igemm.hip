@@ -1,6 +1,7 @@
 // Host side of the implicit-GEMM convolution: argument checks, LDS layout, tile-descriptor table, dispatch.
 // The kernel itself is in igemm_kernel.h (instantiated by igemm_inst.hip).
 #include "igemm_kernel.h"
+#include "sconv.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
@@ -167,11 +168,18 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
 }
 
 extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
+  if (d && d->depth == -2) return vsseg_sconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
 
 extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
+  if (d && d->depth == -2) {  // streaming kernel (sconv.hip): fails loudly when the launch is outside its domain, never falls back
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_sconv_launch(d, z, as_stream(stream));
+  }
   IgemmK k;
   int lds = igemm_prepare(d, k);
   if (lds < 0) return lds;

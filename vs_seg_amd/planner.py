@@ -140,6 +140,42 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
     return round_up(ksteps * 16, 16) + 3 * nt * 16 * 4 + w * (nbuf if nchunks > 1 else 1) + nbuf * round_up(hb, 1024) + aux + tables  # ring buffers padded to whole 1 KiB DMA instructions
 
 
+# ---- streaming kernel (csrc/sconv.hip): depth -2 ------------------------------------------------------------------------
+STREAM_TILE = (8, 8, 4)
+STREAM_SHAPES = {(8, 1, 9), (8, 2, 9), (16, 1, 9), (16, 2, 9), (16, 4, 9), (32, 1, 9), (32, 2, 9), (32, 4, 9),
+                 (16, 1, 1), (16, 2, 1), (32, 1, 1), (32, 2, 1), (32, 4, 1), (64, 2, 1), (64, 4, 1)}  # (input channels, 16-channel output tiles, taps) instantiated by sconv.hip
+_TAPS_3x3x1 = [(t // 3 - 1, t % 3 - 1, 0) for t in range(9)]
+
+
+def stream_eligible(cls: "LatticeClass", q, kc, nreal, es) -> bool:
+    """Mirror of sc_find() in csrc/sconv.hip for what a plan decides (the tensors' layout is checked by the library, loudly)."""
+    offs = [tuple(t[0]) for t in cls.taps]
+    if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0):
+        return False
+    if offs != _TAPS_3x3x1 and offs != [(0, 0, 0)]:
+        return False
+    if any(v % t for v, t in zip(q, STREAM_TILE)):
+        return False
+    return (kc, (nreal + 15) // 16, len(offs)) in STREAM_SHAPES
+
+
+def stream_lds_bytes(kc, nt, ntaps):
+    g = kc // 8
+    r = 1 if ntaps == 9 else 0
+    pieces = (STREAM_TILE[0] + 2 * r) * (STREAM_TILE[1] + 2 * r) * STREAM_TILE[2] * g
+    return ((ntaps * g + 3) // 4) * nt * 1024 + ((pieces + 255) // 256) * 4096 + 3 * nt * 16 * 4
+
+
+def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPlan"]:
+    """The depth -2 candidate: the compile-time-geometry streaming kernel on the launches it covers (stride-1 3x3x1 / 1x1x1 bf16,
+    at most 64 channels either side, extents divisible by the 8x8x4 tile)."""
+    if not stream_eligible(cls, q, kc, nreal, es):
+        return None
+    nt = (nreal + 15) // 16
+    ntaps = len(cls.taps)
+    return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, STREAM_TILE, 4, nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
+
+
 def _pow2_floor(v):
     p = 1
     while p * 2 <= v:
@@ -221,6 +257,10 @@ def plan_igemm(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, lds_budget=1
     return best
 
 
+def in_split_unsupported(in_split, kc) -> bool:
+    return bool(in_split) and (in_split % 8 != 0 or in_split >= kc)
+
+
 def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=4, in_split=0, limit=10) -> List[IgemmPlan]:
     """Feasible alternatives to `plan_igemm`'s choice, default first (pack maps are filled for all of them).
 
@@ -266,6 +306,9 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
             lds = igemm_lds_bytes(pl.tile, cls.is_, cls.taps, pl.ck, pl.ksteps, pl.nt, pl.mtw, es, pl.nchunks, aux_es, -1)
             twins.append(dataclasses.replace(pl, depth=-1, lds=lds))
     rest = rest + twins
+    sp = stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal)
+    if sp is not None and not in_split_unsupported(in_split, kc):
+        rest = rest + [sp]
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
