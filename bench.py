@@ -220,8 +220,9 @@ def main():
             print(f"{k:34s} n={a['n']:4d} {a['ms']:9.3f} ms {100 * a['ms'] / tot:5.1f}%  {extra}", file=sys.stderr)
         torch.cuda.synchronize()
         rows = sorted(((e0.elapsed_time(e1), name, (meta or {}).get("tag", ""), meta) for name, meta, e0, e1 in plan.timer["events"]), key=lambda r: -r[0])
-        print("--- 45 slowest launches ---", file=sys.stderr)
-        for ms, name, tag, meta in rows[:45]:
+        nrows = int(os.environ.get("VSSEG_PROFILE_ROWS", "45"))
+        print(f"--- {nrows} slowest launches ---", file=sys.stderr)
+        for ms, name, tag, meta in rows[:nrows]:
             tf = f"{meta['flops'] / ms / 1e9:7.1f} TF" if meta and meta.get("flops") else ""
             gb = f"{meta['bytes'] / ms / 1e6:7.0f} GB/s" if meta and meta.get("bytes") else ""
             print(f"{ms:8.3f} ms {name:18s} {tf} {gb} {tag}", file=sys.stderr)

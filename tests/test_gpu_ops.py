@@ -342,6 +342,8 @@ STREAM_CASES = [
     ("conv_dgrad", (3, 3, 1), 64, 32, (16, 16, 8), 0),  # K = 32, N = 64: four 16-channel tiles per workgroup
     ("conv_dgrad", (1, 1, 1), 64, 32, (16, 8, 8), 0),
     ("conv_fwd", (1, 1, 1), 32, 16, (8, 16, 4), 0),
+    ("conv_fwd", (3, 3, 1), 64, 32, (12, 16, 8), 32),  # level-1 concat: 64 input channels, 4x8x4 tile
+    ("conv_fwd", (1, 1, 1), 64, 32, (16, 8, 8), 32),
 ]
 
 

@@ -12,7 +12,7 @@ from tests import gpu_harness as H  # noqa: E402
 from vs_seg_amd import _lib as L  # noqa: E402
 from vs_seg_amd import planner as P  # noqa: E402
 
-CASES = [("conv_fwd", (3, 3, 1), 16, 16, (384, 128, 128), "plain"), ("conv_fwd", (3, 3, 1), 16, 16, (384, 128, 128), "stats"), ("conv_fwd", (3, 3, 1), 32, 16, (384, 128, 128), "stats"),
+CASES = [("conv_fwd", (3, 3, 1), 64, 32, (192, 64, 128), "stats"), ("conv_fwd", (1, 1, 1), 64, 32, (192, 64, 128), "plain"), ("conv_fwd", (3, 3, 1), 16, 16, (384, 128, 128), "plain"), ("conv_fwd", (3, 3, 1), 16, 16, (384, 128, 128), "stats"), ("conv_fwd", (3, 3, 1), 32, 16, (384, 128, 128), "stats"),
          ("conv_dgrad", (3, 3, 1), 32, 16, (384, 128, 128), "accumulate"), ("conv_dgrad", (3, 3, 1), 16, 16, (384, 128, 128), "plain"), ("conv_fwd", (3, 3, 1), 32, 32, (192, 64, 128), "stats"),
          ("conv_dgrad", (3, 3, 1), 64, 32, (192, 64, 128), "plain"), ("conv_dgrad", (1, 1, 1), 64, 32, (192, 64, 128), "accumulate")]
 

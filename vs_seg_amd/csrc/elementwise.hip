@@ -278,8 +278,28 @@ __device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, 
   return dal;
 }
 
-template <typename T>
-__global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc) {
+// Pass 1 of the BatchNorm + dropout + PReLU backward.  Per thread: one 8-channel group, U voxels in flight (2*U independent 16-byte loads).
+// The loop keeps only the forward's folded affine (scale, shift: the PReLU branch is re-decided on the SAME fp32 value) in registers and
+// accumulates sum(dz), sum(dz*y), sum(dout); sum(dz*xhat) = invstd * (sum(dz*y) - mean * sum(dz)) is formed once per workgroup, in fp64, from
+// the workgroup's partial sums (16 fewer live registers and 2 fewer VALU per element than normalising inside the loop).
+// 8 channels as loaded (bf16: 4 registers) — converted to fp32 only when consumed, so that U voxels in flight cost 8*U registers, not 16*U
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> {
+  uint4 u;
+  static __device__ __forceinline__ Raw8 ld(const bf16_t* p) { Raw8 r; r.u = *reinterpret_cast<const uint4*>(p); return r; }
+  __device__ __forceinline__ f8 cvt() const {
+    return f8{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+               __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+  }
+};
+template <> struct Raw8<float> {
+  f8 v;
+  static __device__ __forceinline__ Raw8 ld(const float* p) { Raw8 r; r.v = ld8(p); return r; }
+  __device__ __forceinline__ f8 cvt() const { return v; }
+};
+
+template <typename T, int U>
+__global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc) {
   extern __shared__ float red[];  // [3][c] + [1]
   const int C = cgs * 8;
   for (int i = threadIdx.x; i < 3 * C + 1; i += blockDim.x) red[i] = 0.f;
@@ -288,31 +308,48 @@ __global__ void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const 
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs);
   const int c = cg * 8;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = a.scale[c + j]; sh[j] = a.shift[c + j]; }
+  const bool drop = a.p_drop > 0.f;
+  const float inv_keep = 1.f / (1.f - a.p_drop);
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
-  // two voxels per iteration: four independent 16-byte loads in flight per thread (one pair measured 3.0 TB/s: the kernel is bound by the
-  // bytes in flight, ~90 VGPRs allow 5 waves per SIMD)
   const int64_t vstep = nthreads / cgs;
   auto one = [&](const f8& yy, const f8& da, int64_t v) {
-    f8 dz, xh;
-    dal += bn_bwd_elem8(yy, da, c, v * cgs + cg, a, alpha, dz, xh);
+    const unsigned keep = drop ? dropout_keep8(a.seed, a.salt, (uint64_t)(v * cgs + cg), a.p_drop) : 0xffu;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] += dz.v[j]; s2[j] += dz.v[j] * xh.v[j]; s3[j] += da.v[j]; }
+    for (int j = 0; j < 8; ++j) {
+      const float z = yy.v[j] * sc[j] + sh[j];
+      const bool k = (keep >> j) & 1u;
+      const float d = k ? z * inv_keep : 0.f;
+      const float g = da.v[j];
+      const float dd = d > 0.f ? g : alpha * g;
+      if (d < 0.f) dal += g * d;
+      const float dz = k ? dd * inv_keep : 0.f;
+      s1[j] += dz; s2[j] += dz * yy.v[j]; s3[j] += g;
+    }
   };
   int64_t v = gt / cgs;
-  for (; v + vstep < nvox; v += 2 * vstep) {
-    const f8 y0 = ld8(y + v * yp + c), d0 = ld8(dout + v * dp + c);
-    const f8 y1 = ld8(y + (v + vstep) * yp + c), d1 = ld8(dout + (v + vstep) * dp + c);
-    one(y0, d0, v);
-    one(y1, d1, v + vstep);
+  for (; v + (U - 1) * vstep < nvox; v += U * vstep) {
+    Raw8<T> yv[U], dv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { yv[u] = Raw8<T>::ld(y + (v + u * vstep) * yp + c); dv[u] = Raw8<T>::ld(dout + (v + u * vstep) * dp + c); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(yv[u].cvt(), dv[u].cvt(), v + u * vstep);
   }
-  if (v < nvox) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
+  for (; v < nvox; v += vstep) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
 #pragma unroll
   for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
   if ((threadIdx.x & 63) == 0) atomicAdd(&red[3 * C], dal);
   __syncthreads();
   const int shard = blockIdx.x % VSSEG_STAT_SHARDS;
-  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) atomicAdd(&sums[(int64_t)shard * 3 * stride + (i / C) * stride + (i % C)], (double)red[i]);
+  for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
+    const int which = i / C, ch = i % C;
+    double val = (double)red[i];
+    if (which == 1) val = (double)a.invstd[ch] * (val - (double)a.mean[ch] * (double)red[ch]);  // sum(dz * xhat) of this workgroup
+    atomicAdd(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val);
+  }
   if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[3 * C]);
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
@@ -323,9 +360,17 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
   int64_t nv = tensor_voxels(y);
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
-  int grid = grid_for((nv * cgs + 1) / 2, blk, 256 * 8);
+  static int unroll = -1;  // voxels in flight per thread (tuning aid: VSSEG_BN_REDUCE_U = 2 | 4)
+  if (unroll < 0) { const char* e = getenv("VSSEG_BN_REDUCE_U"); unroll = e ? atoi(e) : 2; }
   size_t lds = (3 * y.c + 1) * sizeof(float);
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<T>, dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
+  if (unroll == 2) {
+    int grid = grid_for((nv * cgs + 1) / 2, blk, 256 * 8);
+    DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
+    VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
+    return VSSEG_OK;
+  }
+  int grid = grid_for((nv * cgs + 3) / 4, blk, 256 * 8);
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }

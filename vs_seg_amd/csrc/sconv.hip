@@ -25,7 +25,9 @@ typedef __attribute__((address_space(1))) const void sc_gvoid_t;
 typedef __attribute__((address_space(3))) void sc_lvoid_t;
 __device__ __forceinline__ void sc_dma16(const void* gsrc, char* lds_wave_base) { __builtin_amdgcn_global_load_lds((sc_gvoid_t*)gsrc, (sc_lvoid_t*)lds_wave_base, 16, 0, 0); }
 
-constexpr int SC_TX = 8, SC_TY = 8, SC_TZ = 4;
+constexpr int SC_TY = 8, SC_TZ = 4;
+// M-tiles (16 voxels) per wave: 4 = tile 8x8x4; 2 = tile 4x8x4 for the 64-channel 3x3x1 inputs, whose 8x8x4 halo + weights would leave one workgroup per CU
+constexpr int sc_mt(int cin, int taps) { return (cin >= 64 && taps == 9) ? 2 : 4; }
 
 struct SconvK {
   const char* in0;   // channels [0, csplit) ...
@@ -62,6 +64,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
   constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
   constexpr int G = CIN / 8, CINB = CIN * 2;
   constexpr int R = TAPS == 9 ? 1 : 0;
+  constexpr int MT = sc_mt(CIN, TAPS), SC_TX = 2 * MT;
   constexpr int HX = SC_TX + 2 * R, HY = SC_TY + 2 * R, HZ = SC_TZ;
   constexpr int PIECES = HX * HY * HZ * G, NINST = (PIECES + 255) / 256;
   constexpr int KSTEPS = (TAPS * G + 3) / 4;
@@ -105,8 +108,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     const int dx = TAPS == 9 ? tap / 3 : 0, dy = TAPS == 9 ? tap % 3 : 0;
     koff[ks] = tap < TAPS ? ((dx * HY + dy) * HZ) * CINB + ((cg ^ sc_swz<G>(vy0 + dy, vz)) * 16) : 0;  // padded K-groups: zero weights times valid data
   }
-  const int vb0 = (((wave * 2) * HY + vy0) * HZ + vz) * CINB;  // M-tile m: + (m & 1) * 4 rows of y, + (m >> 1) rows of x (immediates; neither changes the swizzle)
-  const unsigned ov0 = (unsigned)(((wave * 2) * Y + vy0) * Z + vz);
+  const int vb0 = (((wave * (MT / 2)) * HY + vy0) * HZ + vz) * CINB;  // M-tile m: + (m & 1) * 4 rows of y, + (m >> 1) rows of x (immediates; neither changes the swizzle)
+  const unsigned ov0 = (unsigned)(((wave * (MT / 2)) * Y + vy0) * Z + vz);
   const unsigned out_es = k.out_f32 ? 4u : 2u;
   const bool vec_store = (cout & 3) == 0;
   const bool simple = vec_store && !k.out_f32 && !k.scale && (k.act == VSSEG_ACT_NONE || k.act == VSSEG_ACT_PRELU);
@@ -153,11 +156,11 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
       }
     }
     // auxiliary operands of the epilogue: ordinary loads issued behind the DMA, in flight with it
-    uint2 auxv[AUXM ? 4 : 1][AUXM ? NT : 1];
-    float gatev[AUXM ? 4 : 1];
+    uint2 auxv[AUXM ? MT : 1][AUXM ? NT : 1];
+    float gatev[AUXM ? MT : 1];
     if constexpr (AUXM) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const int64_t vox = ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
         if (k.aux_mode == 4) gatev[m] = k.gate[vox];
 #pragma unroll
@@ -171,9 +174,9 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
 #pragma unroll
       for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (ks * NT + t) * 1024);
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const bf16x8 av = *reinterpret_cast<const bf16x8*>(Hl + vb0 + koff[ks] + (m & 1) * (4 * HZ * CINB) + (m >> 1) * (HY * HZ * CINB));
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t], av, acc[m][t], 0, 0, 0);
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     auto epilogue = [&](auto kind_c) {
       constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < MT; ++m) {
         const int64_t vox = ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
         float gt = 1.f;
         if constexpr (AUXM) gt = k.aux_mode == 4 ? 1.f + gatev[m] : 1.f;
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
 // ---- host side ------------------------------------------------------------------------------------------------------
 template <int CIN, int NT, int TAPS> static int sc_lds() {
   constexpr int G = CIN / 8, R = TAPS == 9 ? 1 : 0;
-  constexpr int PIECES = (SC_TX + 2 * R) * (SC_TY + 2 * R) * SC_TZ * G, NINST = (PIECES + 255) / 256, KSTEPS = (TAPS * G + 3) / 4;
+  constexpr int PIECES = (2 * sc_mt(CIN, TAPS) + 2 * R) * (SC_TY + 2 * R) * SC_TZ * G, NINST = (PIECES + 255) / 256, KSTEPS = (TAPS * G + 3) / 4;
   return KSTEPS * NT * 1024 + NINST * 4096 + 3 * NT * 16 * 4;
 }
 template <int CIN, int NT, int TAPS, int MODE> static int sc_launch_mode(const SconvK& k, hipStream_t s) {
@@ -323,18 +326,19 @@ typedef int (*sc_fn_t)(const SconvK&, hipStream_t);
 struct ScEntry { int cin, nt, taps; sc_fn_t fn; int (*lds)(); };
 #define SC_E(C, N, T) {C, N, T, sc_launch<C, N, T>, sc_lds<C, N, T>}
 static const ScEntry sc_table[] = {SC_E(8, 1, 9),  SC_E(8, 2, 9),  SC_E(16, 1, 9), SC_E(16, 2, 9), SC_E(16, 4, 9), SC_E(32, 1, 9), SC_E(32, 2, 9), SC_E(32, 4, 9),
-                                   SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1)};
+                                   SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1), SC_E(64, 2, 9)};
 
 static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
   auto no = [&](const char* w) { *why = w; return (const ScEntry*)nullptr; };
   if (d->in.dtype != VSSEG_BF16) return no("input is not bf16");
-  if (d->nchunks != 1 || d->nsplit != 1 || d->mtw != 4) return no("needs nchunks = nsplit = 1 and mtw = 4");
-  if (d->tile[0] != SC_TX || d->tile[1] != SC_TY || d->tile[2] != SC_TZ) return no("tile must be 8x8x4");
+  const int mt = sc_mt(d->ck, d->ntaps), SC_TX = 2 * mt;
+  if (d->nchunks != 1 || d->nsplit != 1 || d->mtw != mt) return no("needs nchunks = nsplit = 1 and mtw = 4 (2 for 64 input channels x 9 taps)");
+  if (d->tile[0] != SC_TX || d->tile[1] != SC_TY || d->tile[2] != SC_TZ) return no("tile must be 8x8x4 (4x8x4 for 64 input channels x 9 taps)");
   for (int a = 0; a < 3; ++a)
     if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
   if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || d->q[0] != d->out.x || d->q[1] != d->out.y || d->q[2] != d->out.z) return no("lattice, input and output extents differ");
-  if (d->q[0] % SC_TX || d->q[1] % SC_TY || d->q[2] % SC_TZ) return no("extent is not a multiple of the 8x8x4 tile");
+  if (d->q[0] % SC_TX || d->q[1] % SC_TY || d->q[2] % SC_TZ) return no("extent is not a multiple of the tile");
   if (d->ntaps == 9) {
     for (int t = 0; t < 9; ++t)
       if (d->tap_off[t][0] != t / 3 - 1 || d->tap_off[t][1] != t % 3 - 1 || d->tap_off[t][2] != 0) return no("taps are not the 3x3x1 stencil in (x, y) order");
@@ -402,7 +406,7 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.zeros = zeros;
   k.act = d->act; k.cout = d->out.c; k.cout_mod = d->cout_mod;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
-  k.ntx = k.X / SC_TX; k.nty = k.Y / SC_TY; k.ntz = k.Z / SC_TZ;
+  k.ntx = k.X / (2 * sc_mt(d->ck, d->ntaps)); k.nty = k.Y / SC_TY; k.ntz = k.Z / SC_TZ;
   k.mg_tx = magic(k.ntx); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);
   k.tiles = d->in.n * k.ntx * k.nty * k.ntz;
   k.per_xcd = (k.tiles + 7) / 8;

@@ -605,7 +605,7 @@ class Plan:
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -652,7 +652,7 @@ class Plan:
                     big = self.merged[Lr.prefix].layer
                     kx, ky, kz = big.kernel
                     centre = ((kx // 2) * ky + ky // 2) * kz + kz // 2
-                    B.append([lib.vsseg_merge_residual_grads, [self._gp(big.wkey), self._gp(big.bkey), self._gp(Lr.wkey), self._gp(Lr.bkey), Lr.cout, Lr.cin, kx * ky * kz, centre]])
+                    B.append([lib.vsseg_merge_residual_grads, [self._gp(big.wkey), self._gp(big.bkey), self._gp(Lr.wkey), self._gp(Lr.bkey), Lr.cout, Lr.cin, kx * ky * kz, centre], dict(name="vsseg_merge_residual_grads", kind="hbm", flops=0.0, bytes=0.0, side=True)])
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
@@ -745,10 +745,26 @@ class Plan:
         self._run_eager(lst, stream)
 
     def _run_eager(self, lst, stream):
+        """Launches in list order on `stream` (torch's current stream).  With Engine.overlap, the launches marked side=True — the weight
+        gradients, which nothing in the backward pass reads (they feed the optimizer) — go to a second HIP stream: each forks from the main
+        stream where the list places it (its operands are final there; every gradient tensor has its own buffer, so nothing later on the
+        main stream overwrites them), they serialise among themselves (shared partial-sum scratch), and the main stream joins the side
+        stream at the end of the list.  Under hipGraph capture the fork / join events become graph edges."""
+        side = None
+        overlap = self.eng.overlap
         for rec in lst:
-            rc = rec[0](*rec[1], stream)
+            if overlap and len(rec) > 2 and rec[2].get("side"):
+                main = torch.cuda.current_stream()
+                if side is None:
+                    side = self.eng.side_stream()
+                side.wait_stream(main)
+                rc = rec[0](*rec[1], side.cuda_stream)
+            else:
+                rc = rec[0](*rec[1], stream)
             if rc:
                 L.check(rc, getattr(rec[0], "__name__", "launch"))
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def _run_timed(self, lst, stream):
         """Per-launch HIP-event timing (events are recorded on the stream the kernels are launched on)."""
@@ -787,6 +803,8 @@ class Engine:
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
+        self.overlap = os.environ.get("VSSEG_OVERLAP", "0") == "1" and not dry_run  # weight gradients on a second HIP stream, concurrent with the data-gradient chain
+        self._side = None
         self.use_graphs = os.environ.get("VSSEG_GRAPHS", "1") != "0" and not dry_run  # replay the launch lists as hipGraphs after two eager runs
         self.attention, self.hp = attention, hp
         self.tdtype = {"bf16": torch.bfloat16, "fp32": torch.float32}[dtype]
@@ -795,6 +813,11 @@ class Engine:
         self.prog: Program = build_program(attention, hp)
         self.dropout_p = hp["dropout"] if dropout_p is None else dropout_p
         self.plans: Dict[tuple, Plan] = {}
+
+    def side_stream(self) -> "torch.cuda.Stream":
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     def wgrad_scratch(self) -> torch.Tensor:
         if getattr(self, "_wg_scratch", None) is None:

@@ -141,9 +141,17 @@ def igemm_lds_bytes(tile, is_, taps, ck, ksteps, nt, mtw, es, nchunks=1, aux_es=
 
 
 # ---- streaming kernel (csrc/sconv.hip): depth -2 ------------------------------------------------------------------------
-STREAM_TILE = (8, 8, 4)
+def stream_mt(kc, ntaps) -> int:
+    """M-tiles per wave of the streaming kernel (sc_mt() in csrc/sconv.hip): tile = (2 * mt, 8, 4)."""
+    return 2 if (kc >= 64 and ntaps == 9) else 4
+
+
+def stream_tile(kc, ntaps):
+    return (2 * stream_mt(kc, ntaps), 8, 4)
+
+
 STREAM_SHAPES = {(8, 1, 9), (8, 2, 9), (16, 1, 9), (16, 2, 9), (16, 4, 9), (32, 1, 9), (32, 2, 9), (32, 4, 9),
-                 (16, 1, 1), (16, 2, 1), (32, 1, 1), (32, 2, 1), (32, 4, 1), (64, 2, 1), (64, 4, 1)}  # (input channels, 16-channel output tiles, taps) instantiated by sconv.hip
+                 (16, 1, 1), (16, 2, 1), (32, 1, 1), (32, 2, 1), (32, 4, 1), (64, 2, 1), (64, 4, 1), (64, 2, 9)}  # (input channels, 16-channel output tiles, taps) instantiated by sconv.hip
 _TAPS_3x3x1 = [(t // 3 - 1, t % 3 - 1, 0) for t in range(9)]
 
 
@@ -154,7 +162,7 @@ def stream_eligible(cls: "LatticeClass", q, kc, nreal, es) -> bool:
         return False
     if offs != _TAPS_3x3x1 and offs != [(0, 0, 0)]:
         return False
-    if any(v % t for v, t in zip(q, STREAM_TILE)):
+    if any(v % t for v, t in zip(q, stream_tile(kc, len(offs)))):
         return False
     return (kc, (nreal + 15) // 16, len(offs)) in STREAM_SHAPES
 
@@ -162,7 +170,8 @@ def stream_eligible(cls: "LatticeClass", q, kc, nreal, es) -> bool:
 def stream_lds_bytes(kc, nt, ntaps):
     g = kc // 8
     r = 1 if ntaps == 9 else 0
-    pieces = (STREAM_TILE[0] + 2 * r) * (STREAM_TILE[1] + 2 * r) * STREAM_TILE[2] * g
+    tile = stream_tile(kc, ntaps)
+    pieces = (tile[0] + 2 * r) * (tile[1] + 2 * r) * tile[2] * g
     return ((ntaps * g + 3) // 4) * nt * 1024 + ((pieces + 255) // 256) * 4096 + 3 * nt * 16 * 4
 
 
@@ -173,7 +182,7 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
         return None
     nt = (nreal + 15) // 16
     ntaps = len(cls.taps)
-    return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, STREAM_TILE, 4, nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
+    return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, stream_tile(kc, ntaps), stream_mt(kc, ntaps), nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
 
 
 def _pow2_floor(v):
