@@ -143,23 +143,27 @@ int vsseg_bn_fold_eval(const float* gamma, const float* beta, const float* rm, c
 
 /* out = PReLU(dropout(y*scale+shift)) [+ res]   (ref:.../convolutions.py:148-156; residual add :252-255).
  * Dropout: keep-mask from Philox4x32-10(seed, salt, element index); p = 0 disables.  salt | VSSEG_SEED_INDIRECT: `seed` holds the
- * device address of the seed (every dropout entry point), so that a launch list with fixed arguments can be replayed with a new seed. */
+ * device address of the seed (every dropout entry point), so that a launch list with fixed arguments can be replayed with a new seed.
+ * keep_out (or NULL): [voxels * c/8] bytes — the forward stores the keep-mask of every 8-channel group there, and a backward pass given the
+ * same buffer as keep_in reads it instead of running Philox again (the three BN kernels are VALU-bound on the generator, not on HBM;
+ * NULL regenerates the bit-identical mask from (seed, salt, element index)). */
 int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
-                     vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream);
+                     vsseg_tensor res, int32_t has_res, vsseg_tensor out, uint8_t* keep_out, void* stream);
 /* Same with the residual computed on the fly as the 1x1x1 convolution of a ONE-channel tensor: res[v][c] = x1[v]*res_w[c] + res_b[c]
  * (first encoder ResidualUnit, in_channels = 1, ref:params/networks/blocks/convolutions.py:241-255); x1 is [N][X][Y][Z] in y's dtype. */
 int vsseg_bn_act_fwd_res1(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
-                          const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, void* stream);
+                          const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, uint8_t* keep_out, void* stream);
 /* Backward, pass 1: sums[shard][0][c] += dz, [1][c] += dz*xhat, [2][c] += dout, alpha_acc[shard] += dA*d(d<0). */
 int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
                             const float* scale, const float* shift, /* the forward's folded affine: the PReLU/dropout branch is re-decided on the SAME fp32 value */
-                            const float* alpha, float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream);
+                            const float* alpha, float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, const uint8_t* keep_in, void* stream);
 /* finalize: dgamma, dbeta, dalpha (+= into flat grads) and the two per-channel means used by pass 2 */
 int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
                               float* mean_dz, float* mean_dzx, float* dres_bias /* += sum(dout) or NULL */, void* stream);
 /* pass 2: dy = gamma*invstd*(dz - mean_dz - xhat*mean_dzx) */
 int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                           const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream);
+                           const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy,
+                           const uint8_t* keep_in, void* stream);
 /* debug/parity: write the keep-mask (0/1 as f32, [voxel][c]) the forward used */
 int vsseg_dropout_mask(float* mask, int64_t nvox, int32_t c, float p_drop, uint64_t seed, uint32_t salt, void* stream);
 

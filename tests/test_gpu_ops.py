@@ -182,10 +182,11 @@ def test_igemm_512_voxel_tiles(dims, dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-def test_bn_dropout_prelu_forward_backward(dt, p_drop):
+@pytest.mark.parametrize("p_drop,stored", [(0.0, False), (0.1, False), (0.1, True)])
+def test_bn_dropout_prelu_forward_backward(dt, p_drop, stored):
     """Training-mode BN -> Dropout -> PReLU (+residual): statistics, running stats, forward and all gradients vs the oracle
-    fed with the HIP path's own keep-mask (torch's dropout stream cannot be reproduced)."""
+    fed with the HIP path's own keep-mask (torch's dropout stream cannot be reproduced).  stored: the forward keeps the
+    mask bytes and the backward passes read them (what the engine does) instead of regenerating them from (seed, salt, index)."""
     lib = L.lib()
     torch.manual_seed(5)
     c, dims, n = 48, (8, 8, 4), 2
@@ -208,12 +209,18 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     L.check(lib.vsseg_bn_finalize(stats.data_ptr(), c, c, float(nvox), g.data_ptr(), be.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), nb.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), S))
     out = torch.zeros_like(ycl)
     seed, salt = 0x1234ABCD5678, 7
-    L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, H.tdesc(rcl), 1, H.tdesc(out), S))
+    keep = torch.zeros(nvox * c // 8, dtype=torch.uint8, device="cuda") if stored else None
+    kptr = keep.data_ptr() if stored else None
+    L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, H.tdesc(rcl), 1, H.tdesc(out), kptr, S))
     mask = torch.ones(n, *dims, c, device="cuda")
     L.check(lib.vsseg_dropout_mask(mask.data_ptr(), nvox, c, p_drop, seed, salt, S))
     torch.cuda.synchronize()
     if p_drop > 0:
         assert 0.85 < float(mask.mean()) < 0.95
+    if stored:  # bit j of byte i = keep decision of element 8*i + j
+        bits = ((keep.view(-1, 1).int() >> torch.arange(8, device="cuda").view(1, 8)) & 1).float().view(-1)
+        assert torch.equal(bits, mask.view(-1))
+        seed ^= 0x5A5A5A5A  # the backward passes must now use the stored bytes: a different seed would regenerate a different mask
     # oracle: BN->dropout(mask)->PReLU on the same y, plus residual
     yy = H.from_cl(ycl).double().requires_grad_(True)
     sd64 = {k2: (v.double() if v.is_floating_point() else v) for k2, v in sd.items()}
@@ -234,11 +241,11 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop):
     ref.backward(H.from_cl(gcl).double())
     sums = torch.zeros(L.STAT_SHARDS, 3, c, dtype=torch.float64, device="cuda")
     aacc = torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
-    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), S))
+    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, sums.data_ptr(), c, aacc.data_ptr(), kptr, S))
     dg, db, da, drb = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda"), torch.zeros(c, device="cuda")
     L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), drb.data_ptr(), S))
     dy = torch.zeros_like(ycl)
-    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), S))
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt, vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), kptr, S))
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(dy).numpy(), yy.grad.float().numpy(), atol=_tol(dt, yy.grad))
     np.testing.assert_allclose(dg.cpu().numpy(), sd64["b.norm.weight"].grad.float().numpy(), rtol=1e-4, atol=1e-3)

@@ -62,13 +62,17 @@ def main():
         dpre = torch.empty((a.batch, *dims, 8), device="cuda").to(dt)
         dbias = torch.zeros(1, device="cuda")
         p = [v.data_ptr() for v in vec]
+        keep = torch.zeros(nvox * c // 8, dtype=torch.uint8, device="cuda")  # stored dropout keep-mask (one byte per 8-channel group)
+        KEEP_W = keep.data_ptr()
         T = lambda t: H.tdesc(t, c=c) if t.shape[-1] != 8 else H.tdesc(t)  # noqa: E731
         rows = [
-            ("bn_act_fwd", 2 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, T(res), 0, T(out), st))),
-            ("bn_act_fwd+res", 3 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, T(res), 1, T(out), st))),
-            ("bn_act_fwd p=0", 2 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), 0.0, 7, 3, T(res), 0, T(out), st))),
-            ("bn_act_bwd_reduce", 2 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_reduce(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, sums.data_ptr(), c, acc.data_ptr(), st))),
-            ("bn_act_bwd_apply", 3 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_apply(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, p[6], p[7], T(dy), st))),
+            ("bn_act_fwd", 2 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, T(res), 0, T(out), KEEP_W, st))),
+            ("bn_act_fwd+res", 3 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, T(res), 1, T(out), KEEP_W, st))),
+            ("bn_act_fwd p=0", 2 * tb, lambda: L.check(lib.vsseg_bn_act_fwd(T(y), p[2], p[3], alpha.data_ptr(), 0.0, 7, 3, T(res), 0, T(out), KEEP_W, st))),
+            ("bn_act_bwd_reduce", 2 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_reduce(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, sums.data_ptr(), c, acc.data_ptr(), None, st))),
+            ("bn_act_bwd_reduce keep", 2 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_reduce(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, sums.data_ptr(), c, acc.data_ptr(), KEEP_W, st))),
+            ("bn_act_bwd_apply", 3 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_apply(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, p[6], p[7], T(dy), None, st))),
+            ("bn_act_bwd_apply keep", 3 * tb, lambda: L.check(lib.vsseg_bn_act_bwd_apply(T(y), T(dout), p[0], p[1], p[4], p[5], p[2], p[3], alpha.data_ptr(), a.pdrop, 7, 3, p[6], p[7], T(dy), KEEP_W, st))),
             ("att_apply_fwd", 2 * tb + nvox * 4, lambda: L.check(lib.vsseg_att_apply_fwd(T(y), att.data_ptr(), T(out), st))),
             ("att_apply_bwd", 3 * tb + nvox * (4 + 8 * es), lambda: L.check(lib.vsseg_att_apply_bwd(T(y), att.data_ptr(), T(dout), None, T(dy), 0, T(dpre), dbias.data_ptr(), None, st))),
             ("torch copy", 2 * tb, lambda: out.copy_(y)),
@@ -76,7 +80,7 @@ def main():
         print(f"--- c={c} dims={dims} batch={a.batch} {a.dtype}: one tensor = {tb / 1e6:.0f} MB")
         for name, nbytes, fn in rows:
             ms = timed(fn, a.reps)
-            print(f"  {name:20s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.0f} GB/s")
+            print(f"  {name:24s} {ms:8.3f} ms  {nbytes / ms / 1e6:8.0f} GB/s")
 
 
 if __name__ == "__main__":

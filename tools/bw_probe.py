@@ -29,5 +29,5 @@ att = torch.rand(4 * 384 * 128 * 128, device="cuda")
 S = torch.cuda.current_stream().cuda_stream
 ms = t(lambda: lib.vsseg_att_apply_fwd(td(x), att.data_ptr(), td(o), S)); print(f"att_apply_fwd 32ch: {ms:.3f} ms  {(2*n*2 + att.numel()*4)/ms/1e6:.0f} GB/s")
 sc = torch.rand(32, device="cuda"); al = torch.tensor([0.25], device="cuda")
-ms = t(lambda: lib.vsseg_bn_act_fwd(td(x), sc.data_ptr(), sc.data_ptr(), al.data_ptr(), 0.1, 123, 1, L.Tensor(), 0, td(o), S)); print(f"bn_act_fwd 32ch dropout: {ms:.3f} ms  {2*n*2/ms/1e6:.0f} GB/s")
-ms = t(lambda: lib.vsseg_bn_act_fwd(td(x), sc.data_ptr(), sc.data_ptr(), al.data_ptr(), 0.0, 123, 1, L.Tensor(), 0, td(o), S)); print(f"bn_act_fwd 32ch no dropout: {ms:.3f} ms  {2*n*2/ms/1e6:.0f} GB/s")
+ms = t(lambda: lib.vsseg_bn_act_fwd(td(x), sc.data_ptr(), sc.data_ptr(), al.data_ptr(), 0.1, 123, 1, L.Tensor(), 0, td(o), None, S)); print(f"bn_act_fwd 32ch dropout: {ms:.3f} ms  {2*n*2/ms/1e6:.0f} GB/s")
+ms = t(lambda: lib.vsseg_bn_act_fwd(td(x), sc.data_ptr(), sc.data_ptr(), al.data_ptr(), 0.0, 123, 1, L.Tensor(), 0, td(o), None, S)); print(f"bn_act_fwd 32ch no dropout: {ms:.3f} ms  {2*n*2/ms/1e6:.0f} GB/s")

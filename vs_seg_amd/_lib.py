@@ -136,11 +136,11 @@ def lib():
         L.vsseg_stage_input.argtypes = [vp, i32, I3, I3, Tensor, vp]
         L.vsseg_bn_finalize.argtypes = [vp, i32, i32, f64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp]
         L.vsseg_bn_fold_eval.argtypes = [vp, vp, vp, vp, f32, vp, vp, i32, vp]
-        L.vsseg_bn_act_fwd.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, Tensor, i32, Tensor, vp]
-        L.vsseg_bn_act_fwd_res1.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, vp, vp, vp, Tensor, vp]
-        L.vsseg_bn_act_bwd_reduce.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, i32, vp, vp]
+        L.vsseg_bn_act_fwd.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, Tensor, i32, Tensor, vp, vp]
+        L.vsseg_bn_act_fwd_res1.argtypes = [Tensor, vp, vp, vp, f32, u64, u32, vp, vp, vp, Tensor, vp, vp]
+        L.vsseg_bn_act_bwd_reduce.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, i32, vp, vp, vp]
         L.vsseg_bn_act_bwd_finalize.argtypes = [vp, i32, vp, i32, f64, vp, vp, vp, vp, vp, vp, vp]
-        L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp]
+        L.vsseg_bn_act_bwd_apply.argtypes = [Tensor, Tensor, vp, vp, vp, vp, vp, vp, vp, f32, u64, u32, vp, vp, Tensor, vp, vp]
         L.vsseg_dropout_mask.argtypes = [vp, i64, i32, f32, u64, u32, vp]
         L.vsseg_att_apply_fwd.argtypes = [Tensor, vp, Tensor, vp]
         L.vsseg_att_apply_bwd.argtypes = [Tensor, vp, Tensor, vp, Tensor, i32, Tensor, vp, vp, vp]

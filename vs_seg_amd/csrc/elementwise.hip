@@ -183,7 +183,7 @@ extern "C" int vsseg_bn_fold_eval(const float* gamma, const float* beta, const f
 template <typename T, int RES>
 __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ alpha_p,
                                   float p_drop, uint64_t seed, uint32_t salt, const T* __restrict__ res, int rp, T* __restrict__ out, int op, int cgs, int64_t nvox,
-                                  const float* __restrict__ rw, const float* __restrict__ rb) {
+                                  const float* __restrict__ rw, const float* __restrict__ rb, uint8_t* __restrict__ keep_out) {
   const int64_t total = nvox * cgs;
   const float alpha = *alpha_p, inv_keep = 1.f / (1.f - p_drop);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -191,6 +191,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
     int c = (int)(i - v * cgs) * 8;
     f8 x = ld8(y + v * yp + c);
     unsigned keep = p_drop > 0.f ? dropout_keep8(seed, salt, (uint64_t)i, p_drop) : 0xffu;
+    if (keep_out) keep_out[i] = (uint8_t)keep;  // one byte per (voxel, 8-channel group): the backward passes read it instead of re-running Philox twice
     f8 r;
     if (RES == 1) r = ld8(res + v * rp + c);
     if (RES == 2) {
@@ -209,7 +210,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
   }
 }
 extern "C" int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
-                                vsseg_tensor res, int32_t has_res, vsseg_tensor out, void* stream) {
+                                vsseg_tensor res, int32_t has_res, vsseg_tensor out, uint8_t* keep_out, void* stream) {
   VSSEG_ONE_PART("vsseg_bn_act_fwd", &y, &res, &out);
   VSSEG_CHECK(y.ptr && out.ptr && scale && shift && alpha && y.c % 8 == 0 && y.pitch % 8 == 0 && out.pitch % 8 == 0 && out.c == y.c && out.dtype == y.dtype, "vsseg_bn_act_fwd: bad arguments");
   VSSEG_CHECK(!has_res || (res.ptr && res.dtype == y.dtype && res.c == y.c && res.pitch % 8 == 0), "vsseg_bn_act_fwd: bad residual");
@@ -217,20 +218,20 @@ extern "C" int vsseg_bn_act_fwd(vsseg_tensor y, const float* scale, const float*
   int64_t nv = tensor_voxels(y);
   int cgs = y.c / 8;
   dim3 g(grid_for(nv * cgs, 256)), b(256);
-  DISPATCH_T(y.dtype, if (has_res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)res.ptr, res.pitch, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr);
-             else hipLaunchKernelGGL((bn_act_fwd_kernel<T, 0>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)nullptr, 0, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr));
+  DISPATCH_T(y.dtype, if (has_res) hipLaunchKernelGGL((bn_act_fwd_kernel<T, 1>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)res.ptr, res.pitch, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr, keep_out);
+             else hipLaunchKernelGGL((bn_act_fwd_kernel<T, 0>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)nullptr, 0, (T*)out.ptr, out.pitch, cgs, nv, (const float*)nullptr, (const float*)nullptr, keep_out));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_fwd");
   return VSSEG_OK;
 }
 extern "C" int vsseg_bn_act_fwd_res1(vsseg_tensor y, const float* scale, const float* shift, const float* alpha, float p_drop, uint64_t seed, uint32_t salt,
-                                     const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, void* stream) {
+                                     const void* x1, const float* res_w, const float* res_b, vsseg_tensor out, uint8_t* keep_out, void* stream) {
   VSSEG_ONE_PART("vsseg_bn_act_fwd_res1", &y, &out);
   VSSEG_CHECK(y.ptr && out.ptr && scale && shift && alpha && x1 && res_w && res_b && y.c % 8 == 0 && y.pitch % 8 == 0 && out.pitch % 8 == 0 && out.c == y.c && out.dtype == y.dtype, "vsseg_bn_act_fwd_res1: bad arguments");
   VSSEG_CHECK(p_drop >= 0.f && p_drop < 1.f, "vsseg_bn_act_fwd_res1: dropout p out of range");
   int64_t nv = tensor_voxels(y);
   int cgs = y.c / 8;
   dim3 g(grid_for(nv * cgs, 256)), b(256);
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, 2>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)x1, 0, (T*)out.ptr, out.pitch, cgs, nv, res_w, res_b));
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_fwd_kernel<T, 2>), g, b, 0, as_stream(stream), (const T*)y.ptr, y.pitch, scale, shift, alpha, p_drop, seed, salt, (const T*)x1, 0, (T*)out.ptr, out.pitch, cgs, nv, res_w, res_b, keep_out));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_fwd_res1");
   return VSSEG_OK;
 }
@@ -299,7 +300,8 @@ template <> struct Raw8<float> {
 };
 
 template <typename T, int U>
-__global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc) {
+__global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc,
+                                                               const uint8_t* __restrict__ keep_in) {
   extern __shared__ float red[];  // [3][c] + [1]
   const int C = cgs * 8;
   for (int i = threadIdx.x; i < 3 * C + 1; i += blockDim.x) red[i] = 0.f;
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   const float inv_keep = 1.f / (1.f - a.p_drop);
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
   const int64_t vstep = nthreads / cgs;
-  auto one = [&](const f8& yy, const f8& da, int64_t v) {
-    const unsigned keep = drop ? dropout_keep8(a.seed, a.salt, (uint64_t)(v * cgs + cg), a.p_drop) : 0xffu;
+  // keep-mask: the byte the forward stored for this (voxel, 8-channel group) when the caller kept one (keep_in), else Philox again
+  auto one = [&](const f8& yy, const f8& da, unsigned keep) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float z = yy.v[j] * sc[j] + sh[j];
@@ -329,15 +331,18 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
       s1[j] += dz; s2[j] += dz * yy.v[j]; s3[j] += g;
     }
   };
+  const bool stored = drop && keep_in != nullptr;
+  auto mask_of = [&](int64_t vv) -> unsigned { return !drop ? 0xffu : (stored ? (unsigned)keep_in[vv * cgs + cg] : dropout_keep8(a.seed, a.salt, (uint64_t)(vv * cgs + cg), a.p_drop)); };
   int64_t v = gt / cgs;
   for (; v + (U - 1) * vstep < nvox; v += U * vstep) {
     Raw8<T> yv[U], dv[U];
+    unsigned kp[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { yv[u] = Raw8<T>::ld(y + (v + u * vstep) * yp + c); dv[u] = Raw8<T>::ld(dout + (v + u * vstep) * dp + c); }
+    for (int u = 0; u < U; ++u) { yv[u] = Raw8<T>::ld(y + (v + u * vstep) * yp + c); dv[u] = Raw8<T>::ld(dout + (v + u * vstep) * dp + c); kp[u] = mask_of(v + u * vstep); }
 #pragma unroll
-    for (int u = 0; u < U; ++u) one(yv[u].cvt(), dv[u].cvt(), v + u * vstep);
+    for (int u = 0; u < U; ++u) one(yv[u].cvt(), dv[u].cvt(), kp[u]);
   }
-  for (; v < nvox; v += vstep) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
+  for (; v < nvox; v += vstep) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), mask_of(v));
 #pragma unroll
   for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[3 * C]);
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
-                                       float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, void* stream) {
+                                       float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, const uint8_t* keep_in, void* stream) {
   VSSEG_ONE_PART("vsseg_bn_act_bwd_reduce", &y, &dout);
   VSSEG_CHECK(y.ptr && dout.ptr && y.dtype == dout.dtype && y.c == dout.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && sums && alpha_acc && stride >= y.c, "vsseg_bn_act_bwd_reduce: bad arguments");
   int cgs = y.c / 8, blk = block_for_cgs(cgs);
@@ -365,12 +370,12 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   size_t lds = (3 * y.c + 1) * sizeof(float);
   if (unroll == 2) {
     int grid = grid_for((nv * cgs + 1) / 2, blk, 256 * 8);
-    DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
+    DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
     VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
     return VSSEG_OK;
   }
   int grid = grid_for((nv * cgs + 3) / 4, blk, 256 * 8);
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc));
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }
@@ -404,7 +409,7 @@ extern "C" int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, con
 // registers and the loop body is address adds + two independent 16-byte load pairs (U = 2 voxels in flight per thread).
 template <typename T>
 __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, const float* __restrict__ mean_dz, const float* __restrict__ mean_dzx,
-                                        T* __restrict__ dy, int dyp, int cgs, int64_t nvox) {
+                                        T* __restrict__ dy, int dyp, int cgs, int64_t nvox, const uint8_t* __restrict__ keep_in) {
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs), c = cg * 8;
   const int64_t vstep = nthreads / cgs;
@@ -416,8 +421,9 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
   }
   const float alpha = *a.alpha, inv_keep = 1.f / (1.f - a.p_drop);
   const bool drop = a.p_drop > 0.f;
+  const bool stored = drop && keep_in != nullptr;
   auto one = [&](const f8& yy, const f8& da, int64_t v) {
-    const unsigned keep = drop ? dropout_keep8(a.seed, a.salt, (uint64_t)(v * cgs + cg), a.p_drop) : 0xffu;
+    const unsigned keep = !drop ? 0xffu : (stored ? (unsigned)keep_in[v * cgs + cg] : dropout_keep8(a.seed, a.salt, (uint64_t)(v * cgs + cg), a.p_drop));
     f8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -442,7 +448,7 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
   if (v < nvox) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
 }
 extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
-                                      float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, void* stream) {
+                                      float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, const uint8_t* keep_in, void* stream) {
   VSSEG_ONE_PART("vsseg_bn_act_bwd_apply", &y, &dout, &dy);
   VSSEG_CHECK(y.ptr && dout.ptr && dy.ptr && y.dtype == dout.dtype && y.dtype == dy.dtype && y.c == dout.c && y.c == dy.c && y.c % 8 == 0 && y.pitch % 8 == 0 && dout.pitch % 8 == 0 && dy.pitch % 8 == 0,
               "vsseg_bn_act_bwd_apply: bad arguments");
@@ -450,7 +456,7 @@ extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const f
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_apply: unsupported channel count %d", y.c);
   int64_t nv = tensor_voxels(y);
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for((nv * cgs + 1) / 2, blk, 256 * 8)), dim3(blk), 0, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, mean_dz, mean_dzx, (T*)dy.ptr, dy.pitch, cgs, nv));
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for((nv * cgs + 1) / 2, blk, 256 * 8)), dim3(blk), 0, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, mean_dz, mean_dzx, (T*)dy.ptr, dy.pitch, cgs, nv, keep_in));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_apply");
   return VSSEG_OK;
 }

@@ -120,7 +120,11 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 // 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
+#ifdef VSSEG_DMA_BUILTIN
   __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_wave_base, 16, 0, 0);
+#else
+  vsseg_dma16(gsrc, lds_wave_base);  // inline assembly: see common.h (the builtin made hipcc drain the DMA queue in front of every K loop)
+#endif
 }
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the immediate must be a literal.  Waiting for a SMALLER count than
@@ -710,6 +714,10 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
         }
       }
     }
+    // The slow path's ordinary loads (residual / previous gradient / gate of boundary tiles) leave hipcc's scoreboard with "maybe pending"
+    // VGPRs at the loop header; it then put `s_waitcnt vmcnt(0)` in front of the K loop of EVERY stage — right behind the next stage's DMA
+    // issue, which serialised the ring.  An explicit (modelled) wait here, on the rare path, leaves the merged state clean.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
     }  // slow epilogue
   }
 

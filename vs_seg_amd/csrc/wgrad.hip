@@ -28,6 +28,7 @@ struct WgradK {
   int lds_hbase, lds_p, lds_h, lds_tab;
   int npp, nph;   // rows of the per-thread coordinate tables (P pieces, H pieces) kept in LDS for the boundary-tile path
   int nbuf;       // 2: tile s+1 streams in while tile s is multiplied; 1: no prefetch, half the LDS, more resident workgroups
+  int walk;       // 1: XCD-contiguous tile walk (see the kernel)
   int hchunks;    // 16-channel chunks of H in total (slab layout); a workgroup owns HG consecutive ones
   int64_t total_tiles;
   const void* zeros;  // >= 16 zero bytes in global memory (source of out-of-bounds pieces)
@@ -38,7 +39,11 @@ struct WgradK {
 typedef __attribute__((address_space(1))) const void wg_gvoid_t;
 typedef __attribute__((address_space(3))) void wg_lvoid_t;
 __device__ __forceinline__ void wg_dma16(const void* gsrc, char* lds_wave_base) {  // LDS address = wave-uniform base + lane*16
+#ifdef VSSEG_DMA_BUILTIN
   __builtin_amdgcn_global_load_lds((wg_gvoid_t*)gsrc, (wg_lvoid_t*)lds_wave_base, 16, 0, 0);
+#else
+  vsseg_dma16(gsrc, lds_wave_base);  // inline assembly: see common.h (the builtin made hipcc wait for tile s+1 before multiplying tile s)
+#endif
 }
 constexpr int WPP = 12;  // 16-byte pieces of the P tile per thread  (P tile <= 48 KiB)
 constexpr int WPH = 16;  // ... of the H halo tile per thread         (halo    <= 64 KiB)
@@ -139,7 +144,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     t.n = b / k.ntile[0];
     return t;
   };
-  const int G = gridDim.x;
+  // Tile walk.  Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), so with the plain walk "tile = b + s*G" the
+  // y- and x-neighbours of a tile — which share two halo rows with it — are in flight on OTHER XCDs and every XCD's L2 fetches those rows from
+  // HBM again (PMC: 1.46x the algorithmic bytes on the 16-channel full-resolution layers).  With k.walk, XCD x owns the contiguous range
+  // [x*tpx, (x+1)*tpx) of the (n, x, y, z)-ordered tile list and its workgroups stride through it: the tiles in flight on one XCD form a
+  // compact brick whose shared rows are L2 hits.
+  const bool xwalk = k.walk && (gridDim.x % 8) == 0 && k.total_tiles >= 8 * (int64_t)(gridDim.x / 8);
+  const int G = xwalk ? (int)gridDim.x / 8 : (int)gridDim.x;
+  const int tpx = xwalk ? (int)((k.total_tiles + 7) / 8) : (int)k.total_tiles;
+  const int t_first = xwalk ? (int)(blockIdx.x & 7) * tpx : 0;
+  const int slot = xwalk ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int t_cnt = (int)k.total_tiles - t_first;
+  t_cnt = t_cnt > tpx ? tpx : (t_cnt < 0 ? 0 : t_cnt);
   const TileIdx step = tile_decode(G);
   auto tile_advance = [&](TileIdx& t) {
     t.tz += step.tz; if (t.tz >= k.ntile[2]) { t.tz -= k.ntile[2]; ++t.ty; }
@@ -147,8 +163,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     t.tx += step.tx; if (t.tx >= k.ntile[0]) { t.tx -= k.ntile[0]; ++t.n; }
     t.n += step.n;
   };
-  TileIdx t_issue = tile_decode((int)blockIdx.x);
-  const int my_tiles = (int)blockIdx.x < (int)k.total_tiles ? ((int)k.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+  TileIdx t_issue = tile_decode(t_first + slot);
+  const int my_tiles = slot < t_cnt ? (t_cnt - 1 - slot) / G + 1 : 0;
 
   const int bufmask = k.nbuf - 1;
   auto issue = [&](int s) {  // LDS-DMA of tile s into buffer s & bufmask
@@ -369,6 +385,7 @@ template <typename T, int MAXT, int NTP, int HG> static int wg_launch(WgradK& k,
     unsigned cap = (unsigned)(256 * cached_per_cu) / grid.y;
     if (cap < 1) cap = 1;
     if (grid.x > cap) grid.x = cap;
+    if (k.walk && grid.x >= 8) grid.x &= ~7u;  // whole rounds of the 8 XCDs (the XCD-contiguous walk needs gridDim.x % 8 == 0)
     hipLaunchKernelGGL((wgrad_kernel<T, MAXT, NTP, HG>), grid, dim3(256), lds, s, k);
     VSSEG_LAUNCH_CHECK("vsseg_wgrad");
     return VSSEG_OK;
@@ -469,6 +486,7 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   const int64_t cap = d->scratch_elems / ((int64_t)hchunks * k.slab_chunk);
   if (gx > cap) gx = cap;
   k.slab = d->scratch;
+  { static int walk = -1; if (walk < 0) { const char* e = getenv("VSSEG_WGRAD_WALK"); walk = e ? atoi(e) : 1; } k.walk = walk; }
   if (k.wv != 1) hipMemsetAsync(d->scratch, 0, sizeof(float) * gx * hchunks * k.slab_chunk, as_stream(stream));
   dim3 grid((unsigned)gx, (unsigned)(hchunks / hg));
   int rc = d->p.dtype == VSSEG_F32 ? vsseg_wgrad_launch_f32(k, maxt, hg, grid, off, as_stream(stream)) : vsseg_wgrad_launch_bf16(k, maxt, hg, grid, off, as_stream(stream));

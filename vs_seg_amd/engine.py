@@ -416,6 +416,14 @@ class Plan:
         p_drop = float(eng.dropout_p) if self.train else 0.0
         self.bn_info = {Lr.prefix: (Lr, salt[Lr.prefix] & ~L.SEED_INDIRECT) for Lr in bn_layers}
 
+        def keep_ptr(Lr: Layer):
+            """Dropout keep-mask bytes of a BatchNorm layer (one byte per voxel and 8-channel group = 1/16 of the bf16 activation): written by
+            the forward, read by both backward passes, which are otherwise VALU-bound on running Philox4x32-10 again (measured: the three
+            BN kernels ran at the same ~90-130 G iterations/s whatever they moved; VSSEG_KEEPMASK=0 regenerates instead)."""
+            if not (self.train and p_drop > 0.0 and eng.keepmask):
+                return None
+            return self._raw("keep:" + Lr.prefix, Lr.out_level, Lr.cout // 8, dtype=torch.uint8).data_ptr()
+
         # First encoder ResidualUnit (in_channels = 1): its 1x1x1 residual convolution is x1[v]*w[c] + b[c]; in training it is
         # computed inside the BN/dropout/PReLU kernel that adds it (vsseg_bn_act_fwd_res1) instead of by an igemm launch that
         # writes a 16-channel tensor for that kernel to read back.  (Eval adds the residual in the conv epilogue and keeps the launch.)
@@ -447,7 +455,7 @@ class Plan:
                         F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None, yd, sptr(0, pre), cpad[pre]]])
                         F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                           self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
-                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out], self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout)])
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out, keep_ptr(Lr)], self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout)])
                     else:
                         self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
                         F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), vptr(2, pre), vptr(3, pre), alp, out, None, 0]])
@@ -459,10 +467,10 @@ class Plan:
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     if fused_res is not None:
                         x1 = self._xdesc(fused_res.x, True)  # compact 1-channel copy of the network input
-                        F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out],
+                        F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out, keep_ptr(Lr)],
                                   self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout + 1)])
                     else:
-                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out],
+                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], res if res is not None else L.Tensor(), 1 if res is not None else 0, out, keep_ptr(Lr)],
                                   self._ew_meta("bn_act_fwd", Lr.out_level, (3 if res is not None else 2) * Lr.cout)])
                 else:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
@@ -629,7 +637,7 @@ class Plan:
                 yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
-                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre)],
+                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre), keep_ptr(Lr)],
                           self._ew_meta("bn_act_bwd_reduce", Lr.out_level, 2 * Lr.cout)])
                 dres_bias = None
                 if op.res is not None and op.res.name in producer:  # residual conv: d(out)/d(res) = 1, its bias gradient is sum(dA) (reduced above)
@@ -638,7 +646,7 @@ class Plan:
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
                 dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd],
+                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd, keep_ptr(Lr)],
                           self._ew_meta("bn_act_bwd_apply", Lr.out_level, 3 * Lr.cout)])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
                     if contribution(op.res):
@@ -802,6 +810,7 @@ class Engine:
         # zero-extended MFMA launch on the full-resolution 1->16 3x3x1 layer (the stencil is issue-bound at ~16 % VALU utilisation).
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
+        self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.overlap = os.environ.get("VSSEG_OVERLAP", "0") == "1" and not dry_run  # weight gradients on a second HIP stream, concurrent with the data-gradient chain
         self._side = None
