@@ -421,6 +421,98 @@ def test_streaming_kernel_equals_general_kernel(kind, k, cin, cout, dims, split)
             np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
 
 
+COMPUTE_CASES = [
+    # kind, cin, cout, dims, input split
+    ("conv_fwd", 32, 48, (8, 16, 32), 0),     # every tile touches the border
+    ("conv_fwd", 96, 48, (12, 24, 48), 48),   # level-2 concat read as a two-part tensor; the centre tile is interior
+    ("conv_dgrad", 96, 48, (8, 16, 32), 0),   # K = 48, N = 96: two workgroups per voxel tile (nsplit 2)
+    ("conv_dgrad", 32, 48, (8, 16, 32), 0),   # K = 48, N = 32: two 16-channel tiles per workgroup
+    ("conv_fwd", 64, 64, (8, 8, 16), 0),      # level-3 shape: 2 x 2 channel tiles
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,dims,split", COMPUTE_CASES)
+def test_compute_kernel_equals_general_kernel(kind, cin, cout, dims, split):
+    """depth -3 selects the compile-time-geometry kernel for the MFMA-bound stride-1 3x3x3 launches (csrc/cconv.hip).  Same packed
+    weights, K order and fp32 accumulation as the general kernel: outputs must be IDENTICAL bit for bit in every epilogue mode (and match
+    the fp64 definition within the bf16 output rounding); BatchNorm statistics agree up to the order of the fp32 partial sums."""
+    lib = L.lib()
+    dt, k = "bf16", (3, 3, 3)
+    torch.manual_seed(7)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * 27) ** 0.5, dt)
+    b = torch.randn(cout)
+    xd = x.double().requires_grad_(True)
+    y = F.conv3d(xd, w.double(), b.double(), padding=P.same_pad(k))
+    if kind == "conv_fwd":
+        inp_cl, want, nout, bias = H.to_cl(x, H.DT[dt]), y.detach(), cout, b.cuda()
+    else:
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        inp_cl, want, nout, bias = H.to_cl(gy, H.DT[dt]), xd.grad, cin, None
+    cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
+    kc = inp_cl.shape[-1]
+    # the general kernel's plan with the same 16-channel chunking: same K order, hence the same fp32 accumulation order
+    gen = next(c for c in P.candidate_plans(kind, tuple(w.shape), cls, dims, 2, kc_pad=kc, in_split=split, aux_es=2) if c.ck == 16 and c.depth >= 0)
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    cp = P.compute_plan(kind, tuple(w.shape), cls, dims, 2, kc, nreal, kreal, split)
+    assert cp is not None and cp.depth == -3 and gen.depth != -3
+    cp.pack_map = P.pack_map(cp, tuple(w.shape))
+    parts = H._split_cl(inp_cl, split) if split else None
+    res_t = H.to_cl(_round(torch.randn(2, nout, *dims), dt), H.DT[dt])
+    gate_t = torch.rand(2, *dims, device="cuda")
+    alpha = torch.tensor([0.25], device="cuda")
+    for mode in ["plain", "stats", "prelu", "accumulate", "res_add", "relu_mask", "gate"]:
+        outs = []
+        for pl in (gen, cp):
+            out = torch.zeros(2, *dims, nout, dtype=H.DT[dt], device="cuda")
+            kw, stats = {}, None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "prelu":
+                kw = dict(act=L.ACT_PRELU, alpha=alpha.data_ptr())
+            elif mode == "accumulate":
+                out = res_t.clone()
+                kw = dict(accumulate=1)
+            elif mode in ("res_add", "relu_mask", "gate"):
+                kw = dict(res=H.tdesc(res_t), res_mode={"res_add": L.RES_ADD, "relu_mask": L.RES_RELUMASK, "gate": L.RES_GATE}[mode])
+                if mode == "gate":
+                    kw["gate"] = gate_t.data_ptr()
+            if bias is not None:
+                kw["bias"] = bias.data_ptr()
+            wp = H.pack(pl, w, inp_cl.dtype)
+            d = H.igemm_desc(pl, wp, H.two_part(*parts) if parts else H.tdesc(inp_cl), H.tdesc(out), **kw)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm D={pl.depth} {mode}")
+            torch.cuda.synchronize()
+            outs.append((out, stats))
+        (og, sg), (oc, sc) = outs
+        assert torch.equal(og, oc), f"{mode}: compute kernel differs from the general kernel (max {float((og.float() - oc.float()).abs().max())})"
+        if mode == "plain":
+            np.testing.assert_allclose(H.from_cl(oc).numpy(), want.float().numpy(), atol=_tol(dt, want))
+        if mode == "stats":
+            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), sc.view(L.STAT_SHARDS, 2, -1).sum(0)
+            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
+
+
+def test_compute_kernel_rejects_what_it_does_not_cover():
+    """depth -3 outside the compute kernel's domain is an error (no silent fallback to the general kernel)."""
+    lib = L.lib()
+    k, cin, cout, dims = (3, 3, 3), 32, 48, (8, 16, 24)  # 24 is not a multiple of the 16-voxel tile
+    w = torch.randn(cout, cin, *k)
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    assert P.compute_plan("conv_fwd", tuple(w.shape), cls, dims, 2, cin, cout, cin) is None
+    pl = P.plan_igemm("conv_fwd", tuple(w.shape), cls, dims, 2, kc_pad=cin)
+    pl.pack_map = P.pack_map(pl, tuple(w.shape))
+    x = torch.zeros(1, *dims, cin, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, *dims, cout, dtype=torch.bfloat16, device="cuda")
+    d = H.igemm_desc(pl, H.pack(pl, w, x.dtype), H.tdesc(x), H.tdesc(out))
+    d.depth = -3
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL
+    assert b"compute kernel" in lib.vsseg_last_error()
+
+
 def test_streaming_kernel_rejects_what_it_does_not_cover():
     """depth -2 on a launch outside the streaming kernel's domain is an error (no silent fallback to the general kernel)."""
     lib = L.lib()

@@ -26,6 +26,9 @@ def bench_name(short_name):
     m = re.match(r"sconv_kernel<(\d+), (\d+), (\d+), \d+>", short_name)  # streaming kernel: the MODE / tap / input-channel variants of one NT share a bench name
     if m:
         return f"sconv<bf16,{m.group(2)}>"
+    m = re.match(r"cconv_kernel<(\d+), \d+>", short_name)  # compute-bound kernel: the MODE variants of one NT share a bench name
+    if m:
+        return f"cconv<bf16,{m.group(1)}>"
     m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)(, \d+)?>", short_name)  # MAXT / H-group variants of one (type, NTP) share a bench name
     if m:
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"

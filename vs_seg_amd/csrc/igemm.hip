@@ -2,6 +2,7 @@
 // The kernel itself is in igemm_kernel.h (instantiated by igemm_inst.hip).
 #include "igemm_kernel.h"
 #include "sconv.h"
+#include "cconv.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
@@ -169,6 +170,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
 
 extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && d->depth == -2) return vsseg_sconv_lds_bytes(d);
+  if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
@@ -179,6 +181,12 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_sconv_launch(d, z, as_stream(stream));
+  }
+  if (d && d->depth == -3) {  // compute-bound kernel (cconv.hip): same contract — outside its domain is an error
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_cconv_launch(d, z, as_stream(stream));
   }
   IgemmK k;
   int lds = igemm_prepare(d, k);

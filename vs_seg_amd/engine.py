@@ -378,7 +378,7 @@ class Plan:
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
-        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth == -2 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"), kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth == -2 else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
                     bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)

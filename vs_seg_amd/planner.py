@@ -185,6 +185,36 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
     return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, stream_tile(kc, ntaps), stream_mt(kc, ntaps), nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
 
 
+# ---- compute-bound kernel (csrc/cconv.hip): depth -3 -----------------------------------------------------------------------
+COMPUTE_TILE = (4, 8, 16)
+_TAPS_3x3x3 = [(t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1) for t in range(27)]
+
+
+def compute_split(nreal):
+    """(nt, nsplit) of the compute-bound kernel for `nreal` output channels: 2 or 3 sixteen-channel tiles per workgroup, 1 or 2 workgroups
+    per voxel tile (cc_check() in csrc/cconv.hip)."""
+    return {32: (2, 1), 48: (3, 1), 64: (2, 2), 96: (3, 2)}.get(nreal)
+
+
+def compute_lds_bytes(nt):
+    return 2 * (34 * 1024 + 14 * nt * 1024) + 3 * nt * 16 * 4
+
+
+def compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split=0) -> Optional["IgemmPlan"]:
+    """The depth -3 candidate: the compile-time-geometry kernel for the MFMA-bound launches (stride-1 3x3x3 bf16, input channels a multiple
+    of 16 processed in 16-channel chunks, 32 / 48 / 64 / 96 output channels, extents divisible by the 4x8x16 tile)."""
+    offs = [tuple(t[0]) for t in cls.taps]
+    if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x3:
+        return None
+    if any(v % t for v, t in zip(q, COMPUTE_TILE)) or kc % 16 or kc < 32 or kc != round_up(kreal, 16) or (in_split and in_split % 16):
+        return None
+    sp = compute_split(nreal)
+    if sp is None:
+        return None
+    nt, nsplit = sp
+    return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, COMPUTE_TILE, 8, nt, nsplit, 16, kc // 16, 14, compute_lds_bytes(nt), -3)
+
+
 def _pow2_floor(v):
     p = 1
     while p * 2 <= v:
@@ -318,6 +348,9 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     sp = stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal)
     if sp is not None and not in_split_unsupported(in_split, kc):
         rest = rest + [sp]
+    cp = compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split)
+    if cp is not None:
+        rest = rest + [cp]
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
