@@ -1,6 +1,7 @@
 // HBM-bound kernels of the hot path: BatchNorm/Dropout/PReLU forward+backward, attention gate, staging, Adam.
 // All are one-pass streaming kernels with 16-byte (8 x bf16) accesses along the channel axis of the channels-last layout.
 #include "common.h"
+#include <algorithm>
 
 #define DISPATCH_T(dtype, ...)                         \
   do {                                                 \
@@ -368,13 +369,18 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   static int unroll = -1;  // voxels in flight per thread (tuning aid: VSSEG_BN_REDUCE_U = 2 | 4)
   if (unroll < 0) { const char* e = getenv("VSSEG_BN_REDUCE_U"); unroll = e ? atoi(e) : 2; }
   size_t lds = (3 * y.c + 1) * sizeof(float);
+  // Every workgroup ends with 3*C fp64 atomics into the sharded sums: on the small tensors of the deep levels a grid sized for streaming
+  // (one item pair per thread) spent more time in those atomics than in the pass (18 launches of levels 2-5 averaged 69 us against 23 us
+  // for the apply pass over the same tensors).  At least 16 voxel groups per thread before another workgroup is worth its flush.
+  const int64_t items = nv * cgs;
+  const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(256, items / ((int64_t)blk * 16)));
   if (unroll == 2) {
-    int grid = grid_for((nv * cgs + 1) / 2, blk, 256 * 8);
+    int grid = grid_for((nv * cgs + 1) / 2, blk, cap);
     DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
     VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
     return VSSEG_OK;
   }
-  int grid = grid_for((nv * cgs + 3) / 4, blk, 256 * 8);
+  int grid = grid_for((nv * cgs + 3) / 4, blk, cap);
   DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
