@@ -131,6 +131,31 @@ def test_wgrad(k, s, cin, cout, dims, tr, dt):
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("k,cin,cout,dims", [((3, 3, 1), 1, 16, (12, 16, 8)), ((1, 1, 1), 1, 16, (6, 8, 4)), ((3, 3, 1), 16, 1, (12, 16, 8)), ((3, 3, 1), 32, 1, (5, 8, 12)), ((3, 3, 1), 1, 8, (3, 4, 2))])
+def test_wgrad_narrow(k, cin, cout, dims, dt):
+    """vsseg_wgrad_narrow: the weight gradient of a convolution with one input or one output channel as a bandwidth reduction, against
+    torch's fp64 autograd (same bar as the MFMA weight-gradient kernel it replaces on those layers)."""
+    lib = L.lib()
+    torch.manual_seed(9)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, padding=P.same_pad(k))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    dw = torch.zeros(cout, cin, *k, device="cuda")
+    if cin == 1:  # t = dY (cout channels), s = x, sign +1: dw[c][0][tap]
+        t_cl, s_cl, sign = H.to_cl(gy, H.DT[dt]), H.to_cl(x, H.DT[dt]), 1
+    else:  # t = x (cin channels), s = dY, sign -1: dw[0][c][tap]
+        t_cl, s_cl, sign = H.to_cl(x, H.DT[dt]), H.to_cl(gy, H.DT[dt]), -1
+    scr = torch.zeros(1 << 20, device="cuda")
+    for _ in range(2):  # accumulates into dw
+        L.check(lib.vsseg_wgrad_narrow(H.tdesc(t_cl), s_cl.data_ptr(), k[0], sign, dw.data_ptr(), k[0] * k[1], scr.data_ptr(), scr.numel(), H.stream()))
+    torch.cuda.synchronize()
+    ref = 2 * w.grad.float()
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.numpy(), atol=(5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("hg,sb", [(1, 1), (2, 0), (2, 1), (4, 0), (4, 1), (3, 1)])
 def test_wgrad_h_chunk_groups(hg, sb, dt):
     """One workgroup multiplies its P tile with `hgroup` 16-channel chunks of H (incl. a two-part H whose split lies inside a group,

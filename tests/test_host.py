@@ -39,7 +39,7 @@ def test_plans_lower_on_cpu(att, dt):
     n_conv = len(prog.layers)
     igemms = [r for r in tr.fwd if r[0] is eng.lib.vsseg_igemm]
     assert len(igemms) >= n_conv  # transposed convs launch one igemm per output-parity class
-    assert sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_wgrad) == n_conv - len(tr.merged)  # the final 1x1x1 residual conv is merged into the final 3x3x1 conv
+    assert sum(1 for r in tr.bwd if r[0] in (eng.lib.vsseg_wgrad, eng.lib.vsseg_wgrad_narrow)) == n_conv - len(tr.merged)  # the final 1x1x1 residual conv is merged into the final 3x3x1 conv
     assert len(tr.merged) == 1 and sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_merge_residual_grads) == 1
     assert len(ev.bwd) == 0 and len(ev.fwd) < len(tr.fwd)
     # every dropout launch reads the seed through the plan's device scalar (fixed arguments: the lists can be captured as hipGraphs)

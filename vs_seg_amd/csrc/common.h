@@ -118,6 +118,15 @@ __device__ __forceinline__ unsigned dropout_keep8(uint64_t seed, uint32_t salt, 
   return m;
 }
 
+// Resolve an indirect seed ONCE per kernel, in front of the element loop: inside dropout_keep8 the read sits behind a branch hipcc cannot
+// speculate, i.e. one scalar load + wait per 8 elements.
+__device__ __forceinline__ void dropout_resolve_seed(uint64_t& seed, uint32_t& salt) {
+  if (salt & VSSEG_SEED_INDIRECT) {
+    seed = *reinterpret_cast<const uint64_t*>(seed);
+    salt &= ~VSSEG_SEED_INDIRECT;
+  }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

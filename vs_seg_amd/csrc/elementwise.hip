@@ -2,6 +2,7 @@
 // All are one-pass streaming kernels with 16-byte (8 x bf16) accesses along the channel axis of the channels-last layout.
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
 
 #define DISPATCH_T(dtype, ...)                         \
   do {                                                 \
@@ -187,6 +188,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
                                   const float* __restrict__ rw, const float* __restrict__ rb, uint8_t* __restrict__ keep_out) {
   const int64_t total = nvox * cgs;
   const float alpha = *alpha_p, inv_keep = 1.f / (1.f - p_drop);
+  if (p_drop > 0.f) dropout_resolve_seed(seed, salt);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t v = i / cgs;
     int c = (int)(i - v * cgs) * 8;
@@ -238,6 +240,7 @@ extern "C" int vsseg_bn_act_fwd_res1(vsseg_tensor y, const float* scale, const f
 }
 
 __global__ void dropout_mask_kernel(float* mask, int64_t n8, float p, uint64_t seed, uint32_t salt) {
+  if (p > 0.f) dropout_resolve_seed(seed, salt);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
     unsigned keep = p > 0.f ? dropout_keep8(seed, salt, (uint64_t)i, p) : 0xffu;
     for (int j = 0; j < 8; ++j) mask[i * 8 + j] = (float)((keep >> j) & 1u);
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   for (int i = threadIdx.x; i < 3 * C + 1; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const float alpha = *a.alpha;
+  if (a.p_drop > 0.f && keep_in == nullptr) dropout_resolve_seed(a.seed, a.salt);
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs);
   const int c = cg * 8;
@@ -332,18 +336,29 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
       s1[j] += dz; s2[j] += dz * yy.v[j]; s3[j] += g;
     }
   };
-  const bool stored = drop && keep_in != nullptr;
-  auto mask_of = [&](int64_t vv) -> unsigned { return !drop ? 0xffu : (stored ? (unsigned)keep_in[vv * cgs + cg] : dropout_keep8(a.seed, a.salt, (uint64_t)(vv * cgs + cg), a.p_drop)); };
-  int64_t v = gt / cgs;
-  for (; v + (U - 1) * vstep < nvox; v += U * vstep) {
-    Raw8<T> yv[U], dv[U];
-    unsigned kp[U];
+  // The source of the keep-mask is decided ONCE, outside the loop: 0 no dropout, 1 the stored bytes, 2 Philox.  A per-element
+  // `stored ? load : philox()` makes hipcc branch around the byte load and wait for it inside the batch of independent loads.
+  auto sweep = [&](auto src_c) {
+    constexpr int SRC = decltype(src_c)::value;
+    auto mask_of = [&](int64_t vv) -> unsigned {
+      if constexpr (SRC == 0) return 0xffu;
+      else if constexpr (SRC == 1) return (unsigned)keep_in[vv * cgs + cg];
+      else return dropout_keep8(a.seed, a.salt, (uint64_t)(vv * cgs + cg), a.p_drop);
+    };
+    int64_t v = gt / cgs;
+    for (; v + (U - 1) * vstep < nvox; v += U * vstep) {
+      Raw8<T> yv[U], dv[U];
+      unsigned kp[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { yv[u] = Raw8<T>::ld(y + (v + u * vstep) * yp + c); dv[u] = Raw8<T>::ld(dout + (v + u * vstep) * dp + c); kp[u] = mask_of(v + u * vstep); }
+      for (int u = 0; u < U; ++u) { yv[u] = Raw8<T>::ld(y + (v + u * vstep) * yp + c); dv[u] = Raw8<T>::ld(dout + (v + u * vstep) * dp + c); kp[u] = mask_of(v + u * vstep); }
 #pragma unroll
-    for (int u = 0; u < U; ++u) one(yv[u].cvt(), dv[u].cvt(), kp[u]);
-  }
-  for (; v < nvox; v += vstep) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), mask_of(v));
+      for (int u = 0; u < U; ++u) one(yv[u].cvt(), dv[u].cvt(), kp[u]);
+    }
+    for (; v < nvox; v += vstep) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), mask_of(v));
+  };
+  if (!drop) sweep(std::integral_constant<int, 0>{});
+  else if (keep_in != nullptr) sweep(std::integral_constant<int, 1>{});
+  else sweep(std::integral_constant<int, 2>{});
 #pragma unroll
   for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
@@ -427,9 +442,8 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
   }
   const float alpha = *a.alpha, inv_keep = 1.f / (1.f - a.p_drop);
   const bool drop = a.p_drop > 0.f;
-  const bool stored = drop && keep_in != nullptr;
-  auto one = [&](const f8& yy, const f8& da, int64_t v) {
-    const unsigned keep = !drop ? 0xffu : (stored ? (unsigned)keep_in[v * cgs + cg] : dropout_keep8(a.seed, a.salt, (uint64_t)(v * cgs + cg), a.p_drop));
+  if (drop && keep_in == nullptr) dropout_resolve_seed(a.seed, a.salt);
+  auto one = [&](const f8& yy, const f8& da, unsigned keep, int64_t v) {
     f8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -444,15 +458,29 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
     }
     st8(dy + v * dyp + c, o);
   };
-  int64_t v = gt / cgs;
-  for (; v + vstep < nvox; v += 2 * vstep) {
-    const f8 y0 = ld8(y + v * yp + c), d0 = ld8(dout + v * dp + c);
-    const f8 y1 = ld8(y + (v + vstep) * yp + c), d1 = ld8(dout + (v + vstep) * dp + c);
-    one(y0, d0, v);
-    one(y1, d1, v + vstep);
-  }
-  if (v < nvox) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), v);
+  // mask source decided once, outside the loop (0 no dropout, 1 stored bytes, 2 Philox): see bn_act_bwd_reduce_kernel
+  auto sweep = [&](auto src_c) {
+    constexpr int SRC = decltype(src_c)::value;
+    auto mask_of = [&](int64_t vv) -> unsigned {
+      if constexpr (SRC == 0) return 0xffu;
+      else if constexpr (SRC == 1) return (unsigned)keep_in[vv * cgs + cg];
+      else return dropout_keep8(a.seed, a.salt, (uint64_t)(vv * cgs + cg), a.p_drop);
+    };
+    int64_t v = gt / cgs;
+    for (; v + vstep < nvox; v += 2 * vstep) {
+      const f8 y0 = ld8(y + v * yp + c), d0 = ld8(dout + v * dp + c);
+      const f8 y1 = ld8(y + (v + vstep) * yp + c), d1 = ld8(dout + (v + vstep) * dp + c);
+      const unsigned m0 = mask_of(v), m1 = mask_of(v + vstep);
+      one(y0, d0, m0, v);
+      one(y1, d1, m1, v + vstep);
+    }
+    if (v < nvox) one(ld8(y + v * yp + c), ld8(dout + v * dp + c), mask_of(v), v);
+  };
+  if (!drop) sweep(std::integral_constant<int, 0>{});
+  else if (keep_in != nullptr) sweep(std::integral_constant<int, 1>{});
+  else sweep(std::integral_constant<int, 2>{});
 }
+
 extern "C" int vsseg_bn_act_bwd_apply(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                       float p_drop, uint64_t seed, uint32_t salt, const float* mean_dz, const float* mean_dzx, vsseg_tensor dy, const uint8_t* keep_in, void* stream) {
   VSSEG_ONE_PART("vsseg_bn_act_bwd_apply", &y, &dout, &dy);

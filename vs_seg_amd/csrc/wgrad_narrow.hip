@@ -1,0 +1,157 @@
+// Weight gradient of the convolutions with ONE input or ONE output channel on the two finest levels (network input 1 -> 16, 3x3x1 and 1x1x1;
+// attention sigmoid convolutions 16 -> 1 and 32 -> 1, 3x3x1; ref:params/networks/nets/unet2d5_spvPA.py:56-93, attentionblock.py:10-30;
+// SURVEY §8a rows 0, 1, 42, 47) as a bandwidth reduction instead of an MFMA launch:
+//
+//     dW[c][tap (dx, dy)] = sum_v T[v][c] * s[v + sign * (dx, dy)]         T: the C-channel tensor, s: the one-channel field
+//
+//   1 -> C:  T = dY (C output channels), s = x (the network input),   sign = +1       (dW[c][0][tap])
+//   C -> 1:  T = x  (C input channels),  s = dY (one real channel),   sign = -1       (dW[0][c][tap]; substitution u = v + off)
+//
+// The MFMA kernel (wgrad.hip) zero-extends the one-channel operand to an 8-channel K group and builds both operands with transpose reads:
+// 0.41-0.43 ms per launch at full resolution, 2.0-2.1 TB/s of its algorithmic bytes, the matrix cores multiplying zeros.  Here a thread owns
+// one 8-channel group of 4 y-consecutive voxels: 4 coalesced 16-byte loads of T and the 3 x 6 values of s its 9 taps touch (the y taps of
+// neighbouring voxels overlap), 288 FMAs, 72 accumulators kept in registers over all its voxels; per workgroup one LDS reduction and one
+// slab of partial sums (plain stores), summed into dw by a second tiny kernel — 1024 workgroups x 144 fp32 atomics on the same 144
+// addresses measured 0.72 ms for the whole launch, slower than the MFMA kernel.  T is read exactly once, s nine times out of L1/L2.
+#include "common.h"
+
+struct WnK {
+  const void* t;
+  const void* s;
+  float* dw;
+  float* slab;  // [gridDim.x][NT * C] partial sums
+  int tpitch, C, cgs;
+  int n, X, Y, Z, yq;  // yq = Y / 4
+  int sign;
+  int64_t stride_c;
+  int64_t items;  // n * X * yq * Z work items per channel group
+};
+
+template <typename T> __device__ __forceinline__ float wn_ld(const T* p);
+template <> __device__ __forceinline__ float wn_ld<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float wn_ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+
+template <typename T, int K3>  // K3: 3 = 3x3x1 taps, 1 = 1x1x1
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
+  constexpr int NT = K3 * K3, ROWS = K3 == 3 ? 6 : 4, R = K3 / 2;
+  __shared__ float red[NT * 64];
+  const int tid = threadIdx.x, C = k.C, cgs = k.cgs;
+  for (int i = tid; i < NT * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int64_t gt = blockIdx.x * 256ll + tid, nthreads = (int64_t)gridDim.x * 256;
+  const int cg = (int)(gt % cgs);
+  const int64_t step = nthreads / cgs;
+  const T* tp = reinterpret_cast<const T*>(k.t) + cg * 8;
+  const T* sp = reinterpret_cast<const T*>(k.s);
+  const int X = k.X, Y = k.Y, Z = k.Z;
+  float acc[NT][8];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[t][c] = 0.f;
+  // Work item = (n, x, y quad, z), z fastest: the lanes of a wave read consecutive voxels.  A thread's items are `step` apart; its coordinates
+  // advance by the mixed-radix digits of `step` with carries (the first version decoded a 64-bit item index with six divisions per item and
+  // formed eighteen 64-bit voxel addresses: ~900 instructions around 288 FMAs, 1.1 TB/s)
+  const unsigned first = (unsigned)(gt / cgs), ustep = (unsigned)step, uitems = (unsigned)k.items;
+  const int YQ = k.yq, ZY = Z * Y;
+  int z = (int)(first % (unsigned)Z), yq = (int)((first / (unsigned)Z) % (unsigned)YQ), x = (int)((first / (unsigned)(Z * YQ)) % (unsigned)X), n = (int)(first / (unsigned)(Z * YQ * X));
+  const int sz = (int)(ustep % (unsigned)Z), syq = (int)((ustep / (unsigned)Z) % (unsigned)YQ), sx = (int)((ustep / (unsigned)(Z * YQ)) % (unsigned)X), sn = (int)(ustep / (unsigned)(Z * YQ * X));
+  const int my_items = first < uitems ? (int)((uitems - 1u - first) / ustep) + 1 : 0;
+  const int64_t trow = (int64_t)Z * k.tpitch;  // elements between y-consecutive voxels of T
+  for (int it = 0; it < my_items; ++it) {
+    const int y0 = yq * 4;
+    const int v0 = ((n * X + x) * Y + y0) * Z + z;  // voxel index (< 2^31: checked on the host)
+    const T* t0 = tp + (int64_t)v0 * k.tpitch;
+    f8 tv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tv[i] = ld8(t0 + i * trow);
+#pragma unroll
+    for (int dxi = 0; dxi < K3; ++dxi) {
+      const int xs = x + dxi - R;
+      const bool xok = (unsigned)xs < (unsigned)X;
+      // every load is unconditional, from a clamped (always valid) row, and the zero padding of the convolution is a select on the loaded
+      // value: with `ok ? load : 0` hipcc branched around each of the 18 loads and waited for each one in turn (0.70 ms per launch)
+      const T* s0 = sp + (v0 + (xok ? (dxi - R) * ZY : 0));
+      float sr[ROWS];
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) {
+        const int ys = y0 - R + j;
+        const bool yok = (unsigned)ys < (unsigned)Y;
+        const float v = wn_ld<T>(s0 + (yok ? (j - R) * Z : 0));
+        sr[j] = (xok && yok) ? v : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int dyi = 0; dyi < K3; ++dyi)
+#pragma unroll
+          for (int c = 0; c < 8; ++c) acc[dxi * K3 + dyi][c] += tv[i].v[c] * sr[i + dyi];
+    }
+    z += sz; if (z >= Z) { z -= Z; ++yq; }
+    yq += syq; if (yq >= YQ) { yq -= YQ; ++x; }
+    x += sx; if (x >= X) { x -= X; ++n; }
+    n += sn;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float v = acc[t][c];
+      for (int o = 32; o >= cgs; o >>= 1) v += __shfl_xor(v, o, 64);  // lanes with the same channel group (lane % cgs): cgs divides 64
+      if ((tid & 63) < cgs) atomicAdd(&red[t * C + cg * 8 + c], v);
+    }
+  __syncthreads();
+  float* slab = k.slab + (int64_t)blockIdx.x * (NT * C);
+  for (int i = tid; i < NT * C; i += 256) slab[i] = red[i];
+}
+
+// dw[c*stride_c + weight tap] += sum over workgroups of slab[b][t*C + c]
+__global__ void wgrad_narrow_reduce_kernel(const float* __restrict__ slab, int nblk, int C, int K3, int sign, float* __restrict__ dw, int64_t stride_c) {
+  const int NT = K3 * K3, R = K3 / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NT * C) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= nblk; b += 4) {
+    s0 += slab[(int64_t)b * NT * C + i]; s1 += slab[(int64_t)(b + 1) * NT * C + i];
+    s2 += slab[(int64_t)(b + 2) * NT * C + i]; s3 += slab[(int64_t)(b + 3) * NT * C + i];
+  }
+  for (; b < nblk; ++b) s0 += slab[(int64_t)b * NT * C + i];
+  const int t = i / C, c = i - t * C;
+  const int dx = t / K3 - R, dy = t % K3 - R;  // s-offset (dx, dy) = sign * (weight tap offset)
+  const int widx = (sign * dx + R) * K3 + (sign * dy + R);
+  dw[(int64_t)c * stride_c + widx] += (s0 + s1) + (s2 + s3);
+}
+
+extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* scratch, int64_t scratch_elems, void* stream) {
+  VSSEG_CHECK(t.ptr && s && dw && scratch && !t.ptr2, "vsseg_wgrad_narrow: bad pointers (two-part tensors are not supported)");
+  VSSEG_CHECK(k3 == 1 || k3 == 3, "vsseg_wgrad_narrow: 3x3x1 or 1x1x1 kernels only (k3 = %d)", k3);
+  VSSEG_CHECK(sign == 1 || sign == -1, "vsseg_wgrad_narrow: sign must be +1 or -1");
+  VSSEG_CHECK(t.c % 8 == 0 && t.c >= 8 && t.c <= 64 && 64 % (t.c / 8) == 0 && t.pitch % 8 == 0, "vsseg_wgrad_narrow: channel count %d must be 8, 16, 32 or 64", t.c);
+  VSSEG_CHECK(t.y % 4 == 0, "vsseg_wgrad_narrow: y extent %d must be a multiple of 4", t.y);
+  WnK k;
+  k.t = t.ptr; k.s = s; k.dw = dw;
+  k.tpitch = t.pitch; k.C = t.c; k.cgs = t.c / 8;
+  k.n = t.n; k.X = t.x; k.Y = t.y; k.Z = t.z; k.yq = t.y / 4;
+  k.sign = sign; k.stride_c = stride_c;
+  k.items = (int64_t)t.n * t.x * k.yq * t.z;
+  VSSEG_CHECK((int64_t)t.n * t.x * t.y * t.z < (1ll << 31), "vsseg_wgrad_narrow: more than 2^31 voxels");
+  // >= 16 items per thread before another workgroup is worth its flush; at most 4 workgroups per CU
+  int grid = grid_for(k.items * k.cgs / 16, 256, 256 * 4);
+  const int64_t cap = scratch_elems / (k3 * k3 * t.c);
+  VSSEG_CHECK(cap >= 1, "vsseg_wgrad_narrow: scratch too small");
+  if (grid > cap) grid = (int)cap;
+  k.slab = scratch;
+  if (t.dtype == VSSEG_F32) {
+    if (k3 == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<float, 3>), dim3(grid), dim3(256), 0, as_stream(stream), k);
+    else hipLaunchKernelGGL((wgrad_narrow_kernel<float, 1>), dim3(grid), dim3(256), 0, as_stream(stream), k);
+  } else {
+    if (k3 == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<bf16_t, 3>), dim3(grid), dim3(256), 0, as_stream(stream), k);
+    else hipLaunchKernelGGL((wgrad_narrow_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, as_stream(stream), k);
+  }
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow");
+  const int total = k3 * k3 * t.c;
+  hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64), dim3(64), 0, as_stream(stream), (const float*)scratch, grid, (int)t.c, (int)k3, (int)sign, dw, stride_c);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow(reduce)");
+  return VSSEG_OK;
+}

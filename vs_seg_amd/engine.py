@@ -539,9 +539,31 @@ class Plan:
             assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
             return gdesc(t)
 
+        def narrow_wgrad(Lr: Layer, x: TensorSpec, dy: L.Tensor, dy_compact: Optional[L.Tensor]) -> bool:
+            """One input or one output channel, 3x3x1 / 1x1x1, stride 1: the weight gradient is a bandwidth reduction over the C-channel
+            operand (vsseg_wgrad_narrow) instead of an MFMA launch on a zero-extended one (narrow-channel tails off the matrix cores)."""
+            if not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel not in ((3, 3, 1), (1, 1, 1)) or self.lv[Lr.level][1] % 4:
+                return False
+            k3 = Lr.kernel[0]
+            scr = self.eng.wgrad_scratch()  # partial-sum slabs (shared with vsseg_wgrad: the weight-gradient launches serialise on one stream)
+            if Lr.cin == 1 and Lr.cout in (8, 16, 32, 64) and x.root.name == prog.input.name and dy.c == Lr.cout and not dy.ptr2:
+                x1 = self._xdesc(x, True)  # the compact one-channel copy of the network input
+                B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
+                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
+                return True
+            if Lr.cout == 1 and Lr.cin in (8, 16, 32, 64) and dy_compact is not None and x.parts is None and x.base is None:
+                B.append([lib.vsseg_wgrad_narrow, [self._desc(x), dy_compact.ptr, k3, -1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
+                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
+                return True
+            return False
+
         def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None, gate=None):
             cp = self.cplans[Lr.prefix]
             wg = cp.wgrad
+            if narrow_wgrad(Lr, x, dy, dy_compact):
+                assert not bias_grad, "the narrow weight-gradient path does not reduce a bias gradient"
+                conv_backward_data(Lr, x, dy, relumask, dy_compact, gate)
+                return
             xin = self._desc(x)
             d = L.WgradDesc()
             if Lr.transposed:
@@ -617,6 +639,10 @@ class Plan:
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
+            conv_backward_data(Lr, x, dy, relumask, dy_compact, gate)
+
+        def conv_backward_data(Lr: Layer, x: TensorSpec, dy: L.Tensor, relumask, dy_compact, gate):
+            cp = self.cplans[Lr.prefix]
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
@@ -664,7 +690,7 @@ class Plan:
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
-                dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and self.cplans[Lr.prefix].fold_dgrad) else None
+                dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and ("dpre1:" + op.out.name) in self.bufs) else None
                 conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc, gate=gate_fuse.get(Lr.prefix))
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
@@ -682,7 +708,8 @@ class Plan:
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
-                dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if self.cplans[sig.prefix].fold_dgrad else None
+                want_c1 = self.cplans[sig.prefix].fold_dgrad or (eng.narrow_wgrad and sig.kernel in ((3, 3, 1), (1, 1, 1)) and sig.cin in (8, 16, 32, 64) and self.lv[sig.level][1] % 4 == 0)
+                dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if want_c1 else None  # compact copy of d(pre-sigmoid): z-folded data gradient / narrow weight gradient
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
                 B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
                           self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + 8 + 4)])
@@ -811,6 +838,7 @@ class Engine:
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
+        self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         self.overlap = os.environ.get("VSSEG_OVERLAP", "0") == "1" and not dry_run  # weight gradients on a second HIP stream, concurrent with the data-gradient chain
         self._side = None
