@@ -172,11 +172,6 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave's pieces of stage s are in LDS; every wave finished reading the other buffer (stage s-1)
     st_prev = 0;
-    if (s + 1 < nstages) {
-      if (ch_issue == 0) t_issue = tile_of(ti_issue);
-      issue(t_issue, ch_issue, (s + 1) & 1);
-      if (++ch_issue == nch) { ch_issue = 0; ++ti_issue; }
-    }
     if (ch_cur == 0) {
       t_cur = tile_of(ti_cur);
 #pragma unroll
@@ -186,7 +181,9 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
     }
     const bool last = ch_cur + 1 == nch;
     const int64_t ovox = (((int64_t)t_cur.n * X + t_cur.x0) * Y + t_cur.y0) * Z + t_cur.z0;
-    // auxiliary operands of the epilogue: ordinary loads issued in front of the tile's last K loop
+    // auxiliary operands of the epilogue: ordinary loads issued in front of the tile's last K loop — and in front of the next stage's DMAs:
+    // hipcc guards the reuse of their registers with a counted wait that knows nothing of the inline-assembly DMAs, so behind them it
+    // waited for the first DMA of the stage to land before it even issued these loads
     uint2 auxv[AUXM ? MT : 1][AUXM ? NT : 1];
     float gatev[AUXM ? MT : 1];
     if constexpr (AUXM) {
@@ -202,6 +199,11 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
           }
         }
       }
+    }
+    if (s + 1 < nstages) {
+      if (ch_issue == 0) t_issue = tile_of(ti_issue);
+      issue(t_issue, ch_issue, (s + 1) & 1);
+      if (++ch_issue == nch) { ch_issue = 0; ++ti_issue; }
     }
     {
       // K loop: the fragments of step ks+1 are read before the MFMAs of step ks are issued (two register sets), so that a wave's LDS latency
@@ -222,10 +224,12 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const bf16x8*>(Hk + m * (CC_HZ * CC_VB));
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads of step ks+1 in front of the MFMAs of step ks (+2-6 % over hipcc's own interleaving)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ac[m], acc[m][t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < CC_KS) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) wc[t] = wn[t];

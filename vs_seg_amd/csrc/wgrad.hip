@@ -467,6 +467,12 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   k.lds_p = off; off += k.nbuf * k.tvox * k.p_row;                     // double-buffered: tile s+1 streams in by LDS-DMA while tile s is multiplied
   k.lds_h = off; off += k.nbuf * hvox * hg * 16 * es;
   k.npp = (k.tvox * (k.p_row >> 4) + 255) / 256;
+  {  // every tile whole and every P piece made of real channels: the boundary path of the P tile is never taken, its coordinate table (1 KiB per
+     // piece row: 6 KiB on the 48-channel 3x3x3 layers) is not allocated — there that is the difference between two and three resident workgroups
+    bool p_whole = d->ntp * 16 <= d->p.c;
+    for (int a = 0; a < 3; ++a) p_whole = p_whole && d->q[a] % d->tile[a] == 0;
+    if (p_whole) k.npp = 0;
+  }
   k.nph = (hvox * hg * es + 255) / 256;
   k.lds_tab = off; off += (k.npp + k.nph) * 1024;
   VSSEG_CHECK(k.tvox * k.p_row <= WPP * 256 * 16 && hvox * hg * 16 * es <= WPH * 256 * 16, "vsseg_wgrad: tile too large for the DMA piece budget");
