@@ -549,11 +549,11 @@ class Plan:
             if Lr.cin == 1 and Lr.cout in (8, 16, 32, 64) and x.root.name == prog.input.name and dy.c == Lr.cout and not dy.ptr2:
                 x1 = self._xdesc(x, True)  # the compact one-channel copy of the network input
                 B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
-                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
+                          dict(name="wgrad_narrow", kind="hbm", side=Lr.level >= eng.overlap_min_level, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
                 return True
             if Lr.cout == 1 and Lr.cin in (8, 16, 32, 64) and dy_compact is not None and x.parts is None and x.base is None:
                 B.append([lib.vsseg_wgrad_narrow, [self._desc(x), dy_compact.ptr, k3, -1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
-                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
+                          dict(name="wgrad_narrow", kind="hbm", side=Lr.level >= eng.overlap_min_level, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
                 return True
             return False
 
@@ -635,7 +635,7 @@ class Plan:
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=Lr.level >= eng.overlap_min_level, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -758,7 +758,7 @@ class Plan:
     def run(self, lst, stream, graph_key: Optional[str] = None):
         if self.timer is not None:
             return self._run_timed(lst, stream)
-        if graph_key is not None and self.eng.use_graphs:
+        if graph_key is not None and self.eng.use_graphs and not (self.eng.overlap and any(len(r) > 2 and r[2].get("side") for r in lst)):
             g = self._graphs.get(graph_key)
             if g is not None:
                 g.replay()
@@ -802,20 +802,33 @@ class Plan:
             torch.cuda.current_stream().wait_stream(side)
 
     def _run_timed(self, lst, stream):
-        """Per-launch HIP-event timing (events are recorded on the stream the kernels are launched on)."""
+        """Per-launch HIP-event timing (events are recorded on the stream the kernels are launched on).  With Engine.overlap the side
+        launches go to the second stream exactly as in _run_eager — unless EVERY launch is timed (tm['only'] is None: the per-kernel profile
+        wants each kernel alone on the GPU, not sharing it with a concurrent weight gradient)."""
         tm = self.timer
+        overlap = self.eng.overlap and tm["only"] is not None
+        side = None
         for rec in lst:
             name = rec[2]["name"] if len(rec) > 2 else getattr(rec[0], "__name__", "memset")
+            on_side = overlap and len(rec) > 2 and rec[2].get("side")
+            if on_side:
+                if side is None:
+                    side = self.eng.side_stream()
+                side.wait_stream(torch.cuda.current_stream())
+            s_obj = side if on_side else None
+            s_raw = side.cuda_stream if on_side else stream
             if tm["only"] is not None and name not in tm["only"]:
-                rc = rec[0](*rec[1], stream)
+                rc = rec[0](*rec[1], s_raw)
             else:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                rc = rec[0](*rec[1], stream)
-                e1.record()
+                e0.record(s_obj) if s_obj is not None else e0.record()
+                rc = rec[0](*rec[1], s_raw)
+                e1.record(s_obj) if s_obj is not None else e1.record()
                 tm["events"].append((name, rec[2] if len(rec) > 2 else None, e0, e1))
             if rc:
                 L.check(rc, name)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def memory_bytes(self) -> int:
         tot = sum(t.numel() * t.element_size() for t in self.bufs.values()) + sum(t.numel() * t.element_size() for t in self.grads.values())
@@ -840,7 +853,11 @@ class Engine:
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
-        self.overlap = os.environ.get("VSSEG_OVERLAP", "0") == "1" and not dry_run  # weight gradients on a second HIP stream, concurrent with the data-gradient chain
+        # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
+        # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched
+        # eagerly: replayed as ONE hipGraph the two branches ran no faster than serially (measured 37.6 ms)
+        self.overlap = os.environ.get("VSSEG_OVERLAP", "1") == "1" and not dry_run
+        self.overlap_min_level = int(os.environ.get("VSSEG_OVERLAP_MIN_LEVEL", "0"))  # finest level whose weight gradients go to the side stream (measured: 0 = all of them is best, 37.0 / 37.1 / 37.6 / 37.9 ms for 0 / 1 / 2 / 3)
         self._side = None
         self.use_graphs = os.environ.get("VSSEG_GRAPHS", "1") != "0" and not dry_run  # replay the launch lists as hipGraphs after two eager runs
         self.attention, self.hp = attention, hp
