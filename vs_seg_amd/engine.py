@@ -354,8 +354,34 @@ class Plan:
         assert t.c == t.pitch and not t.ptr2 and t.z % fold == 0, "z-folding needs a dense, single-part tensor"
         return L.Tensor(t.ptr, t.dtype, t.c * fold, t.pitch * fold, t.n, t.x, t.y, t.z // fold)
 
+    @staticmethod
+    def _sample(t: Optional[L.Tensor], b: int) -> Optional[L.Tensor]:
+        """Sample b of a batched channels-last tensor (both parts of a two-part tensor), as a batch-1 descriptor."""
+        if t is None:
+            return None
+        step = t.x * t.y * t.z * t.pitch * (2 if t.dtype == L.BF16 else 4)
+        r = L.Tensor(t.ptr + b * step, t.dtype, t.c, t.pitch, 1, t.x, t.y, t.z)
+        if t.ptr2:
+            r.ptr2, r.csplit = t.ptr2 + b * step, t.csplit
+        return r
+
+    def _igemm_classes(self, lst, chs: List[_Choice], inp: L.Tensor, out: L.Tensor, *, res: Optional[L.Tensor] = None, **kw):
+        """All lattice classes of one convolution (the output-parity classes of a transposed convolution / of a strided data gradient: each
+        is its own launch and reads the WHOLE input: 2-3x the algorithmic bytes, profiles/r02_pmc_hbm.txt).  VSSEG_CLASS_INTERLEAVE=1 launches
+        them sample by sample, classes innermost, so that one sample of the input (25-100 MB) could be re-read out of the 256 MB memory-side
+        cache — measured SLOWER (36.4 -> 38.9 ms per step: four times the launches, each with its own weight staging and tail) and left off;
+        the fix is one launch for all classes."""
+        if len(chs) > 1 and self.n > 1 and self.eng.class_interleave and kw.get("gate", 0) == 0:
+            for b in range(self.n):
+                for ch in chs:
+                    self._igemm(lst, ch, self._sample(inp, b), self._sample(out, b), res=self._sample(res, b), nb=1, **kw)
+        else:
+            for ch in chs:
+                self._igemm(lst, ch, inp, out, res=res, **kw)
+
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None):
+        nb = self.n if nb is None else nb
         d = L.IgemmDesc()
         d.gate = gate or None
         if ch.fold:
@@ -367,12 +393,15 @@ class Plan:
         if res is not None:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
-        pl = self._choose(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
-        self._register(ch, pl)
+        if ch.chosen is not None:  # a further launch of the same lattice class (another sample): same plan, same packed weights
+            pl = ch.chosen
+        else:
+            pl = self._choose(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
+            self._register(ch, pl)
         self._fill_desc(d, pl)
         self._wpack_fixups.append((d, ch.map_off))
         self.keep.append(d)
-        nvalid = self.n  # output voxels this lattice class writes
+        nvalid = nb  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
@@ -381,7 +410,7 @@ class Plan:
         meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth == -2 else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
-                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(self.n) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
+                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
     def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:
@@ -461,8 +490,7 @@ class Plan:
                         F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), vptr(2, pre), vptr(3, pre), alp, out, None, 0]])
                 elif self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                    for ch in cp.fwd:
-                        self._igemm(F, ch, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
+                    self._igemm_classes(F, cp.fwd, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     if fused_res is not None:
@@ -474,9 +502,8 @@ class Plan:
                                   self._ew_meta("bn_act_fwd", Lr.out_level, (3 if res is not None else 2) * Lr.cout)])
                 else:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
-                    for ch in cp.fwd:
-                        self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
-                                    res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
+                    self._igemm_classes(F, cp.fwd, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
+                                        res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
                 if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
@@ -649,6 +676,9 @@ class Plan:
                 if gate is not None:  # d(x) = conv^T(dy) + d(gated) * (1 + att): the attention gate's backward rides in this launch's epilogue
                     assert acc == 0 and relumask is None and len(cp.dgrad) == 1
                     self._igemm(B, cp.dgrad[0], dy, gx, res=gate[0], res_mode=L.RES_GATE, gate=gate[1])
+                    return
+                if len(cp.dgrad) > 1 and not any(ch.fold for ch in cp.dgrad):
+                    self._igemm_classes(B, cp.dgrad, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
                     return
                 for ch in cp.dgrad:
                     self._igemm(B, ch, dy_compact if ch.fold else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
@@ -850,6 +880,7 @@ class Engine:
         # zero-extended MFMA launch on the full-resolution 1->16 3x3x1 layer (the stencil is issue-bound at ~16 % VALU utilisation).
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
+        self.class_interleave = os.environ.get("VSSEG_CLASS_INTERLEAVE", "0") == "1" and not dry_run  # experiment, off: multi-class convolutions launched sample by sample (measured 36.4 -> 38.9 ms per step)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
