@@ -57,6 +57,22 @@ typedef struct {
   int32_t reserved;
 } vsseg_tensor;
 
+/* Optional fused first pass of the BatchNorm -> Dropout -> PReLU backward (vsseg_bn_act_bwd_reduce) in the epilogue of the launch that
+ * PRODUCES that layer's output gradient dA (a data gradient of the streaming / compute kernels, plans with depth -2 / -3): the launch has
+ * the dA tile in registers, reads the layer's pre-activation y and its stored keep-mask for the same voxels and adds
+ * sum(dz), sum(dz*xhat) and the PReLU-slope term to the layer's sharded sums — the separate reduce pass (two full tensor reads) is not
+ * launched.  The whole output tensor of the launch must be that layer's dA (same channel count, one part). */
+typedef struct {
+  const void* y;           /* [N][X][Y][Z][y_pitch] pre-activation of the layer, in the launch's output dtype (bf16) */
+  int32_t y_pitch;
+  const uint8_t* keep;     /* keep-mask bytes stored by vsseg_bn_act_fwd; required when p_drop > 0 */
+  const float *scale, *shift, *mean, *invstd, *alpha; /* the layer's folded affine, statistics and PReLU slope */
+  float p_drop;
+  double* sums;            /* as vsseg_bn_act_bwd_reduce: [VSSEG_STAT_SHARDS][3][stride] */
+  int32_t stride;
+  double* alpha_acc;       /* [VSSEG_STAT_SHARDS] */
+} vsseg_bnred;
+
 /* One implicit-GEMM launch over an output lattice q in [0,q): out[q*os+oo][n] = epi( sum_t sum_c in[q*is+off_t][c] * W[t][c][n] ).
  * Covers Conv3d forward, every parity class of ConvTranspose3d forward, and both data-gradients
  * (ref:params/networks/blocks/convolutions.py:114-146 and their autograd at ref:params/VSparams.py:461). */
@@ -92,6 +108,7 @@ typedef struct {
    * real channel c % cout_mod for bias / bias2 / scale / shift / stats.  0: off. */
   int32_t cout_mod;
   const float* gate;       /* VSSEG_RES_GATE: fp32 attention map [N][X][Y][Z] of the output tensor, or NULL */
+  const vsseg_bnred* bnred; /* fused BatchNorm-backward reduction over the output (depth -2 / -3 plans only), or NULL */
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).

@@ -35,6 +35,11 @@ class CropJob(C.Structure):  # vsseg_crop_job
     _fields_ = [("src", C.c_void_p), ("sdims", C.c_int32 * 3), ("origin", C.c_int32 * 3), ("flip_x", C.c_int32)]
 
 
+class BnRed(C.Structure):  # vsseg_bnred
+    _fields_ = [("y", C.c_void_p), ("y_pitch", C.c_int32), ("keep", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("alpha", C.c_void_p), ("p_drop", C.c_float), ("sums", C.c_void_p), ("stride", C.c_int32), ("alpha_acc", C.c_void_p)]
+
+
 class IgemmDesc(C.Structure):
     _fields_ = [
         ("inp", Tensor),
@@ -67,6 +72,7 @@ class IgemmDesc(C.Structure):
         ("stats_stride", C.c_int32),
         ("cout_mod", C.c_int32),
         ("gate", C.c_void_p),
+        ("bnred", C.POINTER(BnRed)),
     ]
 
 

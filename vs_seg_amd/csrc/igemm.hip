@@ -93,6 +93,7 @@ static const void* zero_page() {
 static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d && d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
   VSSEG_CHECK(d->in.dtype == VSSEG_F32 || d->in.dtype == VSSEG_BF16, "vsseg_igemm: bad input dtype");
+  VSSEG_CHECK(!d->bnred, "vsseg_igemm: the fused BatchNorm-backward reduction (bnred) needs a streaming / compute kernel plan (depth -2 / -3)");
   VSSEG_CHECK(d->ntaps >= 1 && d->ntaps <= VSSEG_MAX_TAPS, "vsseg_igemm: ntaps %d out of range", d->ntaps);
   VSSEG_CHECK(d->ck >= 8 && d->ck % 8 == 0 && d->nchunks >= 1, "vsseg_igemm: bad channel chunking ck=%d nchunks=%d", d->ck, d->nchunks);
   VSSEG_CHECK(d->in.c % 8 == 0 && d->in.pitch % 8 == 0, "vsseg_igemm: input channels/pitch must be multiples of 8 (c=%d pitch=%d)", d->in.c, d->in.pitch);

@@ -306,7 +306,7 @@ class Plan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
-               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}")
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|bnr" if bool(d.bnred) else ""))
         cache = _tune_cache()
         hit = cache.get(key)
         if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
@@ -334,7 +334,7 @@ class Plan:
                 times.append(float("inf"))
                 continue
             best = float("inf")
-            for _ in range(3):
+            for _ in range(self.eng.tune_reps):  # best of N single launches (N = 5: with 3 the choice between near-equal plans flipped from run to run by up to 0.5 ms per step)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 lib.vsseg_igemm(C.byref(d), stream)
@@ -380,9 +380,12 @@ class Plan:
                 self._igemm(lst, ch, inp, out, res=res, **kw)
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, bnred: Optional[L.BnRed] = None):
         nb = self.n if nb is None else nb
         d = L.IgemmDesc()
+        if bnred is not None:  # fused first pass of the BatchNorm backward of the layer whose output gradient this launch produces
+            self.keep.append(bnred)
+            d.bnred = C.pointer(bnred)
         d.gate = gate or None
         if ch.fold:
             inp, out, res = self._fold_desc(inp, ch.fold), self._fold_desc(out, ch.fold), (self._fold_desc(res, ch.fold) if res is not None else None)
@@ -405,6 +408,8 @@ class Plan:
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
+        if bnred is not None:
+            accumulate = 1  # metadata only: the launch reads one more output-sized tensor (the layer's pre-activation)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
         meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth == -2 else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
@@ -464,6 +469,31 @@ class Plan:
                     pr = plain_by_out[op.res.name]
                     if pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None:
                         res1_fused[pr.layer.prefix] = pr
+
+        # BatchNorm layers whose output has exactly ONE consumer, a stride-1 convolution: that convolution's data gradient is the only
+        # producer of the layer's output gradient dA and can run the first pass of the layer's backward (sum(dz), sum(dz*xhat), PReLU-slope
+        # term) in its epilogue — vsseg_bnred, streaming / compute kernel plans only.  Intra-unit links
+        # unit0 -> unit1 of the encoder ResidualUnits.
+        uses: Dict[str, list] = {}
+        for op in ops:
+            if isinstance(op, (ConvBnAct, ConvPlain)):
+                for t in (op.x.parts or (op.x,)):
+                    uses.setdefault(t.root.name, []).append(("x" if op.x.parts is None else "part", op))
+                if op.res is not None:
+                    uses.setdefault(op.res.root.name, []).append(("res", op))
+            elif isinstance(op, AttGate):
+                for t in (op.x.parts or (op.x,)):
+                    uses.setdefault(t.root.name, []).append(("gate", op))
+                uses.setdefault(op.att.root.name, []).append(("att", op))
+        self.bnred_of: Dict[str, ConvBnAct] = {}  # consumer convolution prefix -> the BatchNorm layer in front of it
+        self.bnred_done: set = set()
+        if self.train and eng.bnred and eng.es == 2 and self.tune and (p_drop == 0.0 or eng.keepmask):
+            for opb in ops:
+                if not isinstance(opb, ConvBnAct) or opb.out.base is not None:
+                    continue
+                u = uses.get(opb.out.root.name, [])
+                if len(u) == 1 and u[0][0] == "x" and not u[0][1].layer.transposed and tuple(u[0][1].layer.stride) == (1, 1, 1) and u[0][1].x is opb.out:
+                    self.bnred_of[u[0][1].layer.prefix] = opb
 
         # ---- forward
         F = self.fwd
@@ -647,7 +677,7 @@ class Plan:
                                 d.single_buffer, d.hgroup = sb, hg
                                 set_blocks(w)
                                 best = float("inf") if not lib.vsseg_wgrad(C.byref(d), stream) else None
-                                for _ in range(3 if best is not None else 0):
+                                for _ in range(self.eng.tune_reps if best is not None else 0):
                                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                                     e0.record()
                                     lib.vsseg_wgrad(C.byref(d), stream)
@@ -670,6 +700,19 @@ class Plan:
 
         def conv_backward_data(Lr: Layer, x: TensorSpec, dy: L.Tensor, relumask, dy_compact, gate):
             cp = self.cplans[Lr.prefix]
+            opb = self.bnred_of.get(Lr.prefix)
+            if opb is not None and len(cp.dgrad) == 1 and gate is None and relumask is None and not cp.dgrad[0].fold:
+                ch0 = cp.dgrad[0]
+                spec = [c for c in ch0.cands if c.depth == -3 or (c.depth == -2 and c.nt <= 2 and c.ntaps == 9 and c.kc in (16, 32))]
+                if spec:
+                    lb, pb = opb.layer, opb.layer.prefix
+                    acc = contribution(x)
+                    assert acc == 0, "a fused BatchNorm reduction needs the only contribution to the gradient"
+                    br = L.BnRed(self.bufs["y:" + pb].data_ptr(), lb.cout, keep_ptr(lb), vptr(2, pb), vptr(3, pb), vptr(0, pb), vptr(1, pb), self._pp(pb + ".act.weight"), p_drop, sptr(1, pb), cpad[pb], aptr(pb))
+                    fused = _Choice(spec, ch0.woff, ch0.wshape2, ch0.woff2, wshape=ch0.wshape)
+                    self._igemm(B, fused, dy, gdesc(x), bnred=br)
+                    self.bnred_done.add(pb)
+                    return
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
@@ -693,7 +736,8 @@ class Plan:
                 yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
-                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre), keep_ptr(Lr)],
+                if pre not in self.bnred_done:  # else: reduced in the epilogue of the launch that produced dA
+                  B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre), keep_ptr(Lr)],
                           self._ew_meta("bn_act_bwd_reduce", Lr.out_level, 2 * Lr.cout)])
                 dres_bias = None
                 if op.res is not None and op.res.name in producer:  # residual conv: d(out)/d(res) = 1, its bias gradient is sum(dA) (reduced above)
@@ -881,6 +925,11 @@ class Engine:
         self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.class_interleave = os.environ.get("VSSEG_CLASS_INTERLEAVE", "0") == "1" and not dry_run  # experiment, off: multi-class convolutions launched sample by sample (measured 36.4 -> 38.9 ms per step)
+        self.tune_reps = int(os.environ.get("VSSEG_TUNE_REPS", "5"))  # timed launches per candidate plan (best of)
+        # first pass of the BatchNorm backward fused into the producer of its output gradient (vsseg_bnred).  Correct (tests) but measured SLOWER than
+        # the separate pass, 36.4-36.6 -> 36.8 ms per step: the reduce kernel streams its two tensors at 5.2 TB/s, the convolution that takes over
+        # one of those reads runs at 3.5-4.5 TB/s and pays the dz arithmetic in its epilogue.  Off by default
+        self.bnred = os.environ.get("VSSEG_BNRED", "0") == "1"
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient

@@ -172,7 +172,7 @@ def stream_lds_bytes(kc, nt, ntaps):
     r = 1 if ntaps == 9 else 0
     tile = stream_tile(kc, ntaps)
     pieces = (tile[0] + 2 * r) * (tile[1] + 2 * r) * tile[2] * g
-    return ((ntaps * g + 3) // 4) * nt * 1024 + ((pieces + 255) // 256) * 4096 + 3 * nt * 16 * 4
+    return ((ntaps * g + 3) // 4) * nt * 1024 + ((pieces + 255) // 256) * 4096 + 5 * nt * 16 * 4 + 16
 
 
 def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPlan"]:
@@ -197,7 +197,7 @@ def compute_split(nreal):
 
 
 def compute_lds_bytes(nt):
-    return 2 * (34 * 1024 + 14 * nt * 1024) + 3 * nt * 16 * 4
+    return 2 * (34 * 1024 + 14 * nt * 1024) + 5 * nt * 16 * 4 + 16
 
 
 def compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split=0) -> Optional["IgemmPlan"]:
