@@ -573,6 +573,61 @@ def test_fused_bn_backward_reduction_equals_separate_pass(k, c, dims, p_drop):
     assert lib.vsseg_igemm(C.byref(dg), H.stream()) == L.EINVAL
 
 
+@pytest.mark.parametrize("kind,cin,cout,dims,mode", [("convT_fwd", 32, 16, (8, 16, 8), "stats"), ("convT_fwd", 32, 16, (16, 8, 4), "plain"), ("conv_dgrad", 16, 16, (8, 16, 8), "accumulate"),
+                                                     ("conv_dgrad", 16, 16, (16, 16, 4), "plain")])
+def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mode):
+    """depth -4: the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient as ONE launch of the
+    streaming kernel (coarse lattice, 2x2x1 neighbourhood, 4 x 16 output channels, pixel-shuffle store).  Must equal the four per-class
+    launches of the general kernel (up to the fp32 summation order of the taps) and torch's fp64 result, with BatchNorm statistics /
+    gradient accumulation in the epilogue."""
+    lib = L.lib()
+    dt, k, st = "bf16", (3, 3, 1), (2, 2, 1)
+    torch.manual_seed(21)
+    n = 2
+    fine = (2 * dims[0], 2 * dims[1], dims[2])
+    if kind == "convT_fwd":  # x at the coarse level (cin channels) -> y at the fine level (cout channels)
+        x = _round(torch.randn(n, cin, *dims), dt)
+        w = _round(torch.randn(cin, cout, *k) / (cin * 9) ** 0.5, dt)
+        want = F.conv_transpose3d(x.double(), w.double(), stride=st, padding=P.same_pad(k), output_padding=(1, 1, 0))
+        inp_cl, nout = H.to_cl(x, H.DT[dt]), cout
+    else:  # dY at the coarse level (cout channels) -> dX at the fine level (cin channels)
+        w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, dt)
+        xd = torch.zeros(n, cin, *fine, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xd, w.double(), stride=st, padding=P.same_pad(k))
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        want, inp_cl, nout = xd.grad, H.to_cl(gy, H.DT[dt]), cin
+    assert tuple(want.shape[2:]) == fine
+    prev = H.to_cl(_round(torch.randn(n, nout, *fine), dt), H.DT[dt])
+    kw = {}
+    if mode == "accumulate":
+        kw = dict(accumulate=1)
+        want = want + H.from_cl(prev).double()
+
+    def stats_buf():
+        return torch.zeros(L.STAT_SHARDS * 2 * 16, dtype=torch.float64, device="cuda")
+
+    # reference: one launch of the general kernel per parity class
+    out_a = prev.clone() if mode == "accumulate" else torch.zeros(n, *fine, nout, dtype=H.DT[dt], device="cuda")
+    sa = stats_buf()
+    H.run_lattice_op(kind, w, inp_cl, out_a, st, **(dict(stats=sa.data_ptr(), stats_stride=16) if mode == "stats" else kw))
+    # fused
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    pl = P.shuffle_plan(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal)
+    assert pl is not None and pl.depth == -4
+    out_b = prev.clone() if mode == "accumulate" else torch.zeros_like(out_a)
+    sb = stats_buf()
+    d = H.igemm_desc(pl, H.pack(pl, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_b), cout_mod=16, **(dict(stats=sb.data_ptr(), stats_stride=16) if mode == "stats" else kw))
+    L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "fused classes")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(H.from_cl(out_b).numpy(), want.float().numpy(), atol=_tol(dt, want))
+    assert float((out_a.float() - out_b.float()).abs().max()) <= 2 * _tol(dt, want)  # same products, different fp32 summation order of the taps
+    if mode == "stats":
+        a, bb = sa.view(L.STAT_SHARDS, 2, -1).sum(0), sb.view(L.STAT_SHARDS, 2, -1).sum(0)
+        np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2)
+
+
 def test_compute_kernel_rejects_what_it_does_not_cover():
     """depth -3 outside the compute kernel's domain is an error (no silent fallback to the general kernel)."""
     lib = L.lib()

@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/it
-timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "fused_bn or streaming_kernel_equals or compute_kernel_equals" -p no:cacheprovider 2>&1 | tail -4
-timeout 900 python -m pytest tests/test_gpu_benchmark_parity.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
-for cfg in "VSSEG_BNRED=0" "VSSEG_BNRED=1" "VSSEG_BNRED=0" "VSSEG_BNRED=1"; do echo $cfg; env $cfg timeout 300 python tools/time_step.py 30 2>&1 | tail -1; done
+VSSEG_PROFILE_ROWS=300 timeout 900 python bench.py --steps 5 --warmup 3 --no-cpu-baseline --swi-volumes 0 --no-parity --profile > gpurun_out/it/b.json 2> gpurun_out/it/b.err
+grep "D=-4\|convT_fwd\|conv_dgrad q=(192, 64, 128) K=16x[1-4] \|conv_dgrad q=(96, 32, 128) K=32x[1-4] " gpurun_out/it/b.err | cut -c1-210

@@ -170,14 +170,14 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
 }
 
 extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
-  if (d && d->depth == -2) return vsseg_sconv_lds_bytes(d);
+  if (d && (d->depth == -2 || d->depth == -4)) return vsseg_sconv_lds_bytes(d);
   if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
 
 extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
-  if (d && d->depth == -2) {  // streaming kernel (sconv.hip): fails loudly when the launch is outside its domain, never falls back
+  if (d && (d->depth == -2 || d->depth == -4)) {  // streaming kernel (sconv.hip; -4: fused output-parity classes): fails loudly when the launch is outside its domain, never falls back
     VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");

@@ -70,9 +70,13 @@ template <int CIN, int NT, int TAPS, int MODE>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const SconvK k) {
   constexpr bool STATS = MODE == 1, AUXM = MODE == 2, BNR = MODE == 3;
   constexpr int G = CIN / 8, CINB = CIN * 2;
-  constexpr int R = TAPS == 9 ? 1 : 0;
+  // TAPS 9: 3x3x1 stencil (halo 1 on both sides); 1: 1x1x1; 4: the 2x2x1 neighbourhood (+0 / +1) of the FUSED output-parity classes of a
+  // stride-2 transposed convolution / stride-2 data gradient ("pixel shuffle", PS): the launch runs on the coarse lattice, output channel tile
+  // t is parity class (px, py) = (t >> 1, t & 1) and is stored at fine voxel (2x + px, 2y + py, z) — ONE read of the input instead of one per class
+  constexpr int R = TAPS == 9 ? 1 : 0, RH = (TAPS == 9 || TAPS == 4) ? 1 : 0;
+  constexpr bool PS = TAPS == 4;
   constexpr int MT = sc_mt(CIN, TAPS), SC_TX = 2 * MT;
-  constexpr int HX = SC_TX + 2 * R, HY = SC_TY + 2 * R, HZ = SC_TZ;
+  constexpr int HX = SC_TX + R + RH, HY = SC_TY + R + RH, HZ = SC_TZ;
   constexpr int PIECES = HX * HY * HZ * G, NINST = (PIECES + 255) / 256;
   constexpr int KSTEPS = (TAPS * G + 3) / 4;
   constexpr int W_BYTES = KSTEPS * NT * 1024, H_BYTES = NINST * 4096;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     const int p = ks * 4 + g, tap = p / G, cg = p % G;
-    const int dx = TAPS == 9 ? tap / 3 : 0, dy = TAPS == 9 ? tap % 3 : 0;
+    const int dx = TAPS == 9 ? tap / 3 : (TAPS == 4 ? tap >> 1 : 0), dy = TAPS == 9 ? tap % 3 : (TAPS == 4 ? tap & 1 : 0);
     koff[ks] = tap < TAPS ? ((dx * HY + dy) * HZ) * CINB + ((cg ^ sc_swz<G>(vy0 + dy, vz)) * 16) : 0;  // padded K-groups: zero weights times valid data
   }
   const int vb0 = (((wave * (MT / 2)) * HY + vy0) * HZ + vz) * CINB;  // M-tile m: + (m & 1) * 4 rows of y, + (m >> 1) rows of x (immediates; neither changes the swizzle)
@@ -149,7 +153,18 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     const int64_t ovox = (((int64_t)n * X + x0) * Y + y0) * Z + z0;
     const char* org0 = k.in0 + ivox * k.in_vox_bytes;
     const char* org1 = k.in1 + ivox * k.in_vox_bytes;
-    const bool interior = R == 0 || (x0 > 0 && y0 > 0 && x0 + SC_TX < X && y0 + SC_TY < Y);
+    // output voxel of (M-tile m, channel tile t) and the channel of this lane's 4 values inside the OUTPUT tensor
+    auto out_vox = [&](int m, int t) -> int64_t {
+      if constexpr (PS) {
+        const int OY = 2 * Y;
+        const int64_t base = (((int64_t)n * (2 * X) + 2 * x0) * OY + 2 * y0) * Z + z0;
+        return base + (int64_t)((2 * (wave * (MT / 2) + (m >> 1)) + (t >> 1)) * OY + 2 * (vy0 + (m & 1) * 4) + (t & 1)) * Z + vz;
+      } else {
+        return ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
+      }
+    };
+    auto out_ch = [&](int t) -> int { return PS ? g * 4 : t * 16 + g * 4; };
+    const bool interior = (R == 0 || (x0 > 0 && y0 > 0)) && (RH == 0 || (x0 + SC_TX < X && y0 + SC_TY < Y));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave has read the previous tile's halo
     if (interior) {
@@ -174,12 +189,11 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     if constexpr (AUXM) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int64_t vox = ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
-        if (k.aux_mode == 4) gatev[m] = k.gate[vox];
+        if (!PS && k.aux_mode == 4) gatev[m] = k.gate[out_vox(m, 0)];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int c = t * 16 + g * 4;
-          const char* ap = (t * 16 >= k.aux_csplit ? k.aux1 : k.aux0) + vox * k.aux_vox_bytes + c * 2;
+          const char* ap = (t * 16 >= k.aux_csplit ? k.aux1 : k.aux0) + out_vox(m, t) * k.aux_vox_bytes + out_ch(t) * 2;
           if (c < cout) auxv[m][t] = *reinterpret_cast<const uint2*>(ap);
         }
       }
@@ -228,9 +242,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
       constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int64_t vox = ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
         float gt = 1.f;
-        if constexpr (AUXM) gt = k.aux_mode == 4 ? 1.f + gatev[m] : 1.f;
+        if constexpr (AUXM) gt = (!PS && k.aux_mode == 4) ? 1.f + gatev[m] : 1.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int c = t * 16 + g * 4;
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
               ssum[t][r] += dz; ssq[t][r] += dz * yv[r];
             }
           }
-          char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + vox * k.out_vox_bytes + c * (int)out_es;
+          char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + out_vox(m, t) * k.out_vox_bytes + out_ch(t) * (int)out_es;
           if constexpr (KIND != 2) {
             st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
           } else if (vec_store) {
@@ -368,8 +381,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 template <int CIN, int NT, int TAPS> static int sc_lds() {
-  constexpr int G = CIN / 8, R = TAPS == 9 ? 1 : 0;
-  constexpr int PIECES = (2 * sc_mt(CIN, TAPS) + 2 * R) * (SC_TY + 2 * R) * SC_TZ * G, NINST = (PIECES + 255) / 256, KSTEPS = (TAPS * G + 3) / 4;
+  constexpr int G = CIN / 8, R = (TAPS == 9 ? 2 : (TAPS == 4 ? 1 : 0));  // halo voxels added per axis
+  constexpr int PIECES = (2 * sc_mt(CIN, TAPS) + R) * (SC_TY + R) * SC_TZ * G, NINST = (PIECES + 255) / 256, KSTEPS = (TAPS * G + 3) / 4;
   return KSTEPS * NT * 1024 + NINST * 4096 + 5 * NT * 16 * 4 + 16;
 }
 template <int CIN, int NT, int TAPS, int MODE> static int sc_launch_mode(const SconvK& k, hipStream_t s) {
@@ -406,7 +419,8 @@ typedef int (*sc_fn_t)(const SconvK&, hipStream_t);
 struct ScEntry { int cin, nt, taps; sc_fn_t fn; int (*lds)(); };
 #define SC_E(C, N, T) {C, N, T, sc_launch<C, N, T>, sc_lds<C, N, T>}
 static const ScEntry sc_table[] = {SC_E(8, 1, 9),  SC_E(8, 2, 9),  SC_E(16, 1, 9), SC_E(16, 2, 9), SC_E(16, 4, 9), SC_E(32, 1, 9), SC_E(32, 2, 9), SC_E(32, 4, 9),
-                                   SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1), SC_E(64, 2, 9)};
+                                   SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1), SC_E(64, 2, 9),
+                                   SC_E(16, 4, 4), SC_E(32, 4, 4)};  // taps 4: the fused output-parity classes (pixel shuffle), 16 channels per class
 
 static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
@@ -415,11 +429,22 @@ static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   const int mt = sc_mt(d->ck, d->ntaps), SC_TX = 2 * mt;
   if (d->nchunks != 1 || d->nsplit != 1 || d->mtw != mt) return no("needs nchunks = nsplit = 1 and mtw = 4 (2 for 64 input channels x 9 taps)");
   if (d->tile[0] != SC_TX || d->tile[1] != SC_TY || d->tile[2] != SC_TZ) return no("tile must be 8x8x4 (4x8x4 for 64 input channels x 9 taps)");
-  for (int a = 0; a < 3; ++a)
-    if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
-  if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || d->q[0] != d->out.x || d->q[1] != d->out.y || d->q[2] != d->out.z) return no("lattice, input and output extents differ");
+  const bool ps = d->depth == -4;  // fused output-parity classes: coarse lattice in, fine tensor (2x, 2y, z) out, 4 taps (+0 / +1 in x and y)
+  if (ps) {
+    if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->os[0] != 2 || d->os[1] != 2 || d->os[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = 0");
+    if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || 2 * d->q[0] != d->out.x || 2 * d->q[1] != d->out.y || d->q[2] != d->out.z) return no("pixel-shuffle output must be (2x, 2y, z) of the lattice");
+    if (d->ntaps != 4 || d->nt != 4 || d->out.c != 16 || d->cout_mod != 16 || d->out.ptr2 || d->out.dtype != VSSEG_BF16) return no("pixel-shuffle launches need 4 taps, 4 classes of 16 bf16 output channels (cout_mod 16), a one-part output");
+    for (int t = 0; t < 4; ++t)
+      if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
+    if (d->res_mode != VSSEG_RES_NONE || d->bnred) return no("pixel-shuffle launches support statistics or accumulate only");
+  } else {
+    for (int a = 0; a < 3; ++a)
+      if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
+    if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || d->q[0] != d->out.x || d->q[1] != d->out.y || d->q[2] != d->out.z) return no("lattice, input and output extents differ");
+  }
   if (d->q[0] % SC_TX || d->q[1] % SC_TY || d->q[2] % SC_TZ) return no("extent is not a multiple of the tile");
-  if (d->ntaps == 9) {
+  if (ps) {
+  } else if (d->ntaps == 9) {
     for (int t = 0; t < 9; ++t)
       if (d->tap_off[t][0] != t / 3 - 1 || d->tap_off[t][1] != t % 3 - 1 || d->tap_off[t][2] != 0) return no("taps are not the 3x3x1 stencil in (x, y) order");
   } else if (d->ntaps == 1) {
@@ -427,7 +452,7 @@ static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   } else return no("3x3x1 or 1x1x1 taps only");
   if (d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15)) return no("input must be one channel chunk of 16-byte aligned voxel rows");
   if (d->ksteps != (d->ntaps * (d->ck / 8) + 3) / 4) return no("ksteps");
-  if (d->out.c > d->nt * 16 || (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32)) return no("output channels / dtype");
+  if ((!ps && d->out.c > d->nt * 16) || (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32)) return no("output channels / dtype");
   if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
   if (d->stats && (d->accumulate || d->res_mode != VSSEG_RES_NONE)) return no("statistics combined with a residual");
   if (d->accumulate && d->res_mode != VSSEG_RES_NONE) return no("accumulate combined with a residual");
@@ -444,14 +469,14 @@ static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
 int vsseg_sconv_lds_bytes(const vsseg_igemm_desc* d) {
   const char* why;
   const ScEntry* e = sc_find(d, &why);
-  if (!e) { vsseg_set_error("vsseg_igemm: depth -2 (streaming kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -2 / -4 (streaming kernel) not applicable: %s", why); return VSSEG_EINVAL; }
   return e->lds();
 }
 
 int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t s) {
   const char* why;
   const ScEntry* e = sc_find(d, &why);
-  if (!e) { vsseg_set_error("vsseg_igemm: depth -2 (streaming kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -2 / -4 (streaming kernel) not applicable: %s", why); return VSSEG_EINVAL; }
   SconvK k;
   auto magic = [](int dv) { return dv <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)dv - 1) / (unsigned)dv); };
   k.in0 = reinterpret_cast<const char*>(d->in.ptr);
@@ -497,7 +522,7 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
     k.bn_scale = b.scale; k.bn_shift = b.shift; k.bn_mean = b.mean; k.bn_invstd = b.invstd; k.bn_alpha = b.alpha;
     k.bn_sums = b.sums; k.bn_alpha_acc = b.alpha_acc; k.bn_stride = b.stride; k.bn_inv_keep = 1.f / (1.f - b.p_drop);
   }
-  k.act = d->act; k.cout = d->out.c; k.cout_mod = d->cout_mod;
+  k.act = d->act; k.cout = d->depth == -4 ? d->nt * 16 : d->out.c; k.cout_mod = d->cout_mod;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.ntx = k.X / (2 * sc_mt(d->ck, d->ntaps)); k.nty = k.Y / SC_TY; k.ntz = k.Z / SC_TZ;
   k.mg_tx = magic(k.ntx); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);

@@ -223,6 +223,13 @@ class Plan:
         def choices(kind, Lr, q, kc_pad, aux_es, in_split, absorbed, fold=False):
             out = []
             woff = eng.layout.param_off[Lr.wkey][0]
+            if eng.fuse_classes and not fold and absorbed is None and not in_split:
+                # the four output-parity classes of a stride-(2,2,1) transposed convolution / data gradient as ONE streaming-kernel launch
+                # (planner.shuffle_plan): the per-class launches each read the whole input
+                kreal, nreal = P.gemm_dims(kind, Lr.wshape)
+                sp = P.shuffle_plan(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
+                if sp is not None:
+                    return [_Choice([sp], woff, wshape=tuple(Lr.wshape))]
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -402,17 +409,21 @@ class Plan:
             pl = self._choose(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
             self._register(ch, pl)
         self._fill_desc(d, pl)
+        if pl.depth == -4:  # fused output-parity classes: output channel tile t is class t, its channels are the real channels 0..nc-1
+            d.cout_mod = pl.nc
         self._wpack_fixups.append((d, ch.map_off))
         self.keep.append(d)
         nvalid = nb  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
+        if pl.depth == -4:
+            nvalid = nb * out.x * out.y * out.z
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         if bnred is not None:
             accumulate = 1  # metadata only: the launch reads one more output-sized tensor (the layer's pre-activation)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
-        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth == -2 else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * pl.ntaps * pl.kreal * pl.nc / max(ch.fold, 1),
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth in (-2, -4) else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * (2.25 if pl.depth == -4 else pl.ntaps) * pl.kreal * pl.nc / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
                     bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
@@ -930,6 +941,7 @@ class Engine:
         # the separate pass, 36.4-36.6 -> 36.8 ms per step: the reduce kernel streams its two tensors at 5.2 TB/s, the convolution that takes over
         # one of those reads runs at 3.5-4.5 TB/s and pays the dz arithmetic in its epilogue.  Off by default
         self.bnred = os.environ.get("VSSEG_BNRED", "0") == "1"
+        self.fuse_classes = os.environ.get("VSSEG_FUSE_CLASSES", "1") != "0" and not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient

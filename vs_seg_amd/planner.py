@@ -169,9 +169,9 @@ def stream_eligible(cls: "LatticeClass", q, kc, nreal, es) -> bool:
 
 def stream_lds_bytes(kc, nt, ntaps):
     g = kc // 8
-    r = 1 if ntaps == 9 else 0
+    r = {9: 2, 4: 1}.get(ntaps, 0)  # halo voxels added per axis (x, y)
     tile = stream_tile(kc, ntaps)
-    pieces = (tile[0] + 2 * r) * (tile[1] + 2 * r) * tile[2] * g
+    pieces = (tile[0] + r) * (tile[1] + r) * tile[2] * g
     return ((ntaps * g + 3) // 4) * nt * 1024 + ((pieces + 255) // 256) * 4096 + 5 * nt * 16 * 4 + 16
 
 
@@ -183,6 +183,39 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
     nt = (nreal + 15) // 16
     ntaps = len(cls.taps)
     return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, stream_tile(kc, ntaps), stream_mt(kc, ntaps), nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
+
+
+# ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
+def shuffle_plan(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional["IgemmPlan"]:
+    """ONE launch for the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient with 16 output
+    channels: a stride-1 convolution on the coarse lattice over the 2x2x1 neighbourhood (+0 / +1) with 4 x 16 output channels — channel tile
+    t is class (px, py) = (t >> 1, t & 1) and is stored at fine voxel (2x + px, 2y + py, z).  A (class, tap) pair without a kernel element
+    has zero weights (9 of the 16 pairs are real).  The per-class launches each read the whole input; this one reads it once."""
+    if kind not in ("convT_fwd", "conv_dgrad") or tuple(kernel) != (3, 3, 1) or tuple(stride) != (2, 2, 1) or es != 2:
+        return None
+    if nreal != 16 or kc not in (16, 32) or kc != kreal or any(v % t for v, t in zip(q, (8, 8, 4))):
+        return None
+    classes = lattice_classes(kind, kernel, stride)
+    if [tuple(c.oo) for c in classes] != [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)]:
+        return None
+    taps = [((dx, dy, 0), (0, 0, 0)) for dx in (0, 1) for dy in (0, 1)]
+    cls = LatticeClass((2, 2, 1), (0, 0, 0), (1, 1, 1), taps)
+    g = kc // 8
+    pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (8, 8, 4), 4, 4, 1, kc, 1, g, stream_lds_bytes(kc, 4, 4), -4)
+    K = int(np.prod(wshape[2:]))
+    ks, t, lane, j = np.meshgrid(np.arange(g), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
+    p = ks * 4 + (lane >> 4)
+    tap, cg = p // g, p % g
+    c, n = cg * 8 + j, lane & 15
+    kidx = np.full((4, 4), -1, np.int64)  # [class][tap] -> flat kernel index
+    for ci, cl in enumerate(classes):
+        for off, w in cl.taps:
+            kidx[ci, off[0] * 2 + off[1]] = (w[0] * wshape[3] + w[1]) * wshape[4] + w[2]
+    d = kidx[t, tap]
+    valid = (d >= 0) & (c < kreal) & (n < nreal)
+    flat = weight_flat_index(kind, wshape, np.where(valid, c, 0), np.where(valid, n, 0), np.where(valid, d, 0))
+    pl.pack_map = np.where(valid, flat, -1).astype(np.int32).reshape(-1)
+    return pl
 
 
 # ---- compute-bound kernel (csrc/cconv.hip): depth -3 -----------------------------------------------------------------------
