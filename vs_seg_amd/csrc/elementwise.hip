@@ -306,9 +306,11 @@ template <> struct Raw8<float> {
 template <typename T, int U>
 __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc,
                                                                const uint8_t* __restrict__ keep_in) {
-  extern __shared__ float red[];  // [3][c] + [1]
-  const int C = cgs * 8;
-  for (int i = threadIdx.x; i < 3 * C + 1; i += blockDim.x) red[i] = 0.f;
+  // one [3][c] + [1] region per WAVE: with a single region every thread of the workgroup added its 24 partial sums to the same 3*C
+  // addresses (64 .. 128 lanes per address, serialised by the LDS): on a 48-channel 151 MB tensor that tail cost as much as the pass itself
+  extern __shared__ float red[];
+  const int C = cgs * 8, RW = 3 * C + 1, nw = (blockDim.x + 63) >> 6;
+  for (int i = threadIdx.x; i < nw * RW; i += blockDim.x) red[i] = 0.f;
   __syncthreads();
   const float alpha = *a.alpha;
   if (a.p_drop > 0.f && keep_in == nullptr) dropout_resolve_seed(a.seed, a.salt);
@@ -359,19 +361,21 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   if (!drop) sweep(std::integral_constant<int, 0>{});
   else if (keep_in != nullptr) sweep(std::integral_constant<int, 1>{});
   else sweep(std::integral_constant<int, 2>{});
+  float* rw = red + (threadIdx.x >> 6) * RW;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { atomicAdd(&red[c + j], s1[j]); atomicAdd(&red[C + c + j], s2[j]); atomicAdd(&red[2 * C + c + j], s3[j]); }
+  for (int j = 0; j < 8; ++j) { atomicAdd(&rw[c + j], s1[j]); atomicAdd(&rw[C + c + j], s2[j]); atomicAdd(&rw[2 * C + c + j], s3[j]); }
   dal = wave_sum(dal);
-  if ((threadIdx.x & 63) == 0) atomicAdd(&red[3 * C], dal);
+  if ((threadIdx.x & 63) == 0) rw[3 * C] = dal;
   __syncthreads();
+  auto wsum = [&](int i) { float v = 0.f; for (int w = 0; w < nw; ++w) v += red[w * RW + i]; return v; };
   const int shard = blockIdx.x % VSSEG_STAT_SHARDS;
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     const int which = i / C, ch = i % C;
-    double val = (double)red[i];
-    if (which == 1) val = (double)a.invstd[ch] * (val - (double)a.mean[ch] * (double)red[ch]);  // sum(dz * xhat) of this workgroup
+    double val = (double)wsum(i);
+    if (which == 1) val = (double)a.invstd[ch] * (val - (double)a.mean[ch] * (double)wsum(ch));  // sum(dz * xhat) of this workgroup
     atomicAdd(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val);
   }
-  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)red[3 * C]);
+  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)wsum(3 * C));
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, const uint8_t* keep_in, void* stream) {
@@ -383,12 +387,15 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
   static int unroll = -1;  // voxels in flight per thread (tuning aid: VSSEG_BN_REDUCE_U = 2 | 4)
   if (unroll < 0) { const char* e = getenv("VSSEG_BN_REDUCE_U"); unroll = e ? atoi(e) : 2; }
-  size_t lds = (3 * y.c + 1) * sizeof(float);
-  // Every workgroup ends with 3*C fp64 atomics into the sharded sums: on the small tensors of the deep levels a grid sized for streaming
-  // (one item pair per thread) spent more time in those atomics than in the pass (18 launches of levels 2-5 averaged 69 us against 23 us
-  // for the apply pass over the same tensors).  At least 16 voxel groups per thread before another workgroup is worth its flush.
+  size_t lds = (size_t)((blk + 63) / 64) * (3 * y.c + 1) * sizeof(float);
+  // Every workgroup ends with 3*C fp64 atomics into the sharded sums, and those retire at only ~2.3 G/s (measured: a 403 MB 32-channel tensor
+  // 0.185 ms with 1536 workgroups, 0.153 ms = 5.3 TB/s with 768; a 151 MB 48-channel tensor 0.133 ms with 1536, 0.073 ms with 384).  So the
+  // grid is sized by an atomics budget (~64 K per launch beyond 16 channels: 682 workgroups at 32 channels, 455 at 48), never below 384 workgroups
+  // and never with fewer than 16 voxel groups per thread.
   const int64_t items = nv * cgs;
-  const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(256, items / ((int64_t)blk * 16)));
+  static int budget = -1;  // tuning aid: VSSEG_BN_REDUCE_ATOMICS
+  if (budget < 0) { const char* e = getenv("VSSEG_BN_REDUCE_ATOMICS"); budget = e ? atoi(e) : 65536; }
+  const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(384, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 8 : budget / (3 * y.c))));
   if (unroll == 2) {
     int grid = grid_for((nv * cgs + 1) / 2, blk, cap);
     DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
