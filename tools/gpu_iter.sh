@@ -1,4 +1,6 @@
+# one GPU iteration of the round: full test suite, then the step time as a user runs it
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "bn_dropout or fused_bn" -p no:cacheprovider 2>&1 | tail -1
-timeout 300 python tools/bench_eltwise.py --c 16 32 48 64 96 2>&1 | grep "reduce keep" | tr -s ' ' | cut -d' ' -f4-7 | paste -sd'|'
-for b in 400000 65536 400000 65536; do echo -n "budget=$b: "; VSSEG_BN_REDUCE_ATOMICS=$b timeout 300 python tools/time_step.py 30 2>&1 | tail -1; done
+mkdir -p gpurun_out/it
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/it/t.log 2>&1; echo "pytest rc=$?" >> gpurun_out/it/t.log
+tail -3 gpurun_out/it/t.log; grep FAILED gpurun_out/it/t.log | head -5
+for i in 1 2; do timeout 300 python tools/time_step.py 30 2>&1 | tail -1; done
