@@ -388,10 +388,12 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   static int unroll = -1;  // voxels in flight per thread (tuning aid: VSSEG_BN_REDUCE_U = 2 | 4)
   if (unroll < 0) { const char* e = getenv("VSSEG_BN_REDUCE_U"); unroll = e ? atoi(e) : 2; }
   size_t lds = (size_t)((blk + 63) / 64) * (3 * y.c + 1) * sizeof(float);
-  // Every workgroup ends with 3*C fp64 atomics into the sharded sums, and those retire at only ~2.3 G/s (measured: a 403 MB 32-channel tensor
-  // 0.185 ms with 1536 workgroups, 0.153 ms = 5.3 TB/s with 768; a 151 MB 48-channel tensor 0.133 ms with 1536, 0.073 ms with 384).  So the
-  // grid is sized by an atomics budget (~64 K per launch beyond 16 channels: 682 workgroups at 32 channels, 455 at 48), never below 384 workgroups
-  // and never with fewer than 16 voxel groups per thread.
+  // Every workgroup ends with a flush (LDS reduction, then 3*C dependent fp64 adds into the sharded sums), and on everything but the largest
+  // tensors that tail — paid once per wave of workgroups on a CU — costs as much as the streaming itself (measured: a 403 MB 32-channel tensor
+  // 0.185 ms with 1536 workgroups, 0.151 ms = 5.3 TB/s with 682; a 151 MB 48-channel tensor 0.133 ms with 1536, 0.070 ms with 455).  Giving
+  // every workgroup its own row and plain read-modify-writes instead of atomics measured no better: it is the number of flushes, not the
+  // atomics.  So the grid is sized by a flush budget (~64 K adds per launch beyond 16 channels: 682 workgroups at 32 channels, 455 at 48),
+  // never below 384 workgroups and never with fewer than 16 voxel groups per thread.
   const int64_t items = nv * cgs;
   static int budget = -1;  // tuning aid: VSSEG_BN_REDUCE_ATOMICS
   if (budget < 0) { const char* e = getenv("VSSEG_BN_REDUCE_ATOMICS"); budget = e ? atoi(e) : 65536; }
