@@ -574,7 +574,7 @@ def test_fused_bn_backward_reduction_equals_separate_pass(k, c, dims, p_drop):
 
 
 @pytest.mark.parametrize("kind,cin,cout,dims,mode", [("convT_fwd", 32, 16, (8, 16, 8), "stats"), ("convT_fwd", 32, 16, (16, 8, 4), "plain"), ("conv_dgrad", 16, 16, (8, 16, 8), "accumulate"),
-                                                     ("conv_dgrad", 16, 16, (16, 16, 4), "plain")])
+                                                     ("conv_dgrad", 16, 16, (16, 16, 4), "plain"), ("convT_fwd", 48, 32, (8, 16, 8), "stats"), ("conv_dgrad", 32, 32, (8, 8, 8), "accumulate")])
 def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mode):
     """depth -4: the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient as ONE launch of the
     streaming kernel (coarse lattice, 2x2x1 neighbourhood, 4 x 16 output channels, pixel-shuffle store).  Must equal the four per-class
@@ -605,20 +605,21 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
         want = want + H.from_cl(prev).double()
 
     def stats_buf():
-        return torch.zeros(L.STAT_SHARDS * 2 * 16, dtype=torch.float64, device="cuda")
+        return torch.zeros(L.STAT_SHARDS * 2 * nout, dtype=torch.float64, device="cuda")
 
     # reference: one launch of the general kernel per parity class
     out_a = prev.clone() if mode == "accumulate" else torch.zeros(n, *fine, nout, dtype=H.DT[dt], device="cuda")
     sa = stats_buf()
-    H.run_lattice_op(kind, w, inp_cl, out_a, st, **(dict(stats=sa.data_ptr(), stats_stride=16) if mode == "stats" else kw))
+    H.run_lattice_op(kind, w, inp_cl, out_a, st, **(dict(stats=sa.data_ptr(), stats_stride=nout) if mode == "stats" else kw))
     # fused
     kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
-    pl = P.shuffle_plan(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal)
-    assert pl is not None and pl.depth == -4
+    pls = P.shuffle_plans(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal)
+    assert pls is not None and len(pls) == nout // 16 and all(pl.depth == -4 for pl in pls)  # 16 channels: one launch; 32: one per px
     out_b = prev.clone() if mode == "accumulate" else torch.zeros_like(out_a)
     sb = stats_buf()
-    d = H.igemm_desc(pl, H.pack(pl, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_b), cout_mod=16, **(dict(stats=sb.data_ptr(), stats_stride=16) if mode == "stats" else kw))
-    L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "fused classes")
+    for pl in pls:
+        d = H.igemm_desc(pl, H.pack(pl, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_b), cout_mod=nout, **(dict(stats=sb.data_ptr(), stats_stride=nout) if mode == "stats" else kw))
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "fused classes")
     torch.cuda.synchronize()
     np.testing.assert_allclose(H.from_cl(out_b).numpy(), want.float().numpy(), atol=_tol(dt, want))
     assert float((out_a.float() - out_b.float()).abs().max()) <= 2 * _tol(dt, want)  # same products, different fp32 summation order of the taps

@@ -48,6 +48,7 @@ struct SconvK {
   int X, Y, Z, ntx, nty, ntz;
   unsigned mg_tz, mg_ty, mg_tx;  // ceil(2^32 / d): exact quotients by one s_mul_hi_u32
   int tiles, per_xcd, walk;
+  int ps_cls0, ps_tpc_shift;  // fused output-parity classes (taps 4): first class of the launch, log2(channel tiles per class)
   // fused BatchNorm-backward reduction over the output (MODE 3; vsseg_bnred)
   const char* bn_y; const unsigned char* bn_keep;
   const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_alpha;
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
   // t is parity class (px, py) = (t >> 1, t & 1) and is stored at fine voxel (2x + px, 2y + py, z) — ONE read of the input instead of one per class
   constexpr int R = TAPS == 9 ? 1 : 0, RH = (TAPS == 9 || TAPS == 4) ? 1 : 0;
   constexpr bool PS = TAPS == 4;
+  const int tpc_sh = PS ? k.ps_tpc_shift : 0;  // PS: log2 of the 16-channel tiles per parity class (1 tile: all 4 classes in this launch; 2 tiles: classes (px, 0) and (px, 1))
   constexpr int MT = sc_mt(CIN, TAPS), SC_TX = 2 * MT;
   constexpr int HX = SC_TX + R + RH, HY = SC_TY + R + RH, HZ = SC_TZ;
   constexpr int PIECES = HX * HY * HZ * G, NINST = (PIECES + 255) / 256;
@@ -158,12 +160,13 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
       if constexpr (PS) {
         const int OY = 2 * Y;
         const int64_t base = (((int64_t)n * (2 * X) + 2 * x0) * OY + 2 * y0) * Z + z0;
-        return base + (int64_t)((2 * (wave * (MT / 2) + (m >> 1)) + (t >> 1)) * OY + 2 * (vy0 + (m & 1) * 4) + (t & 1)) * Z + vz;
+        const int cls = k.ps_cls0 + (t >> tpc_sh);  // parity class (px, py) = (cls >> 1, cls & 1)
+        return base + (int64_t)((2 * (wave * (MT / 2) + (m >> 1)) + (cls >> 1)) * OY + 2 * (vy0 + (m & 1) * 4) + (cls & 1)) * Z + vz;
       } else {
         return ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
       }
     };
-    auto out_ch = [&](int t) -> int { return PS ? g * 4 : t * 16 + g * 4; };
+    auto out_ch = [&](int t) -> int { return PS ? (t & ((1 << tpc_sh) - 1)) * 16 + g * 4 : t * 16 + g * 4; };
     const bool interior = (R == 0 || (x0 > 0 && y0 > 0)) && (RH == 0 || (x0 + SC_TX < X && y0 + SC_TY < Y));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave has read the previous tile's halo
@@ -420,7 +423,7 @@ struct ScEntry { int cin, nt, taps; sc_fn_t fn; int (*lds)(); };
 #define SC_E(C, N, T) {C, N, T, sc_launch<C, N, T>, sc_lds<C, N, T>}
 static const ScEntry sc_table[] = {SC_E(8, 1, 9),  SC_E(8, 2, 9),  SC_E(16, 1, 9), SC_E(16, 2, 9), SC_E(16, 4, 9), SC_E(32, 1, 9), SC_E(32, 2, 9), SC_E(32, 4, 9),
                                    SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1), SC_E(64, 2, 9),
-                                   SC_E(16, 4, 4), SC_E(32, 4, 4)};  // taps 4: the fused output-parity classes (pixel shuffle), 16 channels per class
+                                   SC_E(16, 4, 4), SC_E(32, 4, 4), SC_E(48, 4, 4)};  // taps 4: fused output-parity classes (pixel shuffle): 4 classes x 16 channels, or 2 classes x 32 channels per launch
 
 static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
@@ -431,9 +434,11 @@ static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
   if (d->tile[0] != SC_TX || d->tile[1] != SC_TY || d->tile[2] != SC_TZ) return no("tile must be 8x8x4 (4x8x4 for 64 input channels x 9 taps)");
   const bool ps = d->depth == -4;  // fused output-parity classes: coarse lattice in, fine tensor (2x, 2y, z) out, 4 taps (+0 / +1 in x and y)
   if (ps) {
-    if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->os[0] != 2 || d->os[1] != 2 || d->os[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = 0");
+    if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->os[0] != 2 || d->os[1] != 2 || d->os[2] != 1 || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = (px, 0, 0)");
     if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || 2 * d->q[0] != d->out.x || 2 * d->q[1] != d->out.y || d->q[2] != d->out.z) return no("pixel-shuffle output must be (2x, 2y, z) of the lattice");
-    if (d->ntaps != 4 || d->nt != 4 || d->out.c != 16 || d->cout_mod != 16 || d->out.ptr2 || d->out.dtype != VSSEG_BF16) return no("pixel-shuffle launches need 4 taps, 4 classes of 16 bf16 output channels (cout_mod 16), a one-part output");
+    // nt = 4 channel tiles: all four classes of 16 channels (oo = 0), or the classes (px, 0), (px, 1) of 32 channels (oo = (px, 0, 0))
+    if (d->ntaps != 4 || d->nt != 4 || (d->out.c != 16 && d->out.c != 32) || d->cout_mod != d->out.c || d->out.ptr2 || d->out.dtype != VSSEG_BF16) return no("pixel-shuffle launches need 4 taps, 4 channel tiles, 16 or 32 bf16 output channels (cout_mod = channels), a one-part output");
+    if ((d->out.c == 16 && d->oo[0] != 0) || (unsigned)d->oo[0] > 1u) return no("pixel-shuffle class offset");
     for (int t = 0; t < 4; ++t)
       if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
     if (d->res_mode != VSSEG_RES_NONE || d->bnred) return no("pixel-shuffle launches support statistics or accumulate only");
@@ -523,6 +528,8 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
     k.bn_sums = b.sums; k.bn_alpha_acc = b.alpha_acc; k.bn_stride = b.stride; k.bn_inv_keep = 1.f / (1.f - b.p_drop);
   }
   k.act = d->act; k.cout = d->depth == -4 ? d->nt * 16 : d->out.c; k.cout_mod = d->cout_mod;
+  k.ps_cls0 = d->depth == -4 ? 2 * d->oo[0] : 0;
+  k.ps_tpc_shift = (d->depth == -4 && d->out.c == 32) ? 1 : 0;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.ntx = k.X / (2 * sc_mt(d->ck, d->ntaps)); k.nty = k.Y / SC_TY; k.ntz = k.Z / SC_TZ;
   k.mg_tx = magic(k.ntx); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);

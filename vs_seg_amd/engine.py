@@ -227,9 +227,9 @@ class Plan:
                 # the four output-parity classes of a stride-(2,2,1) transposed convolution / data gradient as ONE streaming-kernel launch
                 # (planner.shuffle_plan): the per-class launches each read the whole input
                 kreal, nreal = P.gemm_dims(kind, Lr.wshape)
-                sp = P.shuffle_plan(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
-                if sp is not None:
-                    return [_Choice([sp], woff, wshape=tuple(Lr.wshape))]
+                sps = P.shuffle_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
+                if sps is not None:
+                    return [_Choice([sp], woff, wshape=tuple(Lr.wshape)) for sp in sps]
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -417,7 +417,7 @@ class Plan:
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         if pl.depth == -4:
-            nvalid = nb * out.x * out.y * out.z
+            nvalid = nb * out.x * out.y * out.z * (pl.nt * 16 // pl.nc) // 4  # the parity classes this launch writes
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         if bnred is not None:
             accumulate = 1  # metadata only: the launch reads one more output-sized tensor (the layer's pre-activation)

@@ -186,36 +186,40 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
 
 
 # ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
-def shuffle_plan(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional["IgemmPlan"]:
-    """ONE launch for the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient with 16 output
-    channels: a stride-1 convolution on the coarse lattice over the 2x2x1 neighbourhood (+0 / +1) with 4 x 16 output channels — channel tile
-    t is class (px, py) = (t >> 1, t & 1) and is stored at fine voxel (2x + px, 2y + py, z).  A (class, tap) pair without a kernel element
-    has zero weights (9 of the 16 pairs are real).  The per-class launches each read the whole input; this one reads it once."""
+def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional[List["IgemmPlan"]]:
+    """The output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient fused into streaming-kernel launches: a
+    stride-1 convolution on the coarse lattice over the 2x2x1 neighbourhood (+0 / +1) whose 4 channel tiles are parity classes — channel tile
+    t of class (px, py) is stored at fine voxel (2x + px, 2y + py, z); a (class, tap) pair without a kernel element has zero weights.
+    16 output channels: ONE launch for all four classes (9 of the 16 pairs are real).  32 output channels: one launch per px with the classes
+    (px, 0), (px, 1) (two channel tiles each).  The per-class launches each read the whole input; these read it once / twice."""
     if kind not in ("convT_fwd", "conv_dgrad") or tuple(kernel) != (3, 3, 1) or tuple(stride) != (2, 2, 1) or es != 2:
         return None
-    if nreal != 16 or kc not in (16, 32) or kc != kreal or any(v % t for v, t in zip(q, (8, 8, 4))):
+    if (nreal, kc) not in ((16, 16), (16, 32), (32, 32), (32, 48)) or kc != kreal or any(v % t for v, t in zip(q, (8, 8, 4))):  # instantiations of sconv.hip (taps 4)
         return None
     classes = lattice_classes(kind, kernel, stride)
     if [tuple(c.oo) for c in classes] != [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)]:
         return None
     taps = [((dx, dy, 0), (0, 0, 0)) for dx in (0, 1) for dy in (0, 1)]
-    cls = LatticeClass((2, 2, 1), (0, 0, 0), (1, 1, 1), taps)
     g = kc // 8
-    pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (8, 8, 4), 4, 4, 1, kc, 1, g, stream_lds_bytes(kc, 4, 4), -4)
-    K = int(np.prod(wshape[2:]))
-    ks, t, lane, j = np.meshgrid(np.arange(g), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
-    p = ks * 4 + (lane >> 4)
-    tap, cg = p // g, p % g
-    c, n = cg * 8 + j, lane & 15
+    tpc = nreal // 16  # 16-channel tiles per parity class
     kidx = np.full((4, 4), -1, np.int64)  # [class][tap] -> flat kernel index
     for ci, cl in enumerate(classes):
         for off, w in cl.taps:
             kidx[ci, off[0] * 2 + off[1]] = (w[0] * wshape[3] + w[1]) * wshape[4] + w[2]
-    d = kidx[t, tap]
-    valid = (d >= 0) & (c < kreal) & (n < nreal)
-    flat = weight_flat_index(kind, wshape, np.where(valid, c, 0), np.where(valid, n, 0), np.where(valid, d, 0))
-    pl.pack_map = np.where(valid, flat, -1).astype(np.int32).reshape(-1)
-    return pl
+    plans = []
+    for px in range(tpc):  # tpc == 1: all four classes in one launch; tpc == 2: classes (px, 0), (px, 1)
+        cls = LatticeClass((2, 2, 1), (px, 0, 0), (1, 1, 1), taps)
+        pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (8, 8, 4), 4, 4, 1, kc, 1, g, stream_lds_bytes(kc, 4, 4), -4)
+        ks, t, lane, j = np.meshgrid(np.arange(g), np.arange(4), np.arange(64), np.arange(8), indexing="ij")
+        p = ks * 4 + (lane >> 4)
+        tap, cg = p // g, p % g
+        c, n = cg * 8 + j, (t % tpc) * 16 + (lane & 15)
+        d = kidx[2 * px * (tpc - 1) + t // tpc, tap]
+        valid = (d >= 0) & (c < kreal) & (n < nreal)
+        flat = weight_flat_index(kind, wshape, np.where(valid, c, 0), np.where(valid, n, 0), np.where(valid, d, 0))
+        pl.pack_map = np.where(valid, flat, -1).astype(np.int32).reshape(-1)
+        plans.append(pl)
+    return plans
 
 
 # ---- compute-bound kernel (csrc/cconv.hip): depth -3 -----------------------------------------------------------------------
