@@ -91,8 +91,10 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 ctr, uint2 key) {
   const unsigned M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
   for (int i = 0; i < 10; ++i) {
-    unsigned hi0 = __umulhi(M0, ctr.x), lo0 = M0 * ctr.x;
-    unsigned hi1 = __umulhi(M1, ctr.z), lo1 = M1 * ctr.z;
+    // one 32x32 -> 64-bit product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: the generator is what bounds
+    // bn_act_fwd, and these are quarter-rate instructions
+    const unsigned long long p0 = (unsigned long long)M0 * ctr.x, p1 = (unsigned long long)M1 * ctr.z;
+    const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
     ctr = make_uint4(hi1 ^ ctr.y ^ key.x, lo1, hi0 ^ ctr.w ^ key.y, lo0);
     key.x += W0;
     key.y += W1;
