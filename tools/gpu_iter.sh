@@ -1,4 +1,6 @@
+# one GPU iteration of the round: full test suite, then the step time as a user runs it
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -k "bn_dropout or dropout" -p no:cacheprovider 2>&1 | tail -1
-timeout 300 python tools/bench_eltwise.py --c 16 32 2>&1 | grep "bn_act_fwd\|bwd_reduce  \|---"
+mkdir -p gpurun_out/it
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/it/t.log 2>&1; echo "pytest rc=$?" >> gpurun_out/it/t.log
+tail -3 gpurun_out/it/t.log; grep FAILED gpurun_out/it/t.log | head -5
 for i in 1 2; do timeout 300 python tools/time_step.py 30 2>&1 | tail -1; done
