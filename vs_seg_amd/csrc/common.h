@@ -60,7 +60,12 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
   uint2 u;
   u.x = f2bf2(v.x, v.y);
   u.y = f2bf2(v.z, v.w);
+#ifdef VSSEG_NT_STORES
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_nontemporal_store(u32x2{u.x, u.y}, reinterpret_cast<u32x2*>(p));
+#else
   *reinterpret_cast<uint2*>(p) = u;
+#endif
 }
 // 8 consecutive channels
 struct f8 { float v[8]; };
@@ -83,7 +88,12 @@ __device__ __forceinline__ void st8(bf16_t* p, const f8& a) {
   u.y = f2bf2(a.v[2], a.v[3]);
   u.z = f2bf2(a.v[4], a.v[5]);
   u.w = f2bf2(a.v[6], a.v[7]);
+#ifdef VSSEG_NT_STORES
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(u32x4{u.x, u.y, u.z, u.w}, reinterpret_cast<u32x4*>(p));
+#else
   *reinterpret_cast<uint4*>(p) = u;
+#endif
 }
 
 // ---- Philox4x32-10 counter-based RNG: dropout keep-masks are regenerated in backward instead of stored ----
