@@ -74,7 +74,13 @@ __device__ __forceinline__ f8 ld8(const float* p) {
   return f8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
 }
 __device__ __forceinline__ f8 ld8(const bf16_t* p) {
+#ifdef VSSEG_NT_LOADS
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  uint4 u = make_uint4(t[0], t[1], t[2], t[3]);
+#else
   uint4 u = *reinterpret_cast<const uint4*>(p);
+#endif
   return f8{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
              __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
 }

@@ -1,8 +1,10 @@
 // HBM-bound kernels of the hot path: BatchNorm/Dropout/PReLU forward+backward, attention gate, staging, Adam.
 // All are one-pass streaming kernels with 16-byte (8 x bf16) accesses along the channel axis of the channels-last layout.
-// The streaming kernels of this file write their bf16 outputs with non-temporal stores (st4 / st8 in common.h): +3-6 % on each of them and
-// -0.2 ms per step.  NOT the convolution kernels: with their outputs stored non-temporally the step got 1.5 ms slower.
+// The streaming kernels of this file read and write their bf16 tensors with non-temporal loads / stores (ld8 / st4 / st8 in common.h, Raw8
+// below): stores +3-6 % on each kernel and -0.2 ms per step, loads another +5-12 % (bn_act_bwd_apply 5.2 -> 5.8 TB/s, att_apply_fwd 5.1 -> 5.7)
+// and -0.3 ms.  NOT the convolution kernels: with their outputs stored non-temporally the step got 1.5 ms slower.
 #define VSSEG_NT_STORES
+#define VSSEG_NT_LOADS
 #include "common.h"
 #include <algorithm>
 #include <type_traits>
@@ -294,7 +296,17 @@ __device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, 
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
   uint4 u;
-  static __device__ __forceinline__ Raw8 ld(const bf16_t* p) { Raw8 r; r.u = *reinterpret_cast<const uint4*>(p); return r; }
+  static __device__ __forceinline__ Raw8 ld(const bf16_t* p) {
+    Raw8 r;
+#ifdef VSSEG_NT_LOADS
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    r.u = make_uint4(t[0], t[1], t[2], t[3]);
+#else
+    r.u = *reinterpret_cast<const uint4*>(p);
+#endif
+    return r;
+  }
   __device__ __forceinline__ f8 cvt() const {
     return f8{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
                __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};

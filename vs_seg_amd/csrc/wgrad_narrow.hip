@@ -13,6 +13,7 @@
 // neighbouring voxels overlap), 288 FMAs, 72 accumulators kept in registers over all its voxels; per workgroup one LDS reduction and one
 // slab of partial sums (plain stores), summed into dw by a second tiny kernel — 1024 workgroups x 144 fp32 atomics on the same 144
 // addresses measured 0.72 ms for the whole launch, slower than the MFMA kernel.  T is read exactly once, s nine times out of L1/L2.
+#define VSSEG_NT_LOADS  // the C-channel tensor is read exactly once (ld8): non-temporal; the one-channel field is re-read nine times and stays cached
 #include "common.h"
 
 struct WnK {
