@@ -453,6 +453,7 @@ COMPUTE_CASES = [
     ("conv_dgrad", 96, 48, (8, 16, 32), 0),   # K = 48, N = 96: two workgroups per voxel tile (nsplit 2)
     ("conv_dgrad", 32, 48, (8, 16, 32), 0),   # K = 48, N = 32: two 16-channel tiles per workgroup
     ("conv_fwd", 64, 64, (8, 8, 16), 0),      # level-3 shape: 2 x 2 channel tiles
+    ("conv_dgrad", 128, 64, (8, 8, 16), 0),   # K = 64, N = 128 (the level-3 concat gradient): four workgroups per voxel tile
 ]
 
 

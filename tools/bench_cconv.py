@@ -16,7 +16,7 @@ K3 = (3, 3, 3)
 L2, L3 = (96, 32, 128), (48, 16, 64)
 CASES = [("conv_fwd", 96, 48, L2, "plain"), ("conv_fwd", 96, 48, L2, "stats"), ("conv_fwd", 48, 48, L2, "stats"), ("conv_fwd", 32, 48, L2, "stats"),
          ("conv_dgrad", 96, 48, L2, "accumulate"), ("conv_dgrad", 48, 48, L2, "plain"), ("conv_dgrad", 32, 48, L2, "accumulate"),
-         ("conv_fwd", 128, 64, L3, "stats"), ("conv_fwd", 64, 64, L3, "stats"), ("conv_dgrad", 64, 64, L3, "plain")]
+         ("conv_fwd", 128, 64, L3, "stats"), ("conv_fwd", 64, 64, L3, "stats"), ("conv_dgrad", 64, 64, L3, "plain"), ("conv_dgrad", 128, 64, L3, "plain")]
 
 
 def main():

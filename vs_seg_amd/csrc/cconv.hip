@@ -1,5 +1,5 @@
 // Compute-bound convolution: the MFMA-bound launches of vsseg_igemm — stride-1 3x3x3 bf16 convolutions and data gradients with 32..160 input
-// channels and 32 / 48 output channels per workgroup on the 96x32x128 and 48x16x64 levels of the 2.5D U-Net
+// channels and 32 / 48 output channels per workgroup (1, 2 or 4 workgroups per voxel tile) on the 96x32x128 and 48x16x64 levels of the 2.5D U-Net
 // (ref:params/networks/blocks/convolutions.py:114-146; SURVEY §8a rows 9, 10, 13, 14, 31, 34, 36, 39 and their data gradients: 54 % of the
 // network's MACs) — as a kernel whose geometry is a compile-time constant (launch plans with depth = -3).
 //
@@ -443,7 +443,7 @@ static const char* cc_check(const vsseg_igemm_desc* d) {
     if (d->tap_off[t][0] != t / 9 - 1 || d->tap_off[t][1] != (t / 3) % 3 - 1 || d->tap_off[t][2] != t % 3 - 1) return "taps are not the 3x3x3 stencil in (x, y, z) order";
   if (d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15)) return "input must be 16-byte aligned voxel rows";
   if (d->in.ptr2 && d->in.csplit % 16) return "input split must be a multiple of 16 channels";
-  if (d->nsplit < 1 || d->nsplit > 2 || d->out.c != d->nsplit * d->nt * 16) return "output channels must be nsplit (1, 2) x nt x 16";
+  if (d->nsplit < 1 || d->nsplit > 4 || d->nsplit == 3 || d->out.c != d->nsplit * d->nt * 16) return "output channels must be nsplit (1, 2, 4) x nt x 16";
   if (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32) return "output dtype";
   if (d->out.pitch & 3) return "output pitch";
   if (d->out.ptr2 && d->out.csplit % 16) return "output split must be a multiple of 16 channels";

@@ -229,8 +229,8 @@ _TAPS_3x3x3 = [(t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1) for t in range(27)]
 
 def compute_split(nreal):
     """(nt, nsplit) of the compute-bound kernel for `nreal` output channels: 2 or 3 sixteen-channel tiles per workgroup, 1 or 2 workgroups
-    per voxel tile (cc_check() in csrc/cconv.hip)."""
-    return {32: (2, 1), 48: (3, 1), 64: (2, 2), 96: (3, 2)}.get(nreal)
+    (4 for the 128-channel concat gradient of level 3) per voxel tile (cc_check() in csrc/cconv.hip)."""
+    return {32: (2, 1), 48: (3, 1), 64: (2, 2), 96: (3, 2), 128: (2, 4)}.get(nreal)
 
 
 def compute_lds_bytes(nt):
