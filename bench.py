@@ -160,6 +160,45 @@ def cpu_baseline(budget_s=25.0):
                 sample=f"1 training step (fwd+Dice_spvPA+bwd+Adam, fp32, batch 1) of the oracle on a {shape[0]}x{shape[1]}x{shape[2]} patch = {frac:.3f} of a 384x128x128 patch in {t:.2f} s, scaled by voxels")
 
 
+def sharded_cases(model, n_cases, rank, world, dev, barrier, t2_shape=(448, 448, 80)):
+    """BASELINE config 5's shape on the ranks that are there: `n_cases` synthetic T2-sized cases (the TCIA T2 matrix size is not recorded in the
+    reference, SURVEY §8d: fixed at 448x448x80 here; z pads to 128 -> 12 windows at roi 384x128x128 / overlap 0.5) sharded round-robin over the
+    ranks (`shard_indices`, as VSparams.run_inference does), hard Dice per case, the scores all-gathered INSIDE the timed region.  242 = the
+    size of params/split_TCIA.csv.  Returns the `sharded_cases` block of the bench line (every rank takes part; all ranks return it)."""
+    import torch.distributed as dist
+
+    import vs_seg_amd as V
+    from vs_seg_amd import parallel as DP
+
+    was_training = model.training
+    model.eval()
+    mine = DP.shard_indices(n_cases, rank, world)
+    pred = lambda w: model(w)[0]  # noqa: E731
+    vols = [torch.from_numpy(np.random.default_rng(100 + i % 4).standard_normal((1, 1, *t2_shape), dtype=np.float32)).to(dev) for i in range(4)]  # 4 distinct volumes reused round-robin (HBM-resident inputs)
+    lab = torch.zeros((1, 1, *t2_shape), device=dev)
+    lab[..., 200:260, 210:250, 30:50] = 1.0
+    on_device = world > 1 or DP._collectives_on()
+    with torch.no_grad():
+        V.compute_dice_score(V.sliding_window_inference(vols[0], PATCH, 1, pred, overlap=0.5, mode="gaussian"), lab)
+        barrier()
+        s0 = time.perf_counter()
+        scores = torch.zeros(len(mine), dtype=torch.float32, device=dev)
+        for j, ci in enumerate(mine):
+            out = V.sliding_window_inference(vols[ci % 4], PATCH, 1, pred, overlap=0.5, mode="gaussian")
+            scores[j] = V.compute_dice_score(out, lab).reshape(())
+        all_scores = DP.all_gather_scalars(scores.double().cpu().tolist(), n_cases, device=dev if on_device else "cpu")  # one host read per rank, then the gather
+        barrier()
+        cdt = time.perf_counter() - s0
+    if world > 1:
+        t = torch.tensor([cdt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cdt = float(t)
+    if was_training:
+        model.train()
+    return dict(volumes_per_sec=n_cases / cdt, cases=n_cases, volume="x".join(str(v) for v in t2_shape) + " (synthetic T2 shape)", roi="384x128x128", overlap=0.5, windows=12, mean_dice=float(np.mean(all_scores)),
+                scores=[round(float(v), 6) for v in all_scores][:16], sharding="cases round-robin over ranks (shard_indices), Dice scalars all-gathered inside the timed region")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,8 +207,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="patches per GPU (BASELINE config 2)")
     ap.add_argument("--dtype", default=os.environ.get("VSSEG_DTYPE", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--swi-volumes", type=int, default=2, help="sliding-window volumes per GPU timed after the training steps (0 = skip)")
-    ap.add_argument("--swi-cases", type=int, default=0, help="BASELINE config 5: N synthetic T2-shaped cases (448x448x80 -> 12 windows at roi 384x128x128 / overlap 0.5) sharded over the ranks, "
-                    "hard Dice per case, scores all-gathered; 242 = the size of params/split_TCIA.csv (0 = skip)")
+    ap.add_argument("--swi-cases", type=int, default=8, help="BASELINE config 5: N synthetic T2-shaped cases (448x448x80 -> 12 windows at roi 384x128x128 / overlap 0.5) sharded over the ranks, "
+                    "hard Dice per case, scores all-gathered; 242 = the size of params/split_TCIA.csv; default 8 so that every driver line carries the block (0 = skip)")
     ap.add_argument("--dropout", type=float, default=0.1, help="dropout probability of the timed network (reference: 0.1; other values are experiments and are named in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked configuration against the reference golden")
@@ -273,33 +312,7 @@ def main():
         model.train()
 
     # ---- BASELINE config 5: a TCIA-shaped synthetic T2 set, cases sharded over ranks, Dice scores all-gathered (timed with the gather)
-    c5 = None
-    if args.swi_cases > 0:
-        model.eval()
-        t2_shape = (448, 448, 80)  # the TCIA T2 matrix size is not recorded in the reference: fixed here; pads z to 128 -> 12 windows
-        mine = DP.shard_indices(args.swi_cases, rank, world)
-        pred = lambda w: model(w)[0]  # noqa: E731
-        vols = [torch.from_numpy(np.random.default_rng(100 + i % 4).standard_normal((1, 1, *t2_shape), dtype=np.float32)).to(dev) for i in range(4)]  # 4 distinct volumes reused round-robin (HBM-resident inputs)
-        lab = torch.zeros((1, 1, *t2_shape), device=dev)
-        lab[..., 200:260, 210:250, 30:50] = 1.0
-        with torch.no_grad():
-            V.compute_dice_score(V.sliding_window_inference(vols[0], PATCH, 1, pred, overlap=0.5, mode="gaussian"), lab)
-            barrier()
-            s0 = time.perf_counter()
-            scores = torch.zeros(len(mine), dtype=torch.float32, device=dev)
-            for j, ci in enumerate(mine):
-                out = V.sliding_window_inference(vols[ci % 4], PATCH, 1, pred, overlap=0.5, mode="gaussian")
-                scores[j] = V.compute_dice_score(out, lab).reshape(())
-            all_scores = DP.all_gather_scalars(scores.double().cpu().tolist(), args.swi_cases, device=dev if world > 1 else "cpu")  # one host read per rank, then the gather
-            barrier()
-            cdt = time.perf_counter() - s0
-        if world > 1:
-            t = torch.tensor([cdt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cdt = float(t)
-        c5 = dict(volumes_per_sec=args.swi_cases / cdt, cases=args.swi_cases, volume="448x448x80 (synthetic T2 shape)", roi="384x128x128", overlap=0.5, windows=12, mean_dice=float(np.mean(all_scores)),
-                  sharding="cases round-robin over ranks (shard_indices), Dice scalars all-gathered inside the timed region")
-        model.train()
+    c5 = sharded_cases(model, args.swi_cases, rank, world, dev, barrier) if args.swi_cases > 0 else None
 
     # ---- data side: RandFlipd + RandSpatialCropd of image+label batches from volumes cached in HBM
     from vs_seg_amd.data.transforms import PatchSampler

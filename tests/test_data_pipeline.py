@@ -186,6 +186,35 @@ def test_epoch_batches_give_every_rank_the_same_number_of_steps():
     assert one == [[0, 1], [2, 3], [4, 5], [6]]
 
 
+def test_validation_and_test_loaders_are_not_padded():
+    """wrap-around padding is for the training loader only.  The validation / test loaders issue one collective after
+    their loop; a padded case would be counted twice in the all-reduced Dice sums (46 test cases on 8 ranks: cases 0 and 1 twice)."""
+    from vs_seg_amd.data.transforms import epoch_batches
+    from vs_seg_amd.parallel import shard_indices
+
+    for n, world in [(46, 8), (20, 8), (5, 2), (3, 4)]:
+        per_rank = [epoch_batches(n, 1, False, np.random.RandomState(0), r, world, pad=False) for r in range(world)]
+        for r in range(world):  # exactly the shard run_inference writes its Dice scores into
+            assert [i for b in per_rank[r] for i in b] == shard_indices(n, r, world)
+        seen = sorted(i for b in per_rank for x in b for i in x)
+        assert seen == list(range(n))  # every case exactly once over all ranks
+
+
+def test_cached_loader_pads_only_when_it_shuffles(monkeypatch):
+    from vs_seg_amd import params as PR
+
+    monkeypatch.setattr(PR.DP, "get_rank", lambda: 1)
+    monkeypatch.setattr(PR.DP, "world_size", lambda: 2)
+    cases = [dict(image=None, label=None, image_meta={}, label_meta={}) for _ in range(5)]
+    train = PR.CachedLoader(cases, None, 1, True, None)
+    val = PR.CachedLoader(cases, None, 1, False, None)
+    assert train.pad and not val.pad
+    from vs_seg_amd.data.transforms import epoch_batches
+
+    assert len(epoch_batches(5, 1, True, np.random.RandomState(0), 1, 2, pad=train.pad)) == 3  # padded to 6 -> 3 per rank
+    assert epoch_batches(5, 1, False, np.random.RandomState(0), 1, 2, pad=val.pad) == [[1], [3]]
+
+
 def test_seeded_weights_helper_equals_the_oracle_generator():
     import torch
 

@@ -5,6 +5,7 @@ well inside the 1e-3 bar of BASELINE.json's north_star).  bf16 path = bf16 opera
 pre-rounded to bf16 on both sides so the only difference left is the output rounding (2^-8 relative).
 """
 import ctypes as C
+import dataclasses
 
 import numpy as np
 import pytest
@@ -444,6 +445,89 @@ def test_streaming_kernel_equals_general_kernel(kind, k, cin, cout, dims, split)
             a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), ss.view(L.STAT_SHARDS, 2, -1).sum(0)
             np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
             np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
+
+
+MARCH_CASES = [
+    # kind, cin, cout, dims, input split, (tz, mtw), x steps per workgroup
+    ("conv_fwd", 16, 16, (10, 128, 8), 0, (4, 8), 4),     # full-Y column (no halo rows at all), 3 x segments (4 + 4 + 2 steps)
+    ("conv_fwd", 16, 16, (6, 128, 8), 0, (4, 4), 6),      # two 64-row blocks: rows 63 / 64 are each other's halo
+    ("conv_dgrad", 32, 16, (5, 64, 8), 0, (4, 4), 5),     # K = 16, N = 32 (two channel tiles), one segment
+    ("conv_fwd", 32, 16, (7, 128, 4), 16, (2, 4), 3),     # level-0 concat read as a two-part tensor, TZ 2
+    ("conv_fwd", 32, 2, (4, 128, 4), 0, (2, 4), 4),       # 2-channel fp32 output (logits)
+    ("conv_fwd", 16, 32, (6, 64, 16), 0, (8, 8), 6),      # TZ 8: two rows per M-tile
+    ("conv_fwd", 32, 32, (9, 64, 8), 0, (4, 4), 4),
+    ("conv_dgrad", 64, 32, (6, 64, 8), 0, (4, 2), 6),     # K = 32, N = 64 (four channel tiles), 32-row blocks
+    ("conv_fwd", 64, 32, (6, 32, 4), 32, (2, 1), 6),      # level-1 concat, 64 input channels
+    ("conv_fwd", 64, 32, (5, 64, 4), 32, (2, 2), 2),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,dims,split,shape,lx", MARCH_CASES)
+def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, shape, lx):
+    """depth -5 selects the marching streaming kernel (csrc/mconv.hip: a workgroup walks along x with a ring of planes in LDS, every input
+    voxel fetched once).  Same packed weights, K order and fp32 accumulation as the general kernel: outputs must be IDENTICAL bit for bit in
+    every epilogue mode, across x segments, row blocks and the image borders."""
+    lib = L.lib()
+    dt, k = "bf16", (3, 3, 1)
+    torch.manual_seed(9)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, dt)
+    b = torch.randn(cout)
+    xd = x.double().requires_grad_(True)
+    y = F.conv3d(xd, w.double(), b.double(), padding=P.same_pad(k))
+    if kind == "conv_fwd":
+        inp_cl, want, nout, bias = H.to_cl(x, H.DT[dt], cpad=P.round_up(cin, 8)), y.detach(), cout, b.cuda()
+    else:
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        inp_cl, want, nout, bias = H.to_cl(gy, H.DT[dt], cpad=P.round_up(cout, 8)), xd.grad, cin, None
+    cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
+    kc = inp_cl.shape[-1]
+    gen = P.plan_igemm(kind, tuple(w.shape), cls, dims, 2, kc_pad=kc, in_split=split, aux_es=2)
+    gen.pack_map = P.pack_map(gen, tuple(w.shape))
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    tz, mtw = shape
+    mp = [pl for pl in P.march_plans(kind, tuple(w.shape), cls, dims, 2, kc, nreal, kreal, n=2) if (pl.tile[2], pl.mtw) == (tz, mtw)]
+    assert mp, "no marching plan for this shape"
+    mp = dataclasses.replace(mp[0], tile=(lx, mp[0].tile[1], tz))
+    mp.pack_map = P.pack_map(mp, tuple(w.shape))
+    parts = H._split_cl(inp_cl, split) if split else None
+    odt = torch.float32 if nout == 2 else H.DT[dt]
+    res_t = H.to_cl(_round(torch.randn(2, nout, *dims), dt), H.DT[dt])
+    gate_t = torch.rand(2, *dims, device="cuda")
+    alpha = torch.tensor([0.25], device="cuda")
+    modes = ["plain", "stats", "prelu"] + (["accumulate", "res_add", "relu_mask", "gate"] if nout % 4 == 0 else [])
+    for mode in modes:
+        outs = []
+        for pl in (gen, mp):
+            out = torch.zeros(2, *dims, nout, dtype=odt, device="cuda")
+            kw, stats = {}, None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "prelu":
+                kw = dict(act=L.ACT_PRELU, alpha=alpha.data_ptr())
+            elif mode == "accumulate":
+                out = res_t.clone()
+                kw = dict(accumulate=1)
+            elif mode in ("res_add", "relu_mask", "gate"):
+                kw = dict(res=H.tdesc(res_t), res_mode={"res_add": L.RES_ADD, "relu_mask": L.RES_RELUMASK, "gate": L.RES_GATE}[mode])
+                if mode == "gate":
+                    kw["gate"] = gate_t.data_ptr()
+            if bias is not None:
+                kw["bias"] = bias.data_ptr()
+            wp = H.pack(pl, w, inp_cl.dtype)
+            d = H.igemm_desc(pl, wp, H.two_part(*parts) if parts else H.tdesc(inp_cl), H.tdesc(out), **kw)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm D={pl.depth} {mode}")
+            torch.cuda.synchronize()
+            outs.append((out, stats))
+        (og, sg), (om, sm) = outs
+        assert torch.equal(og, om), f"{mode}: marching kernel differs from the general kernel (max {float((og.float() - om.float()).abs().max())})"
+        if mode == "plain":
+            np.testing.assert_allclose(H.from_cl(om).numpy(), want.float().numpy(), atol=_tol(dt, want))
+        if mode == "stats":
+            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), sm.view(L.STAT_SHARDS, 2, -1).sum(0)
+            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
 COMPUTE_CASES = [

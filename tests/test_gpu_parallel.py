@@ -119,3 +119,122 @@ def test_two_rank_data_parallel_step_and_sharded_inference(tmp_path):
         want_swi = V.sliding_window_inference(vol, ROI, 1, lambda t: m(t)[0], overlap=0.5, mode="gaussian").cpu()
     assert torch.equal(res[0]["swi"], res[1]["swi"])
     assert torch.equal(res[0]["swi"], want_swi)
+
+
+# ---- the RCCL ("nccl") branch itself, on one GPU: a world-size-1 process group with VSSEG_FORCE_COLLECTIVES=1 ------------------------
+def _rccl_worker(out_path, dtype):
+    """One process, one GPU.  First the non-distributed results, then the same step / inference with a world-size-1 `nccl` process
+    group whose collectives are really issued (parallel._collectives_on): init_process_group("nccl", device_id=...), the RCCL
+    all-reduce of the flat gradient on the device buffer ordered after the side-stream weight gradients, the RCCL broadcast of
+    parameters / buffers, and the RCCL all-gather of window logits and Dice scalars."""
+    os.environ.update(VSSEG_AUTOTUNE="0", VSSEG_NO_POISON="1", VSSEG_OVERLAP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VSSEG_DIST_BACKEND", "VSSEG_SHARE_DEVICE", "VSSEG_FORCE_COLLECTIVES"):
+        os.environ.pop(k, None)
+    import torch.distributed as dist
+
+    from vs_seg_amd import parallel as DP
+
+    def run():
+        torch.manual_seed(77)
+        m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, channels=HP["channels"], strides=HP["strides"], kernel_sizes=HP["kernel_sizes"], sample_kernel_sizes=HP["sample_kernel_sizes"],
+                            num_res_units=2, norm="batch", dropout=0.0, attention_module=True, compute_dtype=dtype)
+        m.load_state_dict(O.seeded_state_dict(True, SEED))
+        m = m.to("cuda")
+        loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True)
+        trainer = DP.DataParallelTrainer(m.train(), loss_fn, V.Adam(m.parameters(), lr=1e-3, weight_decay=1e-7))
+        x, y = _batch(0)
+        losses = [float(trainer.step(x, y))]
+        flat, gflat = m.flat_parameters()
+        g1 = gflat.cpu().clone()  # the (all-reduced) gradient of the first step: same parameters in every run
+        losses += [float(trainer.step(x, y)) for _ in range(2)]  # 3 steps: the third one replays the captured forward graph
+        out = dict(losses=losses, g=g1, p=flat.cpu().clone())
+        DP.broadcast_buffers(m)
+        m.eval()
+        vol = synth_input(SEED + 5, VOL).cuda()
+        with torch.no_grad():
+            swi = DP.sharded_sliding_window_inference(vol, ROI, lambda t: m(t)[0], overlap=0.5, mode="gaussian")
+            out["swi"] = swi.cpu().clone()
+            lab = torch.zeros(VOL, device="cuda")
+            lab[..., 30:60, 20:50, 5:15] = 1.0
+            d = float(V.compute_dice_score(swi, lab).reshape(()))
+        out["dice"] = DP.all_gather_scalars([d], 1, device="cuda" if DP._collectives_on() else "cpu")
+        out["mean"] = float(DP.allreduce_scalar_mean(torch.tensor([d], device="cuda")))
+        return out
+
+    plain = run()
+    plain2 = run()  # run-to-run noise of the atomics' summation order (bf16 amplifies it): the yardstick for the comparison below
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), VSSEG_FORCE_COLLECTIVES="1")
+    r, w, local = DP.init_distributed()
+    assert (r, w, local) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == "nccl" and DP._collectives_on()
+    forced = run()
+    dist.destroy_process_group()
+    torch.save(dict(plain=plain, plain2=plain2, forced=forced), out_path)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_rccl_branch_world_size_one_matches_the_non_distributed_run(tmp_path, dtype):
+    ctx = mp.get_context("spawn")
+    out = os.path.join(str(tmp_path), "rccl.pt")
+    p = ctx.Process(target=_rccl_worker, args=(out, dtype))
+    p.start()
+    p.join(900)
+    assert p.exitcode == 0, p.exitcode
+    res = torch.load(out)
+    a, a2, b = res["plain"], res["plain2"], res["forced"]
+    # the collectives are identities at world size 1: what can differ is only the summation order of the fp32 atomics from run to run, which
+    # two non-distributed runs differ by as well — that run-to-run difference is the yardstick (a race between the side-stream weight
+    # gradients and the all-reduce would show as an O(1) difference)
+    noise = float((a["g"] - a2["g"]).norm() / a["g"].norm())
+    rel = float((a["g"] - b["g"]).norm() / a["g"].norm())
+    assert rel <= max(3.0 * noise, 1e-2 if dtype == "bf16" else 1e-4), (rel, noise)
+    assert abs(a["losses"][0] - b["losses"][0]) < (2e-3 if dtype == "bf16" else 1e-5), (a["losses"], b["losses"])
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert abs(la - lb) < (2e-2 if dtype == "bf16" else 1e-4), (a["losses"], b["losses"])
+    relp = float((a["p"] - b["p"]).norm() / a["p"].norm())
+    assert relp < 2e-3, relp  # 3 Adam steps of lr 1e-3 on parameters of O(0.1 .. 1)
+    # eval forward + blend are deterministic given the parameters: compare each run with its own parameters' result only through the Dice
+    assert a["swi"].shape == b["swi"].shape and torch.isfinite(b["swi"]).all()
+    assert len(b["dice"]) == 1 and abs(b["dice"][0] - b["mean"]) < 1e-6 and abs(a["dice"][0] - b["dice"][0]) < 5e-2
+
+
+# ---- BASELINE config 5's harness (bench.py --swi-cases) at 6 cases, Dice scalars gathered through RCCL --------------------------------
+def _c5_worker(out_path):
+    os.environ.update(VSSEG_NO_POISON="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), VSSEG_FORCE_COLLECTIVES="1", VSSEG_AUTOTUNE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VSSEG_DIST_BACKEND", "VSSEG_SHARE_DEVICE"):
+        os.environ.pop(k, None)
+    import bench
+    from vs_seg_amd import parallel as DP
+
+    rank, world, local = DP.init_distributed()
+    dev = torch.device("cuda", local)
+    model = bench.build_model("bf16", dev).eval()
+    block = bench.sharded_cases(model, 6, rank, world, dev, torch.cuda.synchronize)
+    # the same case computed directly, no collective anywhere
+    vol = torch.from_numpy(np.random.default_rng(100).standard_normal((1, 1, 448, 448, 80), dtype=np.float32)).to(dev)
+    lab = torch.zeros((1, 1, 448, 448, 80), device=dev)
+    lab[..., 200:260, 210:250, 30:50] = 1.0
+    with torch.no_grad():
+        out = V.sliding_window_inference(vol, bench.PATCH, 1, lambda w: model(w)[0], overlap=0.5, mode="gaussian")
+        direct = float(V.compute_dice_score(out, lab).reshape(()))
+    torch.distributed.destroy_process_group()
+    torch.save(dict(block=block, direct=direct, shape=tuple(out.shape)), out_path)
+
+
+def test_config5_harness_six_cases_through_rccl(tmp_path):
+    """bench.py's `sharded_cases` block (BASELINE config 5: T2-shaped cases sharded by shard_indices, hard Dice per case, scores all-gathered inside
+    the timed region) at 6 cases of 448x448x80 = 12 windows each, with the gather going through a world-size-1 RCCL group."""
+    ctx = mp.get_context("spawn")
+    out = os.path.join(str(tmp_path), "c5.pt")
+    p = ctx.Process(target=_c5_worker, args=(out,))
+    p.start()
+    p.join(900)
+    assert p.exitcode == 0, p.exitcode
+    res = torch.load(out)
+    b = res["block"]
+    assert b["cases"] == 6 and b["windows"] == 12 and len(b["scores"]) == 6 and b["volumes_per_sec"] > 0
+    assert res["shape"] == (1, 2, 448, 448, 80)
+    s = b["scores"]
+    assert all(np.isfinite(v) and 0.0 <= v <= 1.0 for v in s)
+    assert s[0] == s[4] and s[1] == s[5]  # cases 0 / 4 and 1 / 5 are the same volume: eval forward + blend are deterministic
+    assert abs(s[0] - res["direct"]) < 1e-6
+    assert abs(b["mean_dice"] - float(np.mean(s))) < 1e-6

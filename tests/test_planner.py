@@ -175,3 +175,32 @@ def test_z_folded_plans_compute_the_same_convolution(cin, cout, kind):
         ident = dataclasses.replace(pl)  # simulate_igemm gathers the weights through pack_map itself
         got = P.simulate_igemm(ident, src_f, w.numpy().reshape(-1), (8, 8, 2))
         np.testing.assert_allclose(got.reshape(2, *dims, cd), _cl(want), atol=1e-9, err_msg=f"tile={pl.tile} ck={pl.ck} ns={pl.nsplit}")
+
+
+def test_marching_kernel_lds_layout_is_bank_conflict_free():
+    """csrc/mconv.hip's plane layout [row][piece'][z]: every 16-lane service group of every operand ds_read_b128 hits 16 distinct 16-byte slots."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("lds_conflicts", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "lds_conflicts.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for cin, tz in sorted({(c, z) for (c, _, z, _) in P.MARCH_SHAPES}):
+        extra, base = mod.extra_cycles(cin, tz)
+        assert extra == 0, (cin, tz, extra, base)
+
+
+def test_march_plans_cover_the_benchmark_layers_and_mirror_the_kernel_lds():
+    cls = P.lattice_classes("conv_fwd", (3, 3, 1), (1, 1, 1))[0]
+    for cin, cout, dims in [(16, 16, (384, 128, 128)), (32, 16, (384, 128, 128)), (16, 32, (192, 64, 128)), (32, 32, (192, 64, 128)), (64, 32, (192, 64, 128))]:
+        pls = P.march_plans("conv_fwd", (cout, cin, 3, 3, 1), cls, dims, 2, cin, cout, cin, n=4)
+        assert pls, (cin, cout)
+        for pl in pls:
+            lx, tyb, tz = pl.tile
+            assert pl.depth == -5 and tyb == 64 * pl.mtw // tz and dims[1] % tyb == 0 and dims[2] % tz == 0 and 1 <= lx <= dims[0]
+            g = cin // 8
+            assert pl.lds == ((9 * g + 3) // 4) * pl.nt * 1024 + 4 * (tyb + 2) * tz * g * 16 + 5 * pl.nt * 16 * 4 + 16 <= 160 * 1024
+            assert pl.ksteps == (9 * g + 3) // 4 and pl.nchunks == 1 and pl.ck == cin
+    # outside the domain: strided, 3x3x3, fp32
+    assert P.march_plans("conv_fwd", (16, 16, 3, 3, 1), P.lattice_classes("conv_fwd", (3, 3, 1), (2, 2, 1))[0], (192, 64, 128), 2, 16, 16, 16) == []
+    assert P.march_plans("conv_fwd", (16, 16, 3, 3, 1), cls, (384, 128, 128), 4, 16, 16, 16) == []

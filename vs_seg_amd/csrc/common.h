@@ -162,11 +162,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // after the NEXT stage's DMAs were issued, which serialised "issue stage s+1, wait for it, multiply stage s" (seen in the ISA of
 // igemm_kernel<bf16,2,4,0>; the measured ring depths 1..3 were all equal for that reason).  The kernels order DMA against LDS reads
 // themselves (counted `s_waitcnt vmcnt(N)` + s_barrier), so nothing is lost by hiding the instruction from the compiler's scoreboard.
-// M0 is written here and by nothing else in these kernels (the ISA was checked: hipcc only touches M0 for its own LDS-DMA builtins).
+// M0 is declared clobbered: hipcc must not keep a live value in it across the DMA (s_set_gpr_idx / v_movrel / its own LDS-DMA builtins use M0).
 typedef __attribute__((address_space(3))) const void vsseg_lds_cvoid_t;
 __device__ __forceinline__ void vsseg_dma16(const void* gsrc, const void* lds_wave_base) {
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(vsseg_lds_cvoid_t*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory", "m0");
 }
 
 static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }

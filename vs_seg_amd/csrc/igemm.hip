@@ -3,6 +3,7 @@
 #include "igemm_kernel.h"
 #include "sconv.h"
 #include "cconv.h"
+#include "mconv.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
@@ -172,6 +173,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
 extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && (d->depth == -2 || d->depth == -4)) return vsseg_sconv_lds_bytes(d);
   if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
+  if (d && d->depth == -5) return vsseg_mconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
@@ -188,6 +190,12 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_cconv_launch(d, z, as_stream(stream));
+  }
+  if (d && d->depth == -5) {  // marching streaming kernel (mconv.hip): same contract
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_mconv_launch(d, z, as_stream(stream));
   }
   IgemmK k;
   int lds = igemm_prepare(d, k);

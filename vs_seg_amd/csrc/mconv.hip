@@ -1,0 +1,403 @@
+// Marching streaming convolution (launch plans with depth -5): the HBM-bound stride-1 3x3x1 bf16 convolutions and data gradients of the two
+// finest levels of the 2.5D U-Net (ref:params/networks/blocks/convolutions.py:114-146; the 16/32/64-channel layers at 384x128x128 and
+// 192x64x128, SURVEY §8a rows 2, 5, 6, 41, 44, 46, 49 and their data gradients) with every input voxel fetched from HBM exactly once.
+//
+// The tile kernel (sconv.hip) fetches a (8+2)x(8+2)x4 halo per 8x8x4 output tile: 1.56x the input bytes, and the PMC counters show the
+// overlap is NOT served by L2 (profiles/r02_pmc_hbm.txt: 1.28x the algorithmic bytes on the 16->16 layers = exactly in*1.56 + out).  Here a
+// workgroup owns a column (sample n, rows [y0, y0+TYB), slices [z0, z0+TZ)) and MARCHES along x: a plane = one x position of the column
+// ((TYB+2) rows x TZ voxels x CIN channels, <= 17 KB) is DMA'd into a ring of four LDS slots, the 3x3x1 stencil of plane x reads the slots
+// of x-1, x, x+1 while the DMA of plane x+2 is in flight (issued one whole step ahead: the load latency is hidden inside the workgroup, not
+// only by the neighbours on the CU).  With TYB = Y (the benchmark shapes) there is no halo at all: rows -1 and Y are the convolution's zero
+// padding and are never fetched; x segments re-fetch 2 planes per `lx` steps (2-4 %).  A 3x3x1 stencil has no z halo, so TZ is free: it is
+// chosen so that a plane row (TZ voxels) is a 128- or 256-byte run in HBM.
+//
+//   * LDS plane layout [row][piece'][z] (16-byte pieces of 8 channels, piece' = (piece + 2 * (row * RS / 16)) mod G, RS = TZ*G slots per
+//     row): the 16-lane groups in which the LDS serves a ds_read_b128 hit 16 different slots of a 256-byte bank row for every tap
+//     (tools/lds_conflicts.py checks it exhaustively: 0 conflict cycles for 16/32/64 channels); the permutation is free — the DMA writes LDS in
+//     lane order, so it is applied to the GLOBAL address each lane fetches, and each run of RS lanes still reads one contiguous 128/256-byte
+//     row segment
+//   * same packed weights, K order (tap, 8-channel group), MFMA operand order, output-channel ownership and epilogue semantics as the
+//     general kernel and sconv.hip: results agree bit for bit
+//   * the auxiliary operand of an accumulating / residual / gated launch is loaded one step ahead into registers, in FRONT of the next
+//     plane's DMAs (loads return in order: behind them it would wait for the whole plane)
+#include "common.h"
+#include "mconv.h"
+#include <type_traits>
+
+constexpr int MC_NR = 4;  // ring slots: planes x-1, x, x+1 + the one in flight
+
+struct MconvK {
+  const char* in0;  // channels [0, csplit) ...
+  const char* in1;  // ... and [csplit, c), biased by -csplit channels (== in0 for an ordinary tensor)
+  char* out0; char* out1;
+  const char* aux0; const char* aux1;
+  const float* gate;
+  const char* wpack;
+  const float *bias, *bias2, *scale, *shift, *alpha;
+  double* stats;
+  const void* zeros;
+  int in_csplit_pc;  // first 16-byte piece of a voxel row that lives in part 1
+  int in_vox_bytes, out_vox_bytes, aux_vox_bytes;
+  int out_csplit, aux_csplit;
+  int out_f32, aux_mode, act, cout, cout_mod, stats_stride;
+  int X, Y, Z;
+  int lx, nxs, nyb, nzb;  // x steps per workgroup; segments in x, blocks in y and z
+};
+
+// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16)
+template <int CIN, int NT, int TZ, int MT, int MODE>
+__global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
+  constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
+  constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
+  constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = PLANE_SLOTS * 16, NINST = (PLANE_SLOTS + 255) / 256;
+  constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = KSTEPS * NT * 1024;
+  constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
+  static_assert(PLANE_BYTES % 256 == 0, "ring slots must start on a 256-byte bank row");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wl = smem;
+  char* Rl = smem + W_BYTES;
+  float* epi = reinterpret_cast<float*>(smem + W_BYTES + MC_NR * PLANE_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
+  const int X = k.X, Y = k.Y, Z = k.Z, cout = k.cout;
+
+  // ---- workgroup -> column segment
+  int b = blockIdx.x;
+  const int zb = b % k.nzb; b /= k.nzb;
+  const int yb = b % k.nyb; b /= k.nyb;
+  const int xs = b % k.nxs; const int n = b / k.nxs;
+  const int y0 = yb * TYB, z0 = zb * TZ, xb = xs * k.lx, steps = min(k.lx, X - xb);
+
+  for (int i = tid; i < W_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Wl)[i] = reinterpret_cast<const uint4*>(k.wpack)[i];
+  for (int i = tid; i < MC_NR * PLANE_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Rl)[i] = make_uint4(0u, 0u, 0u, 0u);  // rows outside the image stay zero: they are never fetched
+  for (int i = tid; i < NT * 16; i += 256) {
+    const bool ok = i < cout;
+    const int cv = k.cout_mod > 0 ? i % k.cout_mod : i;
+    epi[i] = ((ok && k.bias) ? k.bias[cv] : 0.f) + ((ok && k.bias2) ? k.bias2[cv] : 0.f);
+    epi[NT * 16 + i] = (ok && k.scale) ? k.scale[cv] : 1.f;
+    epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[cv] : 0.f;
+  }
+  const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
+
+  // ---- this thread's DMA pieces: LDS slot j = (u*4 + wave)*64 + lane of a plane holds (row j / RS, piece' (j % RS) / TZ, z j % TZ)
+  int rel[NINST];
+  unsigned okmask = 0, p1mask = 0;
+#pragma unroll
+  for (int u = 0; u < NINST; ++u) {
+    const int j = (u * 4 + wave) * 64 + lane;
+    const int r = j / RS, within = j % RS, pp = within / TZ, z = within % TZ;
+    const int pc = (pp - 2 * (r * RS / 16)) & (G - 1);
+    const int gy = y0 + r - 1;
+    const bool ok = j < PLANE_SLOTS && (unsigned)gy < (unsigned)Y;
+    rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + pc * 16 : 0;
+    if (ok) okmask |= 1u << u;
+    if (ok && pc >= k.in_csplit_pc) p1mask |= 1u << u;
+  }
+  const int64_t plane_stride = (int64_t)Y * Z * k.in_vox_bytes;
+  const int64_t col0 = (((int64_t)n * X) * Y + y0) * Z + z0;  // voxel (n, 0, y0, z0)
+  const char* org0 = k.in0 + col0 * k.in_vox_bytes;
+  const char* org1 = k.in1 + col0 * k.in_vox_bytes;
+  auto issue = [&](int i) {  // DMA plane i (x = xb - 1 + i) into ring slot i & 3; planes outside the image are zero
+    const int x = xb - 1 + i;
+    char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES;
+    const bool inside = (unsigned)x < (unsigned)X;
+    const char* p0 = org0 + (int64_t)x * plane_stride;
+    const char* p1 = org1 + (int64_t)x * plane_stride;
+#pragma unroll
+    for (int u = 0; u < NINST; ++u)
+      if ((okmask >> u) & 1u) vsseg_dma16(inside ? (const void*)(((p1mask >> u) & 1u ? p1 : p0) + rel[u]) : k.zeros, dst + (u * 4 + wave) * 1024);
+  };
+
+  // ---- MFMA operand addressing: K-group p = ks*4 + g -> (tap p / G, piece p % G); lane column l15 -> voxel (row l15 / TZ, z l15 % TZ) of the M-tile
+  const int rr = l15 / TZ, zz = l15 % TZ;
+  int koff[KSTEPS], dxk[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    int p = ks * 4 + g;
+    if (p >= 9 * G) p -= 9 * G;  // padded K-groups: zero weights times a genuine tap of the same voxel (conflict-free like the real ones)
+    const int tap = p / G, pc = p % G, dy = tap % 3 - 1;
+    const int row = 1 + rr + dy;  // + the M-tile's first row (a multiple of RPM: it does not change the swizzle term)
+    koff[ks] = (row * RS + ((pc + 2 * (row * RS / 16)) & (G - 1)) * TZ + zz) * 16 + wave * (MT * MT_BYTES);
+    dxk[ks] = tap / 3;
+  }
+  const unsigned out_es = k.out_f32 ? 4u : 2u;
+  const bool vec_store = (cout & 3) == 0;
+  const bool simple = vec_store && !k.out_f32 && !k.scale && (k.act == VSSEG_ACT_NONE || k.act == VSSEG_ACT_PRELU);
+  const int ekind = !simple ? 2 : (k.aux_mode == 3 ? 1 : 0);
+  const float alpha_eff = k.act == VSSEG_ACT_PRELU ? alpha : 1.f;
+  const char* Wlane = Wl + lane * 16;
+  float ssum[STATS ? NT : 1][4], ssq[STATS ? NT : 1][4];
+#pragma unroll
+  for (int t = 0; t < (STATS ? NT : 1); ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
+
+  // output voxel of M-tile m (this lane's column) at x: ((n*X + x)*Y + y0 + (wave*MT + m)*RPM + rr)*Z + z0 + zz
+  const int64_t ocol = col0 + (int64_t)((wave * MT) * RPM + rr) * Z + zz;
+  const int64_t oplane = (int64_t)Y * Z;
+  auto out_ch = [&](int t) -> int { return t * 16 + g * 4; };
+
+  uint2 auxv[AUXM ? MT : 1][AUXM ? NT : 1], auxn[AUXM ? MT : 1][AUXM ? NT : 1];
+  float gatev[AUXM ? MT : 1], gaten[AUXM ? MT : 1];
+  auto load_aux = [&](int i, uint2 (&av)[AUXM ? MT : 1][AUXM ? NT : 1], float (&gv)[AUXM ? MT : 1]) {
+    if constexpr (AUXM) {
+      const int64_t vox0 = ocol + (int64_t)(xb - 1 + i) * oplane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int64_t vox = vox0 + (int64_t)m * RPM * Z;
+        gv[m] = k.aux_mode == 4 ? k.gate[vox] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = t * 16 + g * 4;
+          const char* ap = (t * 16 >= k.aux_csplit ? k.aux1 : k.aux0) + vox * k.aux_vox_bytes + c * 2;
+          av[m][t] = c < cout ? *reinterpret_cast<const uint2*>(ap) : make_uint2(0u, 0u);
+        }
+      }
+    }
+  };
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // the ring is zeroed before any DMA writes it
+  load_aux(1, auxv, gatev);
+  issue(0);
+  issue(1);
+  issue(2);
+
+  for (int i = 1; i <= steps; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of plane i+1 have landed (and the previous step's stores have left)
+    __builtin_amdgcn_s_barrier();                        // ... everybody's; and every wave has finished reading plane i-2
+    if (i < steps) load_aux(i + 1, auxn, gaten);         // next step's auxiliary operand, in front of the DMAs
+    if (i + 2 <= steps + 1) issue(i + 2);
+    const int sm1 = ((i - 1) & (MC_NR - 1)) * PLANE_BYTES, s0 = (i & (MC_NR - 1)) * PLANE_BYTES, sp1 = ((i + 1) & (MC_NR - 1)) * PLANE_BYTES;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      bf16x8 w[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (ks * NT + t) * 1024);
+      const char* hb = Rl + koff[ks] + (dxk[ks] == 0 ? sm1 : (dxk[ks] == 1 ? s0 : sp1));
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(hb + m * MT_BYTES);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t], av, acc[m][t], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue (sconv.hip's, on the marching voxel mapping): bias (+ statistics) (+ eval affine) + activation (+ auxiliary operand)
+    const int64_t ovox0 = ocol + (int64_t)(xb - 1 + i) * oplane;
+    auto epilogue = [&](auto kind_c) {
+      constexpr int KIND = decltype(kind_c)::value;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int64_t ovox = ovox0 + (int64_t)m * RPM * Z;
+        float gt = 1.f;
+        if constexpr (AUXM) gt = k.aux_mode == 4 ? 1.f + gatev[m] : 1.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int c = t * 16 + g * 4;
+          if (c >= cout) continue;
+          const float4 bi = *reinterpret_cast<const float4*>(epi + c);
+          float val[4] = {acc[m][t][0] + bi.x, acc[m][t][1] + bi.y, acc[m][t][2] + bi.z, acc[m][t][3] + bi.w};
+          if constexpr (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { ssum[t][r] += val[r]; ssq[t][r] += val[r] * val[r]; }
+          }
+          if constexpr (KIND == 2) {
+            if (k.scale) {
+              const float4 sc = *reinterpret_cast<const float4*>(epi + NT * 16 + c), sh = *reinterpret_cast<const float4*>(epi + 2 * NT * 16 + c);
+              val[0] = val[0] * sc.x + sh.x; val[1] = val[1] * sc.y + sh.y; val[2] = val[2] * sc.z + sh.z; val[3] = val[3] * sc.w + sh.w;
+            }
+            if (k.act == VSSEG_ACT_PRELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[r] = val[r] > 0.f ? val[r] : alpha * val[r];
+            } else if (k.act == VSSEG_ACT_RELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[r] = fmaxf(val[r], 0.f);
+            } else if (k.act == VSSEG_ACT_SIGMOID) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[r] = 1.f / (1.f + __expf(-val[r]));
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[r] = val[r] > 0.f ? val[r] : alpha_eff * val[r];
+          }
+          if constexpr (AUXM) {
+            const uint2 a = auxv[m][t];
+            const float4 av = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u));
+            if (KIND == 1 || (KIND == 2 && k.aux_mode == 3)) {
+              val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
+            } else if (KIND == 2 && k.aux_mode != 4) {
+              val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
+            } else {
+              val[0] += av.x * gt; val[1] += av.y * gt; val[2] += av.z * gt; val[3] += av.w * gt;
+            }
+          }
+          char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + ovox * k.out_vox_bytes + out_ch(t) * (int)out_es;
+          if constexpr (KIND != 2) {
+            st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
+          } else if (vec_store) {
+            if (k.out_f32) st4(reinterpret_cast<float*>(op), make_float4(val[0], val[1], val[2], val[3]));
+            else st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
+          } else {  // 1- and 2-channel outputs (attention map, logits)
+            const int nc = min(4, cout - c);
+            for (int r = 0; r < nc; ++r) {
+              if (k.out_f32) reinterpret_cast<float*>(op)[r] = val[r];
+              else reinterpret_cast<bf16_t*>(op)[r] = f2bf(val[r]);
+            }
+          }
+        }
+      }
+    };
+    if (ekind == 0) epilogue(std::integral_constant<int, 0>{});
+    else if (AUXM && ekind == 1) epilogue(std::integral_constant<int, AUXM ? 1 : 0>{});
+    else epilogue(std::integral_constant<int, 2>{});
+    if constexpr (AUXM) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        gatev[m] = gaten[m];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) auxv[m][t] = auxn[m][t];
+      }
+    }
+  }
+
+  if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's voxels: shuffle tree -> LDS -> sharded fp64 atomics (layout of vsseg_igemm_desc.stats)
+    __syncthreads();
+    float* red = epi;
+    for (int i = tid; i < 2 * NT * 16; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = ssum[t][r], q = ssq[t][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (l15 == 0) {
+          atomicAdd(&red[t * 16 + g * 4 + r], s);
+          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
+        }
+      }
+    __syncthreads();
+    double* st = k.stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * k.stats_stride;
+    for (int i = tid; i < 2 * NT * 16; i += 256) {
+      const int which = i / (NT * 16), c = i - which * NT * 16;
+      if (c < cout) atomicAdd(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)red[i]);
+    }
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+template <int CIN, int NT, int TZ, int MT> static int mc_lds() {
+  constexpr int G = CIN / 8, RS = TZ * G, RPM = 16 / TZ, ROWS = MT * 4 * RPM + 2, KSTEPS = (9 * G + 3) / 4;
+  return KSTEPS * NT * 1024 + MC_NR * ROWS * RS * 16 + 5 * NT * 16 * 4 + 16;
+}
+template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_mode(const MconvK& k, int grid, hipStream_t s) {
+  static bool init = false;
+  const int lds = mc_lds<CIN, NT, TZ, MT>();
+  if (!init) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    init = true;
+  }
+  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_igemm (marching)");
+  return VSSEG_OK;
+}
+template <int CIN, int NT, int TZ, int MT> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
+  if (k.stats) return mc_launch_mode<CIN, NT, TZ, MT, 1>(k, grid, s);
+  if (k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 2>(k, grid, s);
+  return mc_launch_mode<CIN, NT, TZ, MT, 0>(k, grid, s);
+}
+
+typedef int (*mc_fn_t)(const MconvK&, int, hipStream_t);
+struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); };
+#define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M>, mc_lds<C, N, Z, M>}
+// (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
+static const McEntry mc_table[] = {
+    MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
+    MC_E(32, 1, 2, 4), MC_E(32, 1, 4, 4), MC_E(32, 1, 2, 2), MC_E(32, 2, 4, 4), MC_E(32, 2, 2, 4), MC_E(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_E(32, 4, 2, 2), MC_E(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
+    MC_E(64, 2, 2, 2), MC_E(64, 2, 2, 1), MC_E(64, 1, 2, 2), MC_E(64, 1, 2, 1)};                                                   // 64 -> 32 / 16
+
+static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
+  *why = nullptr;
+  auto no = [&](const char* w) { *why = w; return (const McEntry*)nullptr; };
+  if (d->in.dtype != VSSEG_BF16) return no("input is not bf16");
+  if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 9) return no("needs nchunks = nsplit = 1 and the 9 taps of a 3x3x1 stencil");
+  for (int a = 0; a < 3; ++a)
+    if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
+  if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || d->q[0] != d->out.x || d->q[1] != d->out.y || d->q[2] != d->out.z) return no("lattice, input and output extents differ");
+  for (int t = 0; t < 9; ++t)
+    if (d->tap_off[t][0] != t / 3 - 1 || d->tap_off[t][1] != t % 3 - 1 || d->tap_off[t][2] != 0) return no("taps are not the 3x3x1 stencil in (x, y) order");
+  const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
+  if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
+  if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
+  if (d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15)) return no("input must be one channel chunk of 16-byte aligned voxel rows");
+  if (d->ksteps != (9 * (d->ck / 8) + 3) / 4) return no("ksteps");
+  if (d->out.c > d->nt * 16 || (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32)) return no("output channels / dtype");
+  if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
+  if (d->stats && (d->accumulate || d->res_mode != VSSEG_RES_NONE)) return no("statistics combined with a residual");
+  if (d->accumulate && d->res_mode != VSSEG_RES_NONE) return no("accumulate combined with a residual");
+  if (d->bnred) return no("no fused BatchNorm-backward reduction in the marching kernel");
+  if (d->accumulate || d->res_mode != VSSEG_RES_NONE) {
+    const vsseg_tensor& a = d->accumulate ? d->out : d->res;
+    if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");
+  }
+  for (const McEntry& e : mc_table)
+    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt) return &e;
+  return no("no instantiation for this (channels, nt, tz, mtw)");
+}
+
+int vsseg_mconv_lds_bytes(const vsseg_igemm_desc* d) {
+  const char* why;
+  const McEntry* e = mc_find(d, &why);
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  return e->lds();
+}
+
+int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t s) {
+  const char* why;
+  const McEntry* e = mc_find(d, &why);
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  MconvK k;
+  k.in0 = reinterpret_cast<const char*>(d->in.ptr);
+  k.in1 = d->in.ptr2 ? reinterpret_cast<const char*>(d->in.ptr2) - (int64_t)d->in.csplit * 2 : k.in0;
+  k.in_csplit_pc = d->in.ptr2 ? d->in.csplit / 8 : 1 << 20;
+  k.in_vox_bytes = d->in.pitch * 2;
+  const int oes = d->out.dtype == VSSEG_F32 ? 4 : 2;
+  k.out0 = reinterpret_cast<char*>(d->out.ptr);
+  k.out1 = d->out.ptr2 ? reinterpret_cast<char*>(d->out.ptr2) - (int64_t)d->out.csplit * oes : k.out0;
+  k.out_csplit = d->out.ptr2 ? d->out.csplit : 0x7fffffff;
+  k.out_vox_bytes = d->out.pitch * oes;
+  k.out_f32 = d->out.dtype == VSSEG_F32;
+  k.aux_mode = 0;
+  k.aux0 = k.aux1 = nullptr; k.aux_csplit = 0x7fffffff; k.aux_vox_bytes = 0;
+  if (d->accumulate) k.aux_mode = 1;
+  else if (d->res_mode == VSSEG_RES_ADD) k.aux_mode = 2;
+  else if (d->res_mode == VSSEG_RES_RELUMASK) k.aux_mode = 3;
+  else if (d->res_mode == VSSEG_RES_GATE) k.aux_mode = 4;
+  if (k.aux_mode) {
+    const vsseg_tensor& a = d->accumulate ? d->out : d->res;
+    k.aux0 = reinterpret_cast<const char*>(a.ptr);
+    k.aux1 = a.ptr2 ? reinterpret_cast<const char*>(a.ptr2) - (int64_t)a.csplit * 2 : k.aux0;
+    k.aux_csplit = a.ptr2 ? a.csplit : 0x7fffffff;
+    k.aux_vox_bytes = a.pitch * 2;
+  }
+  VSSEG_CHECK(k.aux_mode != 4 || d->gate, "vsseg_igemm: RES_GATE needs the gate map");
+  k.gate = d->gate;
+  k.wpack = reinterpret_cast<const char*>(d->wpack);
+  k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
+  k.stats = d->stats; k.stats_stride = d->stats_stride;
+  k.zeros = zeros;
+  k.act = d->act; k.cout = d->out.c; k.cout_mod = d->cout_mod;
+  k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
+  k.lx = d->tile[0] > k.X ? k.X : d->tile[0];
+  k.nxs = (k.X + k.lx - 1) / k.lx; k.nyb = k.Y / d->tile[1]; k.nzb = k.Z / d->tile[2];
+  const int64_t grid = (int64_t)d->in.n * k.nxs * k.nyb * k.nzb;
+  VSSEG_CHECK(grid > 0 && grid < (1ll << 30), "vsseg_igemm: bad marching grid");
+  return e->fn(k, (int)grid, s);
+}

@@ -138,15 +138,17 @@ class PatchSampler:
         return out[0], out[1]
 
 
-def epoch_batches(n: int, batch_size: int, shuffle: bool, rng: np.random.RandomState, rank: int = 0, world: int = 1) -> List[List[int]]:
+def epoch_batches(n: int, batch_size: int, shuffle: bool, rng: np.random.RandomState, rank: int = 0, world: int = 1, pad: bool = True) -> List[List[int]]:
     """Index batches of one epoch: DataLoader(shuffle=True) order (ref:params/VSparams.py:311-318), sharded over ranks
     (rank r takes positions r, r+world, … of the shuffled list — SURVEY §8e) and cut into batches (last one may be short).
 
-    Every rank gets the SAME number of indices, hence of batches: when n is not a multiple of `world` the list is padded by
-    wrapping around to its own beginning (torch's DistributedSampler(drop_last=False) rule).  Each training step issues a
-    gradient all-reduce and validation all-reduces its sums, so unequal step counts would pair mismatched collectives."""
+    `pad=True` (TRAINING loaders only): every rank gets the SAME number of indices, hence of batches — when n is not a multiple of
+    `world` the list is padded by wrapping around to its own beginning (torch's DistributedSampler(drop_last=False) rule), because each
+    training step issues a gradient all-reduce and unequal step counts would pair mismatched collectives.  Validation and test loaders
+    pass `pad=False`: they issue ONE collective after their loop, so ranks may run different numbers of cases, and a wrapped case would
+    be counted twice in the all-reduced Dice / loss sums (rank r then owns exactly `shard_indices(n, r, world)`)."""
     order = rng.permutation(n) if shuffle else np.arange(n)
-    if world > 1 and n % world and n > 0:
+    if pad and world > 1 and n % world and n > 0:
         pad = world - n % world
         order = np.concatenate([order, np.resize(order, pad)])
     mine = [int(i) for i in order[rank::world]]

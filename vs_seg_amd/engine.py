@@ -236,7 +236,7 @@ class Plan:
                     out.append(_Choice(cands, woff, wshape=tuple(Lr.wshape), fold=P.FOLD, cmod=P.gemm_dims(kind, Lr.wshape)[1]))
                     continue
                 if self.tune:
-                    cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)
+                    cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split, n=self.n)
                 else:
                     cands = [P.plan_igemm(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)]
                 out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0, wshape=tuple(Lr.wshape)))
@@ -423,11 +423,22 @@ class Plan:
             accumulate = 1  # metadata only: the launch reads one more output-sized tensor (the layer's pre-activation)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
-        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=(f"sconv<bf16,{pl.nt}>" if pl.depth in (-2, -4) else (f"cconv<bf16,{pl.nt}>" if pl.depth == -3 else f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>")), kind="mfma", flops=2.0 * nvalid * (2.25 if pl.depth == -4 else pl.ntaps) * pl.kreal * pl.nc / max(ch.fold, 1),
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma", flops=2.0 * nvalid * (2.25 if pl.depth == -4 else pl.ntaps) * pl.kreal * pl.nc / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
                     bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
+
+    @staticmethod
+    def _igemm_name(pl: P.IgemmPlan, inp: L.Tensor) -> str:
+        """Kernel group of a convolution launch in the profiles: which of the four kernels its plan runs on."""
+        if pl.depth in (-2, -4):
+            return f"sconv<bf16,{pl.nt}>"
+        if pl.depth == -3:
+            return f"cconv<bf16,{pl.nt}>"
+        if pl.depth == -5:
+            return f"mconv<bf16,{pl.nt}>"
+        return f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"
 
     def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:
         """Launch metadata of a streaming kernel: algorithmic bytes = (channels read + written per voxel, summed over its tensor
@@ -617,11 +628,11 @@ class Plan:
             if Lr.cin == 1 and Lr.cout in (8, 16, 32, 64) and x.root.name == prog.input.name and dy.c == Lr.cout and not dy.ptr2:
                 x1 = self._xdesc(x, True)  # the compact one-channel copy of the network input
                 B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
-                          dict(name="wgrad_narrow", kind="hbm", side=Lr.level >= eng.overlap_min_level, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
+                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
                 return True
             if Lr.cout == 1 and Lr.cin in (8, 16, 32, 64) and dy_compact is not None and x.parts is None and x.base is None:
                 B.append([lib.vsseg_wgrad_narrow, [self._desc(x), dy_compact.ptr, k3, -1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
-                          dict(name="wgrad_narrow", kind="hbm", side=Lr.level >= eng.overlap_min_level, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
+                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
                 return True
             return False
 
@@ -703,7 +714,7 @@ class Plan:
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=Lr.level >= eng.overlap_min_level, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -949,7 +960,8 @@ class Engine:
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched
         # eagerly: replayed as ONE hipGraph the two branches ran no faster than serially (measured 37.6 ms)
         self.overlap = os.environ.get("VSSEG_OVERLAP", "1") == "1" and not dry_run
-        self.overlap_min_level = int(os.environ.get("VSSEG_OVERLAP_MIN_LEVEL", "0"))  # finest level whose weight gradients go to the side stream (measured: 0 = all of them is best, 37.0 / 37.1 / 37.6 / 37.9 ms for 0 / 1 / 2 / 3)
+        # (ALL weight gradients go to the side stream: they share one partial-sum scratch and must serialise on one stream; keeping the finest
+        # levels on the main stream measured slower anyway, 37.0 / 37.1 / 37.6 / 37.9 ms for side-stream levels >= 0 / 1 / 2 / 3)
         self._side = None
         self.use_graphs = os.environ.get("VSSEG_GRAPHS", "1") != "0" and not dry_run  # replay the launch lists as hipGraphs after two eager runs
         self.attention, self.hp = attention, hp

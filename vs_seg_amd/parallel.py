@@ -35,7 +35,7 @@ def init_distributed(backend: str | None = None):
     backend = backend or os.environ.get("VSSEG_DIST_BACKEND") or None
     if os.environ.get("VSSEG_SHARE_DEVICE") == "1" and torch.cuda.is_available():
         local = local % torch.cuda.device_count()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -47,6 +47,17 @@ def init_distributed(backend: str | None = None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def _force_collectives() -> bool:
+    """VSSEG_FORCE_COLLECTIVES=1: a single process still creates its process group and issues every collective (a world-size-1 RCCL
+    all-reduce / all-gather / broadcast is a real RCCL call on the device tensor, ordered on the HIP stream like the 8-GPU one).  It is how
+    the `nccl` branch, and its stream hand-off with the side-stream weight gradients, is executed on a 1-GPU box (tests/test_gpu_parallel.py)."""
+    return os.environ.get("VSSEG_FORCE_COLLECTIVES") == "1"
+
+
+def _collectives_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force_collectives())
 
 
 def _via_host(x: torch.Tensor) -> bool:
@@ -100,14 +111,14 @@ def shard_indices(n: int, rank: int | None = None, world: int | None = None) -> 
 
 
 def broadcast_parameters(flat: torch.Tensor, src: int = 0):
-    if world_size() > 1:
+    if _collectives_on():
         _broadcast(flat, src)
 
 
 def broadcast_buffers(model, src: int = 0):
     """BatchNorm running statistics / batch counters of rank `src` to every rank (per-rank batch statistics make them drift apart;
     validation and checkpoints must describe ONE model).  No-op in a single process."""
-    if world_size() > 1:
+    if _collectives_on():
         model.flat_parameters()
         _broadcast(model._bflat, src)
         _broadcast(model._cflat, src)
@@ -115,13 +126,13 @@ def broadcast_buffers(model, src: int = 0):
 
 def allreduce_gradients(gflat: torch.Tensor, async_op: bool = False):
     """Sum the flat gradient buffer over ranks (single bucket).  The mean is applied by Adam's `grad_scale`."""
-    if world_size() > 1:
+    if _collectives_on():
         return _all_reduce_sum(gflat, async_op)
     return None
 
 
 def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
-    if world_size() > 1:
+    if _collectives_on():
         x = x.clone()
         _all_reduce_sum(x)
         x /= world_size()
@@ -130,7 +141,7 @@ def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
 
 def allreduce_sum(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (identity in a single process); returns x."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         _all_reduce_sum(x)
     return x
 
@@ -138,7 +149,7 @@ def allreduce_sum(x: torch.Tensor) -> torch.Tensor:
 def all_gather_scalars(values: Sequence[float], total: int, device="cpu") -> List[float]:
     """Each rank passes the scores of its `shard_indices(total)`; returns the `total` scores in case order on every rank."""
     W, r = world_size(), get_rank()
-    if W == 1:
+    if not _collectives_on():
         return list(values)
     per = (total + W - 1) // W
     buf = torch.full((per,), float("nan"), dtype=torch.float64, device=device)
@@ -174,7 +185,7 @@ def sharded_window_logits(inputs: torch.Tensor, roi_size, predictor: Callable, o
         probe = predictor(crop_fn(inputs, [windows[0]], roi, pad_before))
         local = torch.zeros((per, *probe.shape[1:]), dtype=torch.float32, device=probe.device)
     local = local.contiguous()
-    if W == 1:
+    if not _collectives_on():
         return windows, local[: len(windows)], (roi, padded, pad_before)
     gathered = _all_gather(local)
     out = torch.empty((len(windows), *local.shape[1:]), dtype=torch.float32, device=local.device)

@@ -47,8 +47,11 @@ class CachedLoader:
     meta dicts of the cases for batch_size 1 loaders).  `len()` = number of cases, `batch_size` as in torch's DataLoader —
     the reference's first-epoch log line divides one by the other (ref:params/VSparams.py:466)."""
 
-    def __init__(self, cases: List[Dict], roi: Optional[Sequence[int]], batch_size: int, shuffle: bool, flip_prob: Optional[float], seed: int = 0):
+    def __init__(self, cases: List[Dict], roi: Optional[Sequence[int]], batch_size: int, shuffle: bool, flip_prob: Optional[float], seed: int = 0, pad: Optional[bool] = None):
         self.cases, self.batch_size, self.shuffle = cases, batch_size, shuffle
+        # equal step counts on every rank (wrap-around padding) only where every step issues a collective: the shuffled training loader.
+        # Validation / test loaders give rank r exactly shard_indices(n, r, world) — a padded case would be counted twice in their sums
+        self.pad = shuffle if pad is None else pad
         self.rank, self.world = DP.get_rank(), DP.world_size()
         # every rank shuffles with the SAME stream (the shards must partition one permutation) but draws its own flips / crops
         self.sampler = PatchSampler(cases, roi, flip_prob, seed + 7919 * self.rank) if roi is not None else None
@@ -58,7 +61,7 @@ class CachedLoader:
         return len(self.cases)
 
     def __iter__(self) -> Iterator[Dict]:
-        for idx in epoch_batches(len(self.cases), self.batch_size, self.shuffle, self._order, self.rank, self.world):
+        for idx in epoch_batches(len(self.cases), self.batch_size, self.shuffle, self._order, self.rank, self.world, pad=self.pad):
             if self.sampler is not None:
                 img, lab = self.sampler.sample(idx)
             else:  # test chain: whole volumes, no crop (ref:params/VSparams.py:238-245)
@@ -329,12 +332,13 @@ class VSparams:
         n = len(data_loader)
         dice_dev = torch.zeros(n, dtype=torch.float32, device=self.device)
         predictor = lambda *a, **k: model(*a, **k)[0]  # noqa: E731
-        mine = DP.shard_indices(n)
+        mine = DP.shard_indices(n)  # the unpadded, unshuffled test loader yields exactly these cases, in this order
         with torch.no_grad():
             for i, data in enumerate(data_loader):
-                logger.info("starting image {}".format(mine[i] if i < len(mine) else i))
+                assert i < len(mine), "the test loader yielded more cases than this rank's shard (a padded loader would double-count them)"
+                logger.info("starting image {}".format(mine[i]))
                 outputs = sliding_window_inference(inputs=data["image"], roi_size=self.sliding_window_inferer_roi_size, sw_batch_size=1, predictor=predictor, mode="gaussian")
-                gi = mine[i] if i < len(mine) else i
+                gi = mine[i]
                 dice_dev[gi] = self.compute_dice_score(outputs, data["label"]).reshape(())
                 if self.export_inferred_segmentations:
                     self.export_segmentation(outputs, data["label_meta_dict"])

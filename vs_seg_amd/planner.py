@@ -185,6 +185,43 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
     return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, stream_tile(kc, ntaps), stream_mt(kc, ntaps), nt, 1, kc, 1, (ntaps * (kc // 8) + 3) // 4, stream_lds_bytes(kc, nt, ntaps), -2)
 
 
+# ---- marching streaming kernel (csrc/mconv.hip): depth -5 ------------------------------------------------------------------
+# (input channels, 16-channel output tiles, TZ, M-tiles per wave) instantiated by mconv.hip; rows per workgroup TYB = 64 * mt / tz
+MARCH_SHAPES = {(16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
+                (32, 1, 2, 4), (32, 1, 4, 4), (32, 1, 2, 2), (32, 2, 4, 4), (32, 2, 2, 4), (32, 2, 2, 2), (32, 4, 4, 4), (32, 4, 2, 2), (32, 4, 4, 2),
+                (64, 2, 2, 2), (64, 2, 2, 1), (64, 1, 2, 2), (64, 1, 2, 1)}
+MARCH_RING = 4
+
+
+def march_lds_bytes(kc, nt, tz, mt):
+    g = kc // 8
+    rows = mt * 4 * (16 // tz) + 2
+    return ((9 * g + 3) // 4) * nt * 1024 + MARCH_RING * rows * tz * g * 16 + 5 * nt * 16 * 4 + 16
+
+
+def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmPlan"]:
+    """The depth -5 candidates: the marching kernel (every input voxel fetched once: a workgroup owns a column of `tyb` rows x `tz` slices and
+    walks along x with a ring of planes in LDS) on the stride-1 3x3x1 bf16 launches it is instantiated for.  tile = (x steps per workgroup,
+    rows per workgroup, tz); x is cut into segments so that the launch has about two (or one) rounds of 512 resident workgroups."""
+    offs = [tuple(t[0]) for t in cls.taps]
+    if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x1 or kc != kreal:
+        return []
+    nt = (nreal + 15) // 16
+    out = []
+    for (c, t, tz, mt) in sorted(MARCH_SHAPES):
+        tyb = 64 * mt // tz
+        if c != kc or t != nt or q[1] % tyb or q[2] % tz or march_lds_bytes(kc, nt, tz, mt) > 158 * 1024:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (lx, tyb, tz), mt, nt, 1, kc, 1, (9 * (kc // 8) + 3) // 4, march_lds_bytes(kc, nt, tz, mt), -5)
+            if not any(o.tile == pl.tile and o.mtw == pl.mtw for o in out):
+                out.append(pl)
+    return out
+
+
 # ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
 def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional[List["IgemmPlan"]]:
     """The output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient fused into streaming-kernel launches: a
@@ -337,7 +374,7 @@ def in_split_unsupported(in_split, kc) -> bool:
     return bool(in_split) and (in_split % 8 != 0 or in_split >= kc)
 
 
-def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=4, in_split=0, limit=10) -> List[IgemmPlan]:
+def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=4, in_split=0, limit=10, n=1) -> List[IgemmPlan]:
     """Feasible alternatives to `plan_igemm`'s choice, default first (pack maps are filled for all of them).
 
     What differs between them is what the heuristic cannot see without measuring: the channel chunk (LDS footprint, hence
@@ -388,6 +425,8 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     cp = compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split)
     if cp is not None:
         rest = rest + [cp]
+    if not in_split_unsupported(in_split, kc):
+        rest = rest + march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n)
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
