@@ -459,6 +459,8 @@ MARCH_CASES = [
     ("conv_dgrad", 64, 32, (6, 64, 8), 0, (4, 2), 6),     # K = 32, N = 64 (four channel tiles), 32-row blocks
     ("conv_fwd", 64, 32, (6, 32, 4), 32, (2, 1), 6),      # level-1 concat, 64 input channels
     ("conv_fwd", 64, 32, (5, 64, 4), 32, (2, 2), 2),
+    ("conv_fwd", 1, 16, (6, 64, 8), 0, (8, 8), 3),        # the network input, zero-extended to one 8-channel group
+    ("conv_dgrad", 32, 2, (5, 128, 4), 0, (4, 8), 5),     # data gradient of the logits convolution: K = 2 (-> 8), N = 32
 ]
 
 

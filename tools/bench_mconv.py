@@ -13,7 +13,7 @@ from vs_seg_amd import _lib as L  # noqa: E402
 from vs_seg_amd import planner as P  # noqa: E402
 
 # (kind, cin, cout, dims, mode, in_split)
-CASES = [("conv_fwd", 16, 16, (384, 128, 128), "stats", 0), ("conv_dgrad", 16, 16, (384, 128, 128), "plain", 0), ("conv_fwd", 32, 16, (384, 128, 128), "plain", 16),
+CASES = [("conv_fwd", 1, 16, (384, 128, 128), "stats", 0), ("conv_dgrad", 16, 1, (384, 128, 128), "accumulate", 0), ("conv_dgrad", 32, 2, (384, 128, 128), "plain", 0), ("conv_fwd", 16, 16, (384, 128, 128), "stats", 0), ("conv_dgrad", 16, 16, (384, 128, 128), "plain", 0), ("conv_fwd", 32, 16, (384, 128, 128), "plain", 16),
          ("conv_dgrad", 32, 16, (384, 128, 128), "gate", 0), ("conv_fwd", 32, 2, (384, 128, 128), "plain", 0),
          ("conv_fwd", 16, 32, (192, 64, 128), "stats", 0), ("conv_fwd", 32, 32, (192, 64, 128), "stats", 0), ("conv_dgrad", 32, 32, (192, 64, 128), "plain", 0),
          ("conv_fwd", 64, 32, (192, 64, 128), "plain", 32), ("conv_dgrad", 64, 32, (192, 64, 128), "accumulate", 0), ("conv_dgrad", 32, 16, (192, 64, 128), "plain", 0)]

@@ -49,10 +49,9 @@ template <int CIN, int NT, int TZ, int MT, int MODE>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
-  constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = PLANE_SLOTS * 16, NINST = (PLANE_SLOTS + 255) / 256;
+  constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
   constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = KSTEPS * NT * 1024;
   constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
-  static_assert(PLANE_BYTES % 256 == 0, "ring slots must start on a 256-byte bank row");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
   char* Rl = smem + W_BYTES;
@@ -243,7 +242,9 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
           } else if (vec_store) {
             if (k.out_f32) st4(reinterpret_cast<float*>(op), make_float4(val[0], val[1], val[2], val[3]));
             else st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
-          } else {  // 1- and 2-channel outputs (attention map, logits)
+          } else if (cout == 2 && k.out_f32) {  // the logits: one 8-byte store per voxel
+            *reinterpret_cast<float2*>(op) = make_float2(val[0], val[1]);
+          } else {  // 1-channel outputs (attention map)
             const int nc = min(4, cout - c);
             for (int r = 0; r < nc; ++r) {
               if (k.out_f32) reinterpret_cast<float*>(op)[r] = val[r];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 // ---- host side ------------------------------------------------------------------------------------------------------
 template <int CIN, int NT, int TZ, int MT> static int mc_lds() {
   constexpr int G = CIN / 8, RS = TZ * G, RPM = 16 / TZ, ROWS = MT * 4 * RPM + 2, KSTEPS = (9 * G + 3) / 4;
-  return KSTEPS * NT * 1024 + MC_NR * ROWS * RS * 16 + 5 * NT * 16 * 4 + 16;
+  return KSTEPS * NT * 1024 + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
 }
 template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_mode(const MconvK& k, int grid, hipStream_t s) {
   static bool init = false;
@@ -319,6 +320,7 @@ struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); };
 #define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M>, mc_lds<C, N, Z, M>}
 // (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
 static const McEntry mc_table[] = {
+    MC_E(8, 1, 8, 8), MC_E(8, 2, 8, 8), MC_E(8, 1, 4, 8), MC_E(8, 2, 4, 8), MC_E(8, 1, 4, 4), MC_E(8, 2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
     MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
     MC_E(32, 1, 2, 4), MC_E(32, 1, 4, 4), MC_E(32, 1, 2, 2), MC_E(32, 2, 4, 4), MC_E(32, 2, 2, 4), MC_E(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_E(32, 4, 2, 2), MC_E(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
     MC_E(64, 2, 2, 2), MC_E(64, 2, 2, 1), MC_E(64, 1, 2, 2), MC_E(64, 1, 2, 1)};                                                   // 64 -> 32 / 16

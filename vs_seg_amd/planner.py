@@ -187,7 +187,7 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
 
 # ---- marching streaming kernel (csrc/mconv.hip): depth -5 ------------------------------------------------------------------
 # (input channels, 16-channel output tiles, TZ, M-tiles per wave) instantiated by mconv.hip; rows per workgroup TYB = 64 * mt / tz
-MARCH_SHAPES = {(16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
+MARCH_SHAPES = {(8, 1, 8, 8), (8, 2, 8, 8), (8, 1, 4, 8), (8, 2, 4, 8), (8, 1, 4, 4), (8, 2, 4, 4), (16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
                 (32, 1, 2, 4), (32, 1, 4, 4), (32, 1, 2, 2), (32, 2, 4, 4), (32, 2, 2, 4), (32, 2, 2, 2), (32, 4, 4, 4), (32, 4, 2, 2), (32, 4, 4, 2),
                 (64, 2, 2, 2), (64, 2, 2, 1), (64, 1, 2, 2), (64, 1, 2, 1)}
 MARCH_RING = 4
@@ -196,7 +196,7 @@ MARCH_RING = 4
 def march_lds_bytes(kc, nt, tz, mt):
     g = kc // 8
     rows = mt * 4 * (16 // tz) + 2
-    return ((9 * g + 3) // 4) * nt * 1024 + MARCH_RING * rows * tz * g * 16 + 5 * nt * 16 * 4 + 16
+    return ((9 * g + 3) // 4) * nt * 1024 + MARCH_RING * round_up(rows * tz * g * 16, 256) + 5 * nt * 16 * 4 + 16
 
 
 def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmPlan"]:
@@ -204,7 +204,7 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
     walks along x with a ring of planes in LDS) on the stride-1 3x3x1 bf16 launches it is instantiated for.  tile = (x steps per workgroup,
     rows per workgroup, tz); x is cut into segments so that the launch has about two (or one) rounds of 512 resident workgroups."""
     offs = [tuple(t[0]) for t in cls.taps]
-    if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x1 or kc != kreal:
+    if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x1 or kc != round_up(kreal, 8):
         return []
     nt = (nreal + 15) // 16
     out = []
