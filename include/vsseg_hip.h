@@ -132,6 +132,8 @@ typedef struct {
   int32_t hgroup;          /* 16-channel chunks of H one workgroup multiplies with the P tile it fetched (1..4; 0 = 1): P is read ceil(chunks/hgroup) times.
                             * Clamped by the library to a divisor of the chunk count that fits registers / LDS. */
   float* dbias_p;          /* optional: dbias_p[cP] += sum_q P[q][cP] (bias gradient of a convolution without BatchNorm, P = dY) or NULL */
+  int32_t march;           /* 1: the marching kernel (csrc/mwgrad.hip; stride-1 3x3x1 bf16 only, outside its domain is an error): tile = (x steps per
+                            * workgroup, rows per workgroup, z slices per workgroup in {2, 4, 8}); persistent_blocks / single_buffer / hgroup unused */
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);

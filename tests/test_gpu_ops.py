@@ -131,6 +131,50 @@ def test_wgrad(k, s, cin, cout, dims, tr, dt):
     np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=(5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max()))
 
 
+MARCH_WGRAD_CASES = [
+    # cin (H), cout (P), dims, H split, march tile (x steps, rows, z slices)
+    (16, 16, (10, 64, 8), 0, (4, 64, 4)),    # K-steps split over the waves; 3 x segments
+    (16, 16, (6, 128, 8), 0, (6, 32, 4)),    # four 32-row blocks: each other's halo rows
+    (16, 16, (5, 64, 16), 0, (5, 32, 8)),    # TZ 8
+    (32, 16, (7, 64, 8), 16, (3, 64, 4)),    # level-0 concat as a two-part H
+    (32, 16, (4, 64, 4), 0, (4, 64, 2)),     # TZ 2
+    (32, 2, (5, 64, 8), 0, (5, 64, 4)),      # logits convolution: P = dY of 2 channels stored as one 8-channel group
+    (16, 32, (6, 64, 8), 0, (2, 64, 4)),
+    (32, 32, (9, 64, 8), 0, (4, 64, 4)),     # (tap, cH tile) units split over the waves
+    (32, 32, (4, 64, 4), 0, (4, 64, 2)),
+    (64, 32, (6, 64, 4), 32, (6, 64, 2)),    # level-1 concat
+    (64, 32, (5, 32, 4), 0, (2, 32, 2)),
+    (64, 32, (4, 32, 8), 0, (4, 32, 4)),
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,split,tile", MARCH_WGRAD_CASES)
+def test_marching_weight_gradient(cin, cout, dims, split, tile):
+    """march = 1 selects the marching weight-gradient kernel (csrc/mwgrad.hip: both operands fetched once, planes of H through an LDS ring).
+    Against the fp64 autograd of F.conv3d on the same bf16 operands (the summation order differs from the tile kernel's, so the comparison is
+    with the definition), together with the bias gradient it reduces on the side, across x segments, row blocks and image borders."""
+    dt, k = "bf16", (3, 3, 1)
+    torch.manual_seed(11)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, padding=P.same_pad(k))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    xcl, gcl = H.to_cl(x, H.DT[dt], P.round_up(cin, 8)), H.to_cl(gy, H.DT[dt], P.round_up(cout, 8))
+    h = H._split_cl(xcl, split) if split else xcl
+    db = torch.zeros(16, dtype=torch.float32, device="cuda") if cout >= 16 else None
+    if db is not None:
+        db = torch.zeros(cout, dtype=torch.float32, device="cuda")
+    dw = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin, march_tile=tile, dbias=db)
+    ref = w.grad.float()
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=1e-4 * float(ref.abs().max()))
+    gen = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin)  # the tile kernel on the same operands
+    np.testing.assert_allclose(dw.numpy(), gen.numpy(), atol=1e-4 * float(ref.abs().max()))
+    if db is not None:
+        want = gy.double().sum((0, 2, 3, 4)).float()
+        np.testing.assert_allclose(db.cpu().numpy(), want.numpy(), atol=1e-4 * float(want.abs().max()) + 1e-3)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("k,cin,cout,dims", [((3, 3, 1), 1, 16, (12, 16, 8)), ((1, 1, 1), 1, 16, (6, 8, 4)), ((3, 3, 1), 16, 1, (12, 16, 8)), ((3, 3, 1), 32, 1, (5, 8, 12)), ((3, 3, 1), 1, 8, (3, 4, 2))])
 def test_wgrad_narrow(k, cin, cout, dims, dt):

@@ -99,6 +99,7 @@ class WgradDesc(C.Structure):
         ("single_buffer", C.c_int32),
         ("hgroup", C.c_int32),
         ("dbias_p", C.c_void_p),
+        ("march", C.c_int32),
     ]
 
 

@@ -339,27 +339,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 }
 
 #ifndef WG_INST
-// dw[cp][ch][tap] += sum over workgroups of their slabs
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
-  const int total = hchunks * slab_chunk;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int chunk = i / slab_chunk, r = i - chunk * slab_chunk;
-    const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
-    const int ch = chunk * 16 + l15;
-    if (cp >= d.cp_valid || ch >= d.ch_valid) continue;
-    // 8 independent partial sums keep 8 loads in flight (a single dependent chain made this kernel cost as much as a wgrad tile pass)
-    float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const float* p = slab + (int64_t)chunk * slab_chunk + r;
-    const int64_t bstride = (int64_t)hchunks * slab_chunk;
-    int b = 0;
-    for (; b + 8 <= nblk; b += 8) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s8[j] += p[(b + j) * bstride];
-    }
-    for (; b < nblk; ++b) s8[0] += p[b * bstride];
-    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-    d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap] += s;
-  }
+// dw[cp][ch][tap] += sum over workgroups of their slabs, as a two-stage tree (vsseg_slab_sum): stage 1 (partial != nullptr) sums slices of 32 slabs
+// into partial[slice][i] over a (elements / 64) x slices grid, stage 2 sums the <= 32 partial rows into dw.  (One thread per element walking all
+// <= 1024 slabs was a 41 us latency chain per layer: 1.9 ms per step in 45 launches, profiles/r02_kernel_stats.txt.)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, float* __restrict__ partial, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
+  __shared__ float lds[256];
+  const int64_t total = (int64_t)hchunks * slab_chunk;
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int b0 = blockIdx.y * VSSEG_SLAB_SLICE, b1 = min(nblk, b0 + VSSEG_SLAB_SLICE);
+  const float s = vsseg_slab_sum(slab, total, i, partial ? b0 : 0, partial ? b1 : nblk, lds);
+  if (threadIdx.x >= 64 || i >= total) return;
+  if (partial) { partial[(int64_t)blockIdx.y * total + i] = s; return; }
+  const int chunk = (int)(i / slab_chunk), r = (int)(i - (int64_t)chunk * slab_chunk);
+  const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
+  const int ch = chunk * 16 + l15;
+  if (cp >= d.cp_valid || ch >= d.ch_valid) return;
+  d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap] += s;
 }
 
 #endif  // WG_INST
@@ -425,8 +420,33 @@ int vsseg_wgrad_launch_f32(WgradK& k, int maxt, int hg, dim3& grid, int lds, hip
 int vsseg_wgrad_launch_bf16(WgradK& k, int maxt, int hg, dim3& grid, int lds, hipStream_t s);
 
 #ifndef WG_INST
+// sums `nblk` partial-sum slabs [nblk][hchunks][slab_chunk] into d->dw (two-stage tree; the first-stage rows live behind the slabs)
+int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, int hchunks, int slab_chunk, hipStream_t s) {
+  const int total = hchunks * slab_chunk;
+  const int slices = (nblk + VSSEG_SLAB_SLICE - 1) / VSSEG_SLAB_SLICE;
+  const float* src = slab;
+  int nsrc = nblk;
+  if (slices > 1 && d->scratch_elems - (slab - d->scratch) >= ((int64_t)nblk + slices) * total) {
+    float* partial = slab + (int64_t)nblk * total;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, slices), dim3(256), 0, s, src, nblk, partial, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
+    src = partial;
+    nsrc = slices;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, src, nsrc, (float*)nullptr, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
+  return VSSEG_OK;
+}
+
+int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_t s);  // mwgrad.hip
+
 extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   VSSEG_CHECK(d && d->p.ptr && d->h.ptr && d->dw, "vsseg_wgrad: null pointer");
+  if (d->march) {  // marching kernel (mwgrad.hip): fails loudly outside its domain, never falls back
+    static void* z = nullptr;
+    if (!z && (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess)) z = nullptr;
+    VSSEG_CHECK(z, "vsseg_wgrad: could not allocate the zero page");
+    return vsseg_mwgrad_launch(d, z, as_stream(stream));
+  }
   VSSEG_CHECK(d->p.dtype == d->h.dtype, "vsseg_wgrad: dtype mismatch");
   VSSEG_CHECK(d->ntaps >= 1 && d->ntaps <= VSSEG_MAX_TAPS, "vsseg_wgrad: ntaps out of range");
   VSSEG_CHECK(d->p.c % 8 == 0 && d->p.pitch % 8 == 0 && d->h.c % 8 == 0 && d->h.pitch % 8 == 0, "vsseg_wgrad: channels/pitch must be multiples of 8");
@@ -497,9 +517,6 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   dim3 grid((unsigned)gx, (unsigned)(hchunks / hg));
   int rc = d->p.dtype == VSSEG_F32 ? vsseg_wgrad_launch_f32(k, maxt, hg, grid, off, as_stream(stream)) : vsseg_wgrad_launch_bf16(k, maxt, hg, grid, off, as_stream(stream));
   if (rc) return rc;
-  const int total = hchunks * k.slab_chunk;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)d->scratch, (int)grid.x, hchunks, d->ntaps, d->ntp * 16, k.slab_chunk, *d);
-  VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
-  return VSSEG_OK;
+  return vsseg_wgrad_reduce_launch(d, d->scratch, (int)grid.x, hchunks, k.slab_chunk, as_stream(stream));
 }
 #endif  // WG_INST

@@ -677,11 +677,20 @@ class Plan:
                 d.persistent_blocks = max(1, min(tiles, (256 * wpc) // max(1, hch // max(1, d.hgroup))))
 
             wpc = 4
-            if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU
-                key = f"wgrad2|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}"
+            # the marching kernel (csrc/mwgrad.hip: both operands fetched once) where it is instantiated: stride-1 3x3x1 bf16, 16/32/64 input channels
+            mtiles = []
+            if eng.es == 2 and not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1) and d.h.c == Lr.cin and d.p.c in (8, 16, 32) and not d.p.ptr2:
+                mtiles = P.march_wgrad_tiles(Lr.cin, d.p.c, wg.q, self.n, scr.numel())
+            live_tile = L.i3(wg.tile)
+            if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU, and the marching kernel's tiles
+                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}"
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
-                    d.single_buffer, d.hgroup, wpc = (int(v) for v in cache[key])
+                    hit = cache[key]
+                    if hit[0] == "m":
+                        d.march, live_tile = 1, L.i3(hit[1:4])
+                    else:
+                        d.single_buffer, d.hgroup, wpc = (int(v) for v in hit)
                     tuned = " tuned[cache]"
                 else:
                     stream = torch.cuda.current_stream().cuda_stream
@@ -692,29 +701,45 @@ class Plan:
                     live_dw, live_db = d.dw, d.dbias_p
                     d.dw = live_dw + delta
                     d.dbias_p = (live_db + delta) if live_db else None
+
+                    def measure():
+                        if lib.vsseg_wgrad(C.byref(d), stream):
+                            return float("inf")
+                        best = float("inf")
+                        for _ in range(self.eng.tune_reps):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            lib.vsseg_wgrad(C.byref(d), stream)
+                            e1.record()
+                            e1.synchronize()
+                            best = min(best, e0.elapsed_time(e1))
+                        return best
+
                     ms = {}
                     for hg in hgs:
                         for sb in (0, 1):
                             for w in (2, 3, 4):
-                                d.single_buffer, d.hgroup = sb, hg
+                                d.march, d.single_buffer, d.hgroup = 0, sb, hg
                                 set_blocks(w)
-                                best = float("inf") if not lib.vsseg_wgrad(C.byref(d), stream) else None
-                                for _ in range(self.eng.tune_reps if best is not None else 0):
-                                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                                    e0.record()
-                                    lib.vsseg_wgrad(C.byref(d), stream)
-                                    e1.record()
-                                    e1.synchronize()
-                                    best = min(best, e0.elapsed_time(e1))
-                                ms[(sb, hg, w)] = float("inf") if best is None else best
-                    d.dw, d.dbias_p = live_dw, live_db
-                    d.single_buffer, d.hgroup, wpc = min(ms, key=ms.get)
-                    cache[key] = [d.single_buffer, d.hgroup, wpc]
+                                ms[(sb, hg, w)] = measure()
+                    for mt in mtiles:
+                        d.march, d.tile = 1, L.i3(mt)
+                        ms[("m", *mt)] = measure()
+                    d.dw, d.dbias_p, d.tile = live_dw, live_db, L.i3(wg.tile)
+                    bestk = min(ms, key=ms.get)
+                    if bestk[0] == "m":
+                        d.march, live_tile = 1, L.i3(bestk[1:4])
+                    else:
+                        d.march = 0
+                        d.single_buffer, d.hgroup, wpc = bestk
+                    cache[key] = list(bestk)
                     _tune_cache.dirty = True
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
+            d.tile = live_tile
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}{tuned}", name=f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>", kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} " + (f"march tile={tuple(d.tile)}" if d.march else f"tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}") + tuned,
+                                                          name=(f"mwgrad<bf16,{wg.ntp}>" if d.march else f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>"), kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -883,7 +908,10 @@ class Plan:
         stream at the end of the list.  Under hipGraph capture the fork / join events become graph edges."""
         side = None
         overlap = self.eng.overlap
+        skip_side = os.environ.get("VSSEG_EXPERIMENT_SKIP_SIDE") == "1"
         for rec in lst:
+            if skip_side and len(rec) > 2 and rec[2].get("side"):
+                continue
             if overlap and len(rec) > 2 and rec[2].get("side"):
                 main = torch.cuda.current_stream()
                 if side is None:

@@ -222,6 +222,31 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
     return out
 
 
+# (H channels, P channels as stored, TZ, M-tiles per wave) instantiated by csrc/mwgrad.hip; rows per workgroup = 64 * mt / tz
+MARCH_WGRAD_SHAPES = {(16, 16, 4, 4), (16, 16, 4, 2), (16, 16, 8, 4), (16, 16, 8, 8), (32, 16, 4, 4), (32, 16, 4, 2), (32, 16, 2, 2), (32, 8, 4, 4), (32, 8, 4, 2),
+                      (16, 32, 4, 4), (16, 32, 8, 4), (16, 32, 4, 2), (32, 32, 4, 4), (32, 32, 4, 2), (32, 32, 2, 2), (64, 32, 2, 2), (64, 32, 2, 1), (64, 32, 4, 2)}
+
+
+def march_wgrad_tiles(ch, cp, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tuple[int, int, int]]:
+    """Candidate tiles (x steps per workgroup, rows, z slices) of the marching weight-gradient kernel for a stride-1 3x3x1 bf16 convolution with
+    `ch` input channels (H = X) and a dY stored with `cp` channels: about 512 / 1024 / 2048 workgroups, each with its own partial-sum slab."""
+    out = []
+    per_blk = (ch // 16) * 9 * max(1, cp // 16) * 256
+    for (h, p, tz, mt) in sorted(MARCH_WGRAD_SHAPES):
+        tyb = 64 * mt // tz
+        if h != ch or p != cp or q[1] % tyb or q[2] % tz:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024, 2048):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            grid = cols * -(-q[0] // lx)
+            if (grid + -(-grid // 32)) * per_blk > scratch_elems or (lx, tyb, tz) in out:
+                continue
+            out.append((lx, tyb, tz))
+    return out
+
+
 # ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
 def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional[List["IgemmPlan"]]:
     """The output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient fused into streaming-kernel launches: a
