@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) {
     int t = wt + i * k.wt;
-    toff[i] = t < d.ntaps ? (((d.tap_off[t][0] - k.off_min[0]) * HY + (d.tap_off[t][1] - k.off_min[1])) * HZ + (d.tap_off[t][2] - k.off_min[2])) * HROW : -1;
+    // a wave with fewer taps than MAXT multiplies tap slot 0 again in its spare slots (never flushed): a `continue` on the spare slots was a branch inside
+    // the unrolled tap loop that kept hipcc from hoisting the next taps' fragment reads over the MFMAs of the current one
+    toff[i] = t < d.ntaps ? (((d.tap_off[t][0] - k.off_min[0]) * HY + (d.tap_off[t][1] - k.off_min[1])) * HZ + (d.tap_off[t][2] - k.off_min[2])) * HROW : 0;
   }
   f32x4 acc[MAXT][HG][NTP];
 #pragma unroll
@@ -251,7 +253,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
       if constexpr (ES == 2) {
         // lane (g, i=l15): rows r=i>>2 of two 4-voxel blocks, 4-channel column chunk q=i&3
         const int r = l15 >> 2, qc = (l15 & 3) * 8;  // byte offset of the 4-channel chunk
-        const int v0 = ks * 32 + g * 8 + r, v1 = v0 + 4;
+        // K-slot g*8 + j of the MFMA holds tile voxel 4g + j (j < 4) / 16 + 4g + (j - 4) of the K-step — the same permutation for both operands, so
+        // the product is unchanged — instead of 8g + j: the two 4-voxel blocks a half-wave reads in one ds_read_b64_tr_b16 are then NEIGHBOURS
+        // (voxels 0..7 / 8..15 of the K-step: one contiguous 256-byte z-row of the 16-channel halo tile, 8 rows of 96 bytes of a 48-channel P tile =
+        // 8 different 32-byte bank groups) where 8g + j put them 8 voxels = a multiple of 256 bytes apart (47 % bank-conflict cycles, r02_pmc_sq.txt)
+        const int v0 = ks * 32 + g * 4 + r, v1 = v0 + 16;
         const int h0 = hbase[v0] * HROW + qc, h1 = hbase[v1] * HROW + qc;
         bf16x8 pa[NTP];
 #pragma unroll
@@ -269,7 +275,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
         }
 #pragma unroll
         for (int i = 0; i < MAXT; ++i) {
-          if (toff[i] < 0) continue;
           typedef __attribute__((address_space(3))) bf16x4 lds_b4;
 #pragma unroll
           for (int h = 0; h < HG; ++h) {
@@ -294,8 +299,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
           }
 #pragma unroll
           for (int i = 0; i < MAXT; ++i) {
-            if (toff[i] < 0) continue;
-#pragma unroll
+  #pragma unroll
             for (int h = 0; h < HG; ++h) {
               const float hb = *reinterpret_cast<const float*>(Hs + hb0 + toff[i] + h * 64);
 #pragma unroll
