@@ -163,6 +163,43 @@ def golden_net_train(only=None):
         print("net_train", name, float(loss))
 
 
+def golden_trajectory():
+    """THREE steps of the reference's training loop (ref:params/VSparams.py:454-467: zero_grad, forward, Dice_spvPA, backward, Adam step with
+    lr 1e-4 / weight_decay 1e-7, ref:388-391) on one fixed batch, dropout p = 0: loss per step, every parameter and every BatchNorm buffer
+    (running_mean / running_var with momentum 0.1, num_batches_tracked) after the third step.  Pins what a single step cannot: the BatchNorm
+    running-statistics recursion, Adam's bias correction over steps on the real network, and that step k+1 starts from step k's parameters."""
+    seed, shape, steps = 27, (1, 1, 128, 128, 32), 3  # 64 values per bottleneck channel: below that training-mode BatchNorm amplifies fp32 summation-order noise to percents
+    model = build_reference_model(True, dropout=0.0)
+    model.load_state_dict(O.seeded_state_dict(True, seed))
+    model.train()
+    x, y = synth_input(seed, shape), synth_label(seed, shape)
+    loss_fn = Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
+    opt = torch.optim.Adam(model.parameters(), 1e-4, weight_decay=1e-7)
+    losses, logit_sub = [], []
+    for _ in range(steps):
+        opt.zero_grad()
+        outputs = model(x)
+        loss = loss_fn(outputs, y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        logit_sub.append(outputs[0].detach().flatten()[::97][:512].numpy().copy())
+    d = dict(seed=seed, shape=np.array(shape), steps=steps, lr=1e-4, weight_decay=1e-7, losses=np.array(losses, np.float64), logits_sub=np.stack(logit_sub))
+    sd0 = O.seeded_state_dict(True, seed)
+    for k, v in model.state_dict().items():
+        v = v.detach()
+        if k.endswith("num_batches_tracked"):
+            d["cnt:" + k] = np.array(int(v))
+        elif "running_" in k:
+            d["bn:" + k] = v.numpy()
+        else:  # the parameter's displacement over the three steps (values are O(1), displacements O(3e-4)): a strided sub-sample + checksums
+            dp = (v.double() - sd0[k].double()).flatten()
+            d["dp:" + k] = dp[:: max(1, dp.numel() // 256)][:256].float().numpy()
+            d["dpsum:" + k] = np.array([float(dp.sum()), float(dp.abs().sum()), float((dp * dp).sum())])
+    np.savez_compressed(os.path.join(HERE, "trajectory_b1_128x128x32.npz"), **d)
+    print("trajectory", losses)
+
+
 def golden_blocks():
     """Per-block goldens: every conv flavour of the network (kernel/stride/transposed), ResidualUnit and attention."""
     d = {}
@@ -264,7 +301,11 @@ if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--only-net-train":
         golden_net_train(set(sys.argv[2:]))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-trajectory":
+        golden_trajectory()
+        sys.exit(0)
     golden_manifest()
+    golden_trajectory()
     golden_blocks()
     golden_loss()
     golden_adam()

@@ -27,7 +27,7 @@ from tests.helpers import load, synth_input, synth_label
 # path crosses ~25 layers; the fp32 compute mode agrees to 1e-4..3e-3 on the same tensors — tools/diag_bf16_grads.py).
 # The 25 PReLU slopes are single scalars, each a heavily cancelling sum over a whole activation tensor: their bf16 values are
 # reported (`grad_scalar_rel_worst`) but carry no bar.
-BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4)
+BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4, prelu_sign_agreement=0.8, prelu_rel_median=0.5)
 
 
 def golden_train_case(name="net_train_b1_384x128x128.npz"):
@@ -84,10 +84,22 @@ def train_step_metrics(model, loss_fn, batch: int = 1, golden: str = "net_train_
     out["grad_rel_l2_worst"] = rr[-1]
     out["grad_worst_tensor"] = max(rels)[1]
     out["grad_scalar_rel_worst"] = max(scal)[0] if scal else 0.0
+    # the 25 PReLU slopes: each gradient is one heavily cancelling sum over a whole activation tensor (sum of dA * d over the negative branch).
+    # Reported one by one against the golden: sign agreement and the median relative error are barred (a slope that trains in the wrong direction
+    # would show here), the worst relative error is the slope whose reference gradient is itself ~0 (the sum cancels to 1e-3 of its terms)
+    slopes = [(float(p.grad.double()), float(g["gsub:" + k][0]), k) for k, p in model.named_parameters() if k.endswith("act.weight")]
+    if slopes:
+        agree = [1.0 if (a > 0) == (b > 0) else 0.0 for a, b, _ in slopes]
+        rel = sorted(abs(a - b) / (abs(b) + 1e-30) for a, b, _ in slopes)
+        out["prelu_slopes"] = len(slopes)
+        out["prelu_sign_agreement"] = float(np.mean(agree))
+        out["prelu_rel_median"] = rel[len(rel) // 2]
+        out["prelu_disagree"] = [k for (a, b, k), ok in zip(slopes, agree) if not ok]
     out["grad_tensors"] = len(rels)
     return out
 
 
 def passes(m: Dict[str, float], bars=BARS) -> bool:
     return (m["loss_abs"] <= bars["loss_abs"] and m["logits_rel_l2"] <= bars["logits_rel_l2"] and m["att_max_abs"] <= bars["att_max_abs"] and m["grad_cos"] >= bars["grad_cos"]
-            and m["grad_rel_l2_median"] <= bars["grad_rel_l2_median"] and m["grad_rel_l2_worst"] <= bars["grad_rel_l2_worst"])
+            and m["grad_rel_l2_median"] <= bars["grad_rel_l2_median"] and m["grad_rel_l2_worst"] <= bars["grad_rel_l2_worst"]
+            and m.get("prelu_sign_agreement", 1.0) >= bars.get("prelu_sign_agreement", 0.0) and m.get("prelu_rel_median", 0.0) <= bars.get("prelu_rel_median", float("inf")))

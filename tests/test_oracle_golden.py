@@ -181,3 +181,44 @@ def test_hard_dice_matches_reference_golden():
         assert tuple(got.shape) == (1, 1)
         assert abs(float(got) - float(g[n + ":dice"])) < 1e-6, n
     assert abs(float(g["perfect:dice"]) - 1.0) < 1e-6 and float(g["both_empty:dice"]) == 1.0
+
+
+def test_three_step_trajectory_matches_reference_golden():
+    """Three steps of the reference's training loop (ref:params/VSparams.py:454-467) restated with the oracle: forward + Dice_spvPA + backward,
+    `adam_step` on every parameter, BatchNorm running statistics / counters carried from step to step (tests/golden/make_goldens.py::golden_trajectory)."""
+    g = load("trajectory_b1_128x128x32.npz")
+    seed, shape, steps = int(g["seed"]), tuple(int(v) for v in g["shape"]), int(g["steps"])
+    sd0 = O.seeded_state_dict(True, seed)
+    sd = {k: v.clone() for k, v in sd0.items()}
+    x, y = synth_input(seed, shape), synth_label(seed, shape)
+    pkeys = [k for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
+    m = {k: torch.zeros_like(sd[k]) for k in pkeys}
+    v = {k: torch.zeros_like(sd[k]) for k in pkeys}
+    for step in range(1, steps + 1):
+        leaf = {k: (t.clone().requires_grad_(True) if k in m else t) for k, t in sd.items()}
+        logits, atts, ctx = O.unet_forward(leaf, x, train=True, attention_module=True, dropout_p=0.0)
+        loss = O.dice_spvpa(logits, atts, y)
+        loss.backward()
+        assert abs(float(loss) - float(g["losses"][step - 1])) < (2e-6 if step == 1 else 2e-5), (step, float(loss))
+        # step 1 is the pinned single step; afterwards elements whose gradient sits at the fp32 noise floor may have moved by +-lr instead of -+lr
+        np.testing.assert_allclose(logits.detach().flatten()[::97][:512].numpy(), g["logits_sub"][step - 1], atol=2e-5 if step == 1 else 1e-3)
+        for k in pkeys:
+            gk = leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(sd[k])  # conv biases in front of a training-mode BatchNorm
+            sd[k], m[k], v[k] = O.adam_step(sd[k], gk, m[k], v[k], step)
+        for k, t in ctx.bn_updates.items():
+            sd[k] = t.detach()
+    for k in g.files:
+        if k.startswith("bn:"):
+            # (running means follow the conv biases in front of them, which the reference's Adam moves by +-lr on rounding noise: 1e-4, not 1e-6)
+            np.testing.assert_allclose(sd[k[3:]].numpy(), g[k], atol=1e-4, rtol=1e-4, err_msg=k)
+        elif k.startswith("cnt:"):
+            assert int(sd[k[4:]]) == int(g[k]) == steps
+        elif k.startswith("dp:"):
+            if k.endswith("conv.bias") and ("dp:" + k[3:].replace("conv.bias", "norm.weight")) in g.files:
+                continue  # a bias in front of a training-mode BatchNorm has zero gradient: Adam turns the reference's rounding noise into +-lr moves
+            dp = (sd[k[3:]].double() - sd0[k[3:]].double()).flatten()
+            sub = dp[:: max(1, dp.numel() // 256)][:256].float().numpy()
+            # Adam's first steps move every element by ~lr whatever the gradient's size: an element whose gradient is at the fp32 noise floor can
+            # take a different sign — barred in aggregate (relative L2), not element by element
+            err = np.linalg.norm(sub - g[k]) / max(np.linalg.norm(g[k]), 1e-12)
+            assert err < 2e-2, (k, err)
