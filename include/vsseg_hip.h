@@ -57,22 +57,6 @@ typedef struct {
   int32_t reserved;
 } vsseg_tensor;
 
-/* Optional fused first pass of the BatchNorm -> Dropout -> PReLU backward (vsseg_bn_act_bwd_reduce) in the epilogue of the launch that
- * PRODUCES that layer's output gradient dA (a data gradient of the streaming / compute kernels, plans with depth -2 / -3): the launch has
- * the dA tile in registers, reads the layer's pre-activation y and its stored keep-mask for the same voxels and adds
- * sum(dz), sum(dz*xhat) and the PReLU-slope term to the layer's sharded sums — the separate reduce pass (two full tensor reads) is not
- * launched.  The whole output tensor of the launch must be that layer's dA (same channel count, one part). */
-typedef struct {
-  const void* y;           /* [N][X][Y][Z][y_pitch] pre-activation of the layer, in the launch's output dtype (bf16) */
-  int32_t y_pitch;
-  const uint8_t* keep;     /* keep-mask bytes stored by vsseg_bn_act_fwd; required when p_drop > 0 */
-  const float *scale, *shift, *mean, *invstd, *alpha; /* the layer's folded affine, statistics and PReLU slope */
-  float p_drop;
-  double* sums;            /* as vsseg_bn_act_bwd_reduce: [VSSEG_STAT_SHARDS][3][stride] */
-  int32_t stride;
-  double* alpha_acc;       /* [VSSEG_STAT_SHARDS] */
-} vsseg_bnred;
-
 /* One implicit-GEMM launch over an output lattice q in [0,q): out[q*os+oo][n] = epi( sum_t sum_c in[q*is+off_t][c] * W[t][c][n] ).
  * Covers Conv3d forward, every parity class of ConvTranspose3d forward, and both data-gradients
  * (ref:params/networks/blocks/convolutions.py:114-146 and their autograd at ref:params/VSparams.py:461). */
@@ -108,7 +92,6 @@ typedef struct {
    * real channel c % cout_mod for bias / bias2 / scale / shift / stats.  0: off. */
   int32_t cout_mod;
   const float* gate;       /* VSSEG_RES_GATE: fp32 attention map [N][X][Y][Z] of the output tensor, or NULL */
-  const vsseg_bnred* bnred; /* fused BatchNorm-backward reduction over the output (depth -2 / -3 plans only), or NULL */
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
@@ -233,14 +216,6 @@ int vsseg_crop_flip(const void* jobs, int32_t njobs, float* dst, const int32_t r
 /* NormalizeIntensityd (ref:params/VSparams.py:213): y = (x - mean) / std over all n voxels (population std; std == 0: no
  * division).  acc2 = 2 doubles of device scratch (sum, sum of squares; left filled for inspection). */
 int vsseg_normalize_intensity(const float* x, float* y, int64_t n, double* acc2, void* stream);
-
-/* Convolution of a ONE-channel tensor as a direct stencil (first encoder block with in_channels = 1: model.0.conv.unit0 3x3x1,
- * model.0.residual 1x1x1; ref:params/networks/blocks/convolutions.py:114-146, 241-250): v = bias[c] + sum_t w[c][t]*x1[voxel+off_t],
- * zero padding.  stats != NULL: out = v and per-channel sum / sum-of-squares of v are added to the sharded statistics (training
- * BatchNorm, same layout as vsseg_igemm_desc.stats).  Otherwise out = act(v*scale[c] + shift[c]) with scale/shift optional (eval
- * BatchNorm folded) and PReLU when alpha != NULL.  x1: [n][X][Y][Z] in `dtype`; w: [out.c][kx*ky] fp32 (the torch weight, flat). */
-int vsseg_conv1ch_fwd(const void* x1, int32_t dtype, int32_t n, const int32_t dims[3], const float* w, const float* bias, const int32_t kernel[3],
-                      const float* scale, const float* shift, const float* alpha, vsseg_tensor out, double* stats, int32_t stats_stride, void* stream);
 
 /* Sliding-window blend (MONAI sliding_window_inference steps 6-7; call site ref:params/VSparams.py:568-574). */
 int vsseg_swi_accumulate(const float* seg /* [rx][ry][rz][c] */, const float* imap /* [rx][ry][rz] */, const int32_t roi[3], const int32_t start[3], int32_t c,

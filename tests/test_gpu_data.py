@@ -25,40 +25,6 @@ def test_normalize_intensity_matches_host():
         np.testing.assert_allclose(y.cpu().numpy(), T.host_normalize_intensity(v), atol=2e-5)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
-@pytest.mark.parametrize("k", [(3, 3, 1), (1, 1, 1)])
-def test_direct_one_channel_convolution(k, dt):
-    """vsseg_conv1ch_fwd against torch's conv3d: statistics mode (training: pre-BN output + per-channel sums) and
-    affine + PReLU mode (eval), 16 and 24 output channels, batch 2, ragged x/y extents."""
-    import torch.nn.functional as F
-
-    lib = L.lib()
-    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
-    torch.manual_seed(5)
-    for cout, dims in ((16, (9, 7, 8)), (24, (16, 5, 12))):
-        x = torch.randn(2, 1, *dims)
-        x = x.to(tdt).float()
-        w, b = torch.randn(cout, 1, *k) / 3.0, torch.randn(cout)
-        y = F.conv3d(x.double(), w.double(), b.double(), padding=(k[0] // 2, k[1] // 2, 0))
-        x1 = x[:, 0].contiguous().cuda().to(tdt)
-        wd, bd = w.reshape(-1).contiguous().cuda(), b.cuda()
-        out = torch.zeros(2, *dims, cout, dtype=tdt, device="cuda")
-        od = L.Tensor(out.data_ptr(), L.F32 if dt == "fp32" else L.BF16, cout, cout, 2, *dims)
-        stats = torch.zeros(L.STAT_SHARDS * 2 * 32, dtype=torch.float64, device="cuda")
-        S = torch.cuda.current_stream().cuda_stream
-        L.check(lib.vsseg_conv1ch_fwd(x1.data_ptr(), od.dtype, 2, L.i3(dims), wd.data_ptr(), bd.data_ptr(), L.i3(k), None, None, None, od, stats.data_ptr(), 32, S))
-        got = out.float().cpu().permute(0, 4, 1, 2, 3)
-        tol = 2e-5 if dt == "fp32" else 2e-2
-        np.testing.assert_allclose(got.numpy(), y.float().numpy(), atol=tol * float(y.abs().max()))
-        st = stats.cpu().view(L.STAT_SHARDS, 2, 32).sum(0)[:, :cout]
-        np.testing.assert_allclose(st[0].numpy(), y.sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=1e-3 * y.abs().sum((0, 2, 3, 4)).max().item())
-        np.testing.assert_allclose(st[1].numpy(), (y * y).sum((0, 2, 3, 4)).numpy(), rtol=1e-4)
-        sc, sh, al = (torch.rand(cout) + 0.5).cuda(), torch.randn(cout).cuda(), torch.tensor([0.2]).cuda()
-        L.check(lib.vsseg_conv1ch_fwd(x1.data_ptr(), od.dtype, 2, L.i3(dims), wd.data_ptr(), bd.data_ptr(), L.i3(k), sc.data_ptr(), sh.data_ptr(), al.data_ptr(), od, None, 0, S))
-        ref = F.prelu(y * sc.cpu().double().view(1, -1, 1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1, 1), al.cpu().double())
-        np.testing.assert_allclose(out.float().cpu().permute(0, 4, 1, 2, 3).numpy(), ref.float().numpy(), atol=tol * float(ref.abs().max()))
-
-
 def _case(vol, lab):
     return {"image": torch.from_numpy(vol).cuda(), "label": torch.from_numpy(lab).cuda()}
 

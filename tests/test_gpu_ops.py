@@ -652,58 +652,6 @@ def test_compute_kernel_equals_general_kernel(kind, cin, cout, dims, split):
             np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
 
 
-@pytest.mark.parametrize("k,c,dims,p_drop", [((3, 3, 1), 16, (16, 16, 8), 0.1), ((3, 3, 1), 32, (16, 24, 8), 0.1), ((3, 3, 3), 48, (8, 16, 32), 0.1), ((3, 3, 3), 32, (8, 16, 16), 0.0)])
-def test_fused_bn_backward_reduction_equals_separate_pass(k, c, dims, p_drop):
-    """vsseg_bnred: the data gradient that produces a BatchNorm layer's output gradient dA runs the first pass of that layer's backward in its
-    epilogue (streaming kernel for 3x3x1, compute kernel for 3x3x3).  The output must be bit-identical to the plain launch and the sharded sums
-    must equal what vsseg_bn_act_bwd_reduce computes from that output (same bf16-rounded dA, same stored keep-mask) up to summation order."""
-    lib = L.lib()
-    torch.manual_seed(13)
-    n, cout = 2, (48 if k == (3, 3, 3) else c)
-    w = _round(torch.randn(cout, c, *k) / (c * np.prod(k)) ** 0.5, "bf16")
-    gy = H.to_cl(_round(torch.randn(n, cout, *dims), "bf16"), torch.bfloat16)          # gradient of the consumer convolution's output
-    y = H.to_cl(_round(torch.randn(n, c, *dims) * 1.3 + 0.2, "bf16"), torch.bfloat16)   # pre-activation of the BatchNorm layer in front of it
-    nvox = n * int(np.prod(dims))
-    vec = torch.randn(4, c, device="cuda")  # mean, invstd, scale, shift
-    vec[1].abs_().add_(0.5)
-    alpha = torch.tensor([0.2], device="cuda")
-    keep = torch.randint(0, 256, (nvox * c // 8,), dtype=torch.uint8, device="cuda") | torch.randint(0, 256, (nvox * c // 8,), dtype=torch.uint8, device="cuda")
-    cls = P.lattice_classes("conv_dgrad", k, (1, 1, 1))[0]
-    kreal, nreal = P.gemm_dims("conv_dgrad", tuple(w.shape))
-    pl = P.compute_plan("conv_dgrad", tuple(w.shape), cls, dims, 2, cout, nreal, kreal) if k == (3, 3, 3) else P.stream_plan("conv_dgrad", tuple(w.shape), cls, dims, 2, cout, nreal, kreal)
-    assert pl is not None
-    pl.pack_map = P.pack_map(pl, tuple(w.shape))
-    wp = H.pack(pl, w, gy.dtype)
-    gam = torch.ones(c, device="cuda")
-
-    def sums_buffers():
-        return torch.zeros(L.STAT_SHARDS, 3, c, dtype=torch.float64, device="cuda"), torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
-
-    out_a = torch.zeros(n, *dims, c, dtype=torch.bfloat16, device="cuda")
-    L.check(lib.vsseg_igemm(C.byref(H.igemm_desc(pl, wp, H.tdesc(gy), H.tdesc(out_a))), H.stream()), "plain")
-    sa, aa = sums_buffers()
-    L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(y), H.tdesc(out_a), vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), gam.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), alpha.data_ptr(), p_drop, 7, 3,
-                                        sa.data_ptr(), c, aa.data_ptr(), keep.data_ptr(), H.stream()))
-    out_b = torch.zeros_like(out_a)
-    sb, ab = sums_buffers()
-    br = L.BnRed(y.data_ptr(), c, keep.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), alpha.data_ptr(), p_drop, sb.data_ptr(), c, ab.data_ptr())
-    d = H.igemm_desc(pl, wp, H.tdesc(gy), H.tdesc(out_b))
-    d.bnred = C.pointer(br)
-    L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "fused")
-    torch.cuda.synchronize()
-    assert torch.equal(out_a, out_b)
-    ta, tb = sa.sum(0).cpu().numpy(), sb.sum(0).cpu().numpy()
-    scale = np.abs(ta[:2]).max()
-    np.testing.assert_allclose(tb[:2], ta[:2], rtol=2e-4, atol=2e-5 * scale)
-    np.testing.assert_allclose(float(ab.sum()), float(aa.sum()), rtol=2e-4, atol=2e-5 * abs(float(aa.sum())) + 1e-4)
-    # the general kernel refuses the request instead of ignoring it
-    gen = P.plan_igemm("conv_dgrad", tuple(w.shape), cls, dims, 2, kc_pad=cout)
-    gen.pack_map = P.pack_map(gen, tuple(w.shape))
-    dg = H.igemm_desc(gen, H.pack(gen, w, gy.dtype), H.tdesc(gy), H.tdesc(out_b))
-    dg.bnred = C.pointer(br)
-    assert lib.vsseg_igemm(C.byref(dg), H.stream()) == L.EINVAL
-
-
 @pytest.mark.parametrize("kind,cin,cout,dims,mode", [("convT_fwd", 32, 16, (8, 16, 8), "stats"), ("convT_fwd", 32, 16, (16, 8, 4), "plain"), ("conv_dgrad", 16, 16, (8, 16, 8), "accumulate"),
                                                      ("conv_dgrad", 16, 16, (16, 16, 4), "plain"), ("convT_fwd", 48, 32, (8, 16, 8), "stats"), ("conv_dgrad", 32, 32, (8, 8, 8), "accumulate")])
 def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mode):

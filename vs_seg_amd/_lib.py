@@ -35,11 +35,6 @@ class CropJob(C.Structure):  # vsseg_crop_job
     _fields_ = [("src", C.c_void_p), ("sdims", C.c_int32 * 3), ("origin", C.c_int32 * 3), ("flip_x", C.c_int32)]
 
 
-class BnRed(C.Structure):  # vsseg_bnred
-    _fields_ = [("y", C.c_void_p), ("y_pitch", C.c_int32), ("keep", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("alpha", C.c_void_p), ("p_drop", C.c_float), ("sums", C.c_void_p), ("stride", C.c_int32), ("alpha_acc", C.c_void_p)]
-
-
 class IgemmDesc(C.Structure):
     _fields_ = [
         ("inp", Tensor),
@@ -72,7 +67,6 @@ class IgemmDesc(C.Structure):
         ("stats_stride", C.c_int32),
         ("cout_mod", C.c_int32),
         ("gate", C.c_void_p),
-        ("bnred", C.POINTER(BnRed)),
     ]
 
 
@@ -105,7 +99,7 @@ class WgradDesc(C.Structure):
 
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_conv1ch_fwd", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_wgrad_narrow", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_wgrad_narrow", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -134,7 +128,6 @@ def lib():
         L.vsseg_copy_bytes.argtypes = [vp, vp, i64, vp]
         L.vsseg_crop_flip.argtypes = [vp, i32, vp, I3, vp]
         L.vsseg_normalize_intensity.argtypes = [vp, vp, i64, vp, vp]
-        L.vsseg_conv1ch_fwd.argtypes = [vp, i32, i32, I3, vp, vp, I3, vp, vp, vp, Tensor, vp, i32, vp]
         L.vsseg_igemm.argtypes = [C.POINTER(IgemmDesc), vp]
         L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
         L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]

@@ -53,12 +53,6 @@ struct CconvK {
   int X, Y, Z, ntx, nty, ntz;
   unsigned mg_tz, mg_ty, mg_tx;
   int tiles, per_xcd;
-  // fused BatchNorm-backward reduction over the output (MODE 3; vsseg_bnred)
-  const char* bn_y; const unsigned char* bn_keep;
-  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_alpha;
-  double* bn_sums; double* bn_alpha_acc;
-  int bn_y_vox_bytes, bn_stride;
-  float bn_inv_keep;
 };
 
 __device__ __forceinline__ unsigned cc_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }  // magic 0: divisor 1
@@ -68,11 +62,10 @@ __device__ __forceinline__ void cc_wait_vm(int n) {  // s_waitcnt vmcnt(n) for t
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16), 3 + first pass of the BatchNorm backward of the layer whose output
-// gradient this launch produces (vsseg_bnred)
+// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16)
 template <int NT, int MODE>
 __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
-  constexpr bool STATS = MODE == 1, AUXM = MODE == 2, BNR = MODE == 3;
+  constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
   constexpr int MT = 4;
   constexpr int BUF = cc_buf_bytes(NT);
   constexpr int WROWS = CC_KS * NT, NW = (WROWS + 7) / 8;
@@ -88,13 +81,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
     epi[i] = ((ok && k.bias) ? k.bias[c] : 0.f) + ((ok && k.bias2) ? k.bias2[c] : 0.f);
     epi[NT * 16 + i] = (ok && k.scale) ? k.scale[c] : 1.f;
     epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[c] : 0.f;
-    if constexpr (BNR) {
-      epi[3 * NT * 16 + i] = ok ? k.bn_scale[c] : 0.f;
-      epi[4 * NT * 16 + i] = ok ? k.bn_shift[c] : 0.f;
-    }
   }
-  const float bn_alpha = BNR ? *k.bn_alpha : 0.f;
-  float bn_dal = 0.f;
   const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
 
   // ---- this thread's halo pieces: LDS slot j = (u*8 + wave)*64 + lane holds the 16-byte group j & 1 of halo voxel j >> 1 ----
@@ -122,9 +109,9 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
   const bool simple = !k.out_f32 && !k.scale && (k.act == VSSEG_ACT_NONE || k.act == VSSEG_ACT_PRELU);
   const int ekind = !simple ? 2 : (k.aux_mode == 3 ? 1 : 0);
   const float alpha_eff = k.act == VSSEG_ACT_PRELU ? alpha : 1.f;
-  float ssum[(STATS || BNR) ? NT : 1][4], ssq[(STATS || BNR) ? NT : 1][4];  // STATS: sum / sum of squares of the output; BNR: sum(dz) / sum(dz * y)
+  float ssum[STATS ? NT : 1][4], ssq[STATS ? NT : 1][4];  // sum / sum of squares of the output
 #pragma unroll
-  for (int t = 0; t < ((STATS || BNR) ? NT : 1); ++t)
+  for (int t = 0; t < (STATS ? NT : 1); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
 
@@ -209,22 +196,6 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
           for (int t = 0; t < NT; ++t) {
             const int c = c_base + t * 16 + g * 4;
             auxv[m][t] = *reinterpret_cast<const uint2*>((c_base + t * 16 >= k.aux_csplit ? k.aux1 : k.aux0) + vox * k.aux_vox_bytes + c * 2);
-          }
-        }
-      }
-    }
-    uint2 bnyv[BNR ? MT : 1][BNR ? NT : 1];
-    unsigned bnkv[BNR ? MT : 1][BNR ? NT : 1];
-    if constexpr (BNR) {
-      if (last) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int64_t vox = ovox + ov0 + (unsigned)(m * Z);
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            const int c = c_base + t * 16 + g * 4;
-            bnyv[m][t] = *reinterpret_cast<const uint2*>(k.bn_y + vox * k.bn_y_vox_bytes + c * 2);
-            bnkv[m][t] = k.bn_keep ? (unsigned)k.bn_keep[vox * (cout >> 3) + (c >> 3)] : 0xffu;
           }
         }
       }
@@ -321,24 +292,6 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
               val[0] += av.x * gt; val[1] += av.y * gt; val[2] += av.z * gt; val[3] += av.w * gt;
             }
           }
-          if constexpr (BNR) {  // dz of the BatchNorm -> Dropout -> PReLU backward on the bf16-rounded gradient (what the separate pass would read back)
-            const uint2 yr = bnyv[m][t];
-            const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16), __uint_as_float(yr.y & 0xffff0000u)};
-            const float4 bsc = *reinterpret_cast<const float4*>(epi + 3 * NT * 16 + cl), bsh = *reinterpret_cast<const float4*>(epi + 4 * NT * 16 + cl);
-            const float sc4[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sh4[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
-            const unsigned kb = bnkv[m][t] >> ((g & 1) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float gq = bf2f(f2bf(val[r]));
-              const float z = yv[r] * sc4[r] + sh4[r];
-              const bool kp = (kb >> r) & 1u;
-              const float dd = kp ? z * k.bn_inv_keep : 0.f;
-              const float dg = dd > 0.f ? gq : bn_alpha * gq;
-              if (dd < 0.f) bn_dal += gq * dd;
-              const float dz = kp ? dg * k.bn_inv_keep : 0.f;
-              ssum[t][r] += dz; ssq[t][r] += dz * yv[r];
-            }
-          }
           char* op = (c_base + t * 16 >= k.out_csplit ? k.out1 : k.out0) + vox * k.out_vox_bytes + c * (int)out_es;
           if (KIND != 2 || !k.out_f32) st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
           else st4(reinterpret_cast<float*>(op), make_float4(val[0], val[1], val[2], val[3]));
@@ -350,37 +303,6 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
     else epilogue(std::integral_constant<int, 2>{});
   }
 
-  if constexpr (BNR) {  // this workgroup's sum(dz), sum(dz*y) -> sum(dz), sum(dz*xhat) in fp64 -> the layer's sharded sums (layout of vsseg_bn_act_bwd_reduce)
-    __syncthreads();
-    float* red = epi;
-    for (int i = tid; i < 2 * NT * 16 + 1; i += 512) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = ssum[t][r], q = ssq[t][r];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l15 == 0) {
-          atomicAdd(&red[t * 16 + g * 4 + r], s);
-          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
-        }
-      }
-    bn_dal = wave_sum(bn_dal);
-    if (lane == 0) atomicAdd(&red[2 * NT * 16], bn_dal);
-    __syncthreads();
-    const int shard = (blockIdx.x + blockIdx.y * gridDim.x) % VSSEG_STAT_SHARDS;
-    double* st = k.bn_sums + (int64_t)shard * 3 * k.bn_stride;
-    for (int i = tid; i < NT * 16; i += 512) {
-      const int c = c_base + i;
-      if (c >= cout) continue;
-      const double s1 = (double)red[i], s2 = (double)red[NT * 16 + i];
-      atomicAdd(&st[c], s1);
-      atomicAdd(&st[k.bn_stride + c], (double)k.bn_invstd[c] * (s2 - (double)k.bn_mean[c] * s1));
-    }
-    if (tid == 0) atomicAdd(&k.bn_alpha_acc[shard], (double)red[2 * NT * 16]);
-  }
   if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics (layout of vsseg_igemm_desc.stats)
     __syncthreads();
     float* red = epi;
@@ -422,7 +344,6 @@ template <int NT, int MODE> static int cc_launch_mode(const CconvK& k, int nspli
   return VSSEG_OK;
 }
 template <int NT> static int cc_launch(const CconvK& k, int nsplit, hipStream_t s) {
-  if (k.bn_sums) return cc_launch_mode<NT, 3>(k, nsplit, s);
   if (k.stats) return cc_launch_mode<NT, 1>(k, nsplit, s);
   if (k.aux_mode) return cc_launch_mode<NT, 2>(k, nsplit, s);
   return cc_launch_mode<NT, 0>(k, nsplit, s);
@@ -498,19 +419,6 @@ int vsseg_cconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
   k.zeros = zeros;
-  k.bn_y = nullptr; k.bn_keep = nullptr; k.bn_scale = k.bn_shift = k.bn_mean = k.bn_invstd = k.bn_alpha = nullptr;
-  k.bn_sums = nullptr; k.bn_alpha_acc = nullptr; k.bn_y_vox_bytes = 0; k.bn_stride = 0; k.bn_inv_keep = 1.f;
-  if (d->bnred) {
-    const vsseg_bnred& b = *d->bnred;
-    VSSEG_CHECK(b.y && b.scale && b.shift && b.mean && b.invstd && b.alpha && b.sums && b.alpha_acc && b.stride >= d->out.c, "vsseg_igemm: incomplete bnred");
-    VSSEG_CHECK(d->out.dtype == VSSEG_BF16 && !d->out.ptr2 && !d->stats && !d->accumulate && d->res_mode == VSSEG_RES_NONE && !d->scale && d->act == VSSEG_ACT_NONE,
-                "vsseg_igemm: bnred needs a plain bf16 data-gradient launch whose whole one-part output is the layer's dA");
-    VSSEG_CHECK(b.p_drop >= 0.f && b.p_drop < 1.f && (b.p_drop == 0.f || b.keep), "vsseg_igemm: bnred with dropout needs the stored keep-mask");
-    k.bn_y = reinterpret_cast<const char*>(b.y); k.bn_y_vox_bytes = b.y_pitch * 2;
-    k.bn_keep = b.p_drop > 0.f ? b.keep : nullptr;
-    k.bn_scale = b.scale; k.bn_shift = b.shift; k.bn_mean = b.mean; k.bn_invstd = b.invstd; k.bn_alpha = b.alpha;
-    k.bn_sums = b.sums; k.bn_alpha_acc = b.alpha_acc; k.bn_stride = b.stride; k.bn_inv_keep = 1.f / (1.f - b.p_drop);
-  }
   k.act = d->act; k.cout = d->out.c;
   k.nch = d->nchunks;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];

@@ -400,8 +400,6 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   VSSEG_CHECK(blk > 0, "vsseg_bn_act_bwd_reduce: unsupported channel count %d", y.c);
   int64_t nv = tensor_voxels(y);
   BnBwdArgs a{mean, invstd, gamma, beta, scale, shift, alpha, p_drop, seed, salt};
-  static int unroll = -1;  // voxels in flight per thread (tuning aid: VSSEG_BN_REDUCE_U = 2 | 4)
-  if (unroll < 0) { const char* e = getenv("VSSEG_BN_REDUCE_U"); unroll = e ? atoi(e) : 2; }
   size_t lds = (size_t)((blk + 63) / 64) * (3 * y.c + 1) * sizeof(float);
   // Every workgroup ends with a flush (LDS reduction, then 3*C dependent fp64 adds into the sharded sums), and on everything but the largest
   // tensors that tail — paid once per wave of workgroups on a CU — costs as much as the streaming itself (measured: a 403 MB 32-channel tensor
@@ -410,17 +408,10 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   // atomics.  So the grid is sized by a flush budget (~64 K adds per launch beyond 16 channels: 682 workgroups at 32 channels, 455 at 48),
   // never below 384 workgroups and never with fewer than 16 voxel groups per thread.
   const int64_t items = nv * cgs;
-  static int budget = -1;  // tuning aid: VSSEG_BN_REDUCE_ATOMICS
-  if (budget < 0) { const char* e = getenv("VSSEG_BN_REDUCE_ATOMICS"); budget = e ? atoi(e) : 65536; }
+  const int budget = 65536;  // fp64 flush atomics per launch the grid is sized for (measured)
   const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(384, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 8 : budget / (3 * y.c))));
-  if (unroll == 2) {
-    int grid = grid_for((nv * cgs + 1) / 2, blk, cap);
-    DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
-    VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
-    return VSSEG_OK;
-  }
-  int grid = grid_for((nv * cgs + 3) / 4, blk, cap);
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 4>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
+  int grid = grid_for((nv * cgs + 1) / 2, blk, cap);  // 2 voxels in flight per thread (measured: 2 beats 4)
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }

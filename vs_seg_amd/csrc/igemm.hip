@@ -68,9 +68,7 @@ static int launch_nt(bool f32, const IgemmK& k, dim3 grid, int lds, hipStream_t 
 static const TileDesc* tile_table(const IgemmK& k, hipStream_t stream) {
   static std::map<std::vector<int64_t>, TileDesc*> cache;
   const vsseg_igemm_desc& d = k.d;
-  static int xb_env = -1;
-  if (xb_env < 0) { const char* e = getenv("VSSEG_TILE_XBAND"); xb_env = e ? atoi(e) : 0; }
-  int xb = xb_env > 0 ? xb_env : 128 / k.ntile[2];  // ~2 scheduling steps of one XCD per (band, y) row
+  int xb = 128 / k.ntile[2];  // ~2 scheduling steps of one XCD per (band, y) row
   xb = xb < 1 ? 1 : (xb > k.ntile[0] ? k.ntile[0] : xb);
   std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles, xb};
   for (int a = 0; a < 3; ++a) { key.push_back(d.q[a]); key.push_back(d.tile[a]); key.push_back(d.is[a]); key.push_back(d.os[a]); key.push_back(d.oo[a]); key.push_back(k.off_min[a]); key.push_back(k.halo[a]); }
@@ -94,7 +92,6 @@ static const void* zero_page() {
 static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d && d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
   VSSEG_CHECK(d->in.dtype == VSSEG_F32 || d->in.dtype == VSSEG_BF16, "vsseg_igemm: bad input dtype");
-  VSSEG_CHECK(!d->bnred, "vsseg_igemm: the fused BatchNorm-backward reduction (bnred) needs a streaming / compute kernel plan (depth -2 / -3)");
   VSSEG_CHECK(d->ntaps >= 1 && d->ntaps <= VSSEG_MAX_TAPS, "vsseg_igemm: ntaps %d out of range", d->ntaps);
   VSSEG_CHECK(d->ck >= 8 && d->ck % 8 == 0 && d->nchunks >= 1, "vsseg_igemm: bad channel chunking ck=%d nchunks=%d", d->ck, d->nchunks);
   VSSEG_CHECK(d->in.c % 8 == 0 && d->in.pitch % 8 == 0, "vsseg_igemm: input channels/pitch must be multiples of 8 (c=%d pitch=%d)", d->in.c, d->in.pitch);

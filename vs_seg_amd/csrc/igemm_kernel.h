@@ -120,11 +120,7 @@ typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 // 16-byte LDS-DMA: LDS address = wave-uniform `lds_wave_base` + lane*16, global address per lane
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_wave_base) {
-#ifdef VSSEG_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((gvoid_t*)gsrc, (lvoid_t*)lds_wave_base, 16, 0, 0);
-#else
   vsseg_dma16(gsrc, lds_wave_base);  // inline assembly: see common.h (the builtin made hipcc drain the DMA queue in front of every K loop)
-#endif
 }
 
 // s_waitcnt vmcnt(n) with a run-time (wave-uniform) n: the immediate must be a literal.  Waiting for a SMALLER count than
@@ -771,10 +767,6 @@ template <typename T, int NT, int MTW, int MODE, int KS = 0> static int launch_m
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igemm_kernel<T, NT, MTW, MODE, KS>, ig_spec(NT) ? 512 : 256, lds) != hipSuccess || n < 1) n = 1;
     cached_per_cu = n > 6 ? 6 : n;
     cached_lds = lds;
-    if (const char* e = getenv("VSSEG_IG_PERCU")) {  // tuning aid: cap the resident workgroups per CU (occupancy scaling experiments)
-      const int cap = atoi(e);
-      if (cap > 0 && cap < cached_per_cu) cached_per_cu = cap;
-    }
   }
   int64_t gx = 256ll * cached_per_cu;
   if (gx > k.total_tiles) gx = k.total_tiles;

@@ -344,7 +344,6 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
   if (d->stats && (d->accumulate || d->res_mode != VSSEG_RES_NONE)) return no("statistics combined with a residual");
   if (d->accumulate && d->res_mode != VSSEG_RES_NONE) return no("accumulate combined with a residual");
-  if (d->bnred) return no("no fused BatchNorm-backward reduction in the marching kernel");
   if (d->accumulate || d->res_mode != VSSEG_RES_NONE) {
     const vsseg_tensor& a = d->accumulate ? d->out : d->res;
     if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");

@@ -49,12 +49,6 @@ struct SconvK {
   unsigned mg_tz, mg_ty, mg_tx;  // ceil(2^32 / d): exact quotients by one s_mul_hi_u32
   int tiles, per_xcd, walk;
   int ps_cls0, ps_tpc_shift;  // fused output-parity classes (taps 4): first class of the launch, log2(channel tiles per class)
-  // fused BatchNorm-backward reduction over the output (MODE 3; vsseg_bnred)
-  const char* bn_y; const unsigned char* bn_keep;
-  const float *bn_scale, *bn_shift, *bn_mean, *bn_invstd, *bn_alpha;
-  double* bn_sums; double* bn_alpha_acc;
-  int bn_y_vox_bytes, bn_stride;
-  float bn_inv_keep;
 };
 
 template <int G> __device__ __forceinline__ int sc_swz(int hy, int hz) {
@@ -65,11 +59,10 @@ template <int G> __device__ __forceinline__ int sc_swz(int hy, int hz) {
 }
 __device__ __forceinline__ unsigned sc_div(unsigned n, unsigned magic, unsigned d) { return magic ? __umulhi(n, magic) : n; }  // magic 0: d == 1
 
-// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16), 3 + first pass of the BatchNorm backward of the layer whose output
-// gradient this launch produces (vsseg_bnred) — registers are spent only on what a launch uses
+// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16) — registers are spent only on what a launch uses
 template <int CIN, int NT, int TAPS, int MODE>
 __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const SconvK k) {
-  constexpr bool STATS = MODE == 1, AUXM = MODE == 2, BNR = MODE == 3;
+  constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
   constexpr int G = CIN / 8, CINB = CIN * 2;
   // TAPS 9: 3x3x1 stencil (halo 1 on both sides); 1: 1x1x1; 4: the 2x2x1 neighbourhood (+0 / +1) of the FUSED output-parity classes of a
   // stride-2 transposed convolution / stride-2 data gradient ("pixel shuffle", PS): the launch runs on the coarse lattice, output channel tile
@@ -96,13 +89,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     epi[i] = ((ok && k.bias) ? k.bias[cv] : 0.f) + ((ok && k.bias2) ? k.bias2[cv] : 0.f);
     epi[NT * 16 + i] = (ok && k.scale) ? k.scale[cv] : 1.f;
     epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[cv] : 0.f;
-    if constexpr (BNR) {
-      epi[3 * NT * 16 + i] = ok ? k.bn_scale[i] : 0.f;
-      epi[4 * NT * 16 + i] = ok ? k.bn_shift[i] : 0.f;
-    }
   }
-  const float bn_alpha = BNR ? *k.bn_alpha : 0.f;
-  float bn_dal = 0.f;
   const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
 
   // ---- this thread's DMA pieces: LDS slot j = (u*4 + wave)*64 + lane holds piece (halo voxel j / G, 16-byte group (j % G) ^ swizzle) ----
@@ -135,9 +122,9 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
   const int ekind = !simple ? 2 : (k.aux_mode == 3 ? 1 : 0);
   const float alpha_eff = k.act == VSSEG_ACT_PRELU ? alpha : 1.f;
   const char* Wlane = Wl + lane * 16;
-  float ssum[(STATS || BNR) ? NT : 1][4], ssq[(STATS || BNR) ? NT : 1][4];  // STATS: sum / sum of squares of the output; BNR: sum(dz) / sum(dz * y)
+  float ssum[STATS ? NT : 1][4], ssq[STATS ? NT : 1][4];  // sum / sum of squares of the output
 #pragma unroll
-  for (int t = 0; t < ((STATS || BNR) ? NT : 1); ++t)
+  for (int t = 0; t < (STATS ? NT : 1); ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wgs = gridDim.x >> 3;
@@ -202,20 +189,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
       }
     }
     // fused BatchNorm-backward reduction: the layer's pre-activation and keep-mask byte for this lane's output elements
-    uint2 bnyv[BNR ? MT : 1][BNR ? NT : 1];
-    unsigned bnkv[BNR ? MT : 1][BNR ? NT : 1];
-    if constexpr (BNR) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int64_t vox = ovox + ov0 + (unsigned)((m & 1) * 4 * Z + (m >> 1) * Y * Z);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int c = t * 16 + g * 4;
-          bnyv[m][t] = *reinterpret_cast<const uint2*>(k.bn_y + vox * k.bn_y_vox_bytes + c * 2);
-          bnkv[m][t] = k.bn_keep ? (unsigned)k.bn_keep[vox * (cout >> 3) + (c >> 3)] : 0xffu;
-        }
-      }
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -287,24 +260,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
               val[0] += av.x * gt; val[1] += av.y * gt; val[2] += av.z * gt; val[3] += av.w * gt;
             }
           }
-          if constexpr (BNR) {  // dz of the BatchNorm -> Dropout -> PReLU backward on the bf16-rounded gradient (what the separate pass would read back)
-            const uint2 yr = bnyv[m][t];
-            const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u), __uint_as_float(yr.y << 16), __uint_as_float(yr.y & 0xffff0000u)};
-            const float4 bsc = *reinterpret_cast<const float4*>(epi + 3 * NT * 16 + c), bsh = *reinterpret_cast<const float4*>(epi + 4 * NT * 16 + c);
-            const float sc4[4] = {bsc.x, bsc.y, bsc.z, bsc.w}, sh4[4] = {bsh.x, bsh.y, bsh.z, bsh.w};
-            const unsigned kb = bnkv[m][t] >> ((g & 1) * 4);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float gq = bf2f(f2bf(val[r]));
-              const float z = yv[r] * sc4[r] + sh4[r];
-              const bool kp = (kb >> r) & 1u;
-              const float dd = kp ? z * k.bn_inv_keep : 0.f;
-              const float dg = dd > 0.f ? gq : bn_alpha * gq;
-              if (dd < 0.f) bn_dal += gq * dd;
-              const float dz = kp ? dg * k.bn_inv_keep : 0.f;
-              ssum[t][r] += dz; ssq[t][r] += dz * yv[r];
-            }
-          }
           char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + out_vox(m, t) * k.out_vox_bytes + out_ch(t) * (int)out_es;
           if constexpr (KIND != 2) {
             st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
@@ -326,36 +281,6 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     else epilogue(std::integral_constant<int, 2>{});
   }
 
-  if constexpr (BNR) {  // this workgroup's sum(dz), sum(dz*y) -> sum(dz), sum(dz*xhat) in fp64 -> the layer's sharded sums (layout of vsseg_bn_act_bwd_reduce)
-    __syncthreads();
-    float* red = epi;
-    for (int i = tid; i < 2 * NT * 16 + 1; i += 256) red[i] = 0.f;
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = ssum[t][r], q = ssq[t][r];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        if (l15 == 0) {
-          atomicAdd(&red[t * 16 + g * 4 + r], s);
-          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
-        }
-      }
-    bn_dal = wave_sum(bn_dal);
-    if (lane == 0) atomicAdd(&red[2 * NT * 16], bn_dal);
-    __syncthreads();
-    const int shard = blockIdx.x % VSSEG_STAT_SHARDS;
-    double* st = k.bn_sums + (int64_t)shard * 3 * k.bn_stride;
-    for (int c = tid; c < NT * 16; c += 256) {
-      if (c >= cout) continue;
-      const double s1 = (double)red[c], s2 = (double)red[NT * 16 + c];
-      atomicAdd(&st[c], s1);
-      atomicAdd(&st[k.bn_stride + c], (double)k.bn_invstd[c] * (s2 - (double)k.bn_mean[c] * s1));
-    }
-    if (tid == 0) atomicAdd(&k.bn_alpha_acc[shard], (double)red[2 * NT * 16]);
-  }
   if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics (layout of vsseg_igemm_desc.stats)
     __syncthreads();
     float* red = epi;
@@ -396,10 +321,6 @@ template <int CIN, int NT, int TAPS, int MODE> static int sc_launch_mode(const S
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sconv_kernel<CIN, NT, TAPS, MODE>, 256, lds) != hipSuccess || n < 1) n = 1;
     per_cu = n > 3 ? 3 : n;  // measured: 3 resident workgroups per CU stream fastest; more only spread the DRAM pages in flight
-    if (const char* e = getenv("VSSEG_SCONV_PERCU")) {
-      const int cap = atoi(e);
-      if (cap > 0 && cap <= n) per_cu = cap;
-    }
   }
   int grid = 256 * per_cu;
   const int need = (k.tiles + 7) / 8 * 8;
@@ -409,10 +330,6 @@ template <int CIN, int NT, int TAPS, int MODE> static int sc_launch_mode(const S
   return VSSEG_OK;
 }
 template <int CIN, int NT, int TAPS> static int sc_launch(const SconvK& k, hipStream_t s) {
-  if (k.bn_sums) {
-    if constexpr (NT <= 2 && TAPS == 9 && CIN >= 16 && CIN <= 32) return sc_launch_mode<CIN, NT, TAPS, 3>(k, s);  // the data gradients of the intra-unit 3x3x1 convolutions
-    else { vsseg_set_error("vsseg_igemm: no streaming-kernel instantiation with the fused BatchNorm-backward reduction for this shape"); return VSSEG_EINVAL; }
-  }
   if (k.stats) return sc_launch_mode<CIN, NT, TAPS, 1>(k, s);
   if (k.aux_mode) return sc_launch_mode<CIN, NT, TAPS, 2>(k, s);
   return sc_launch_mode<CIN, NT, TAPS, 0>(k, s);
@@ -441,7 +358,7 @@ static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {
     if ((d->out.c == 16 && d->oo[0] != 0) || (unsigned)d->oo[0] > 1u) return no("pixel-shuffle class offset");
     for (int t = 0; t < 4; ++t)
       if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
-    if (d->res_mode != VSSEG_RES_NONE || d->bnred) return no("pixel-shuffle launches support statistics or accumulate only");
+    if (d->res_mode != VSSEG_RES_NONE) return no("pixel-shuffle launches support statistics or accumulate only");
   } else {
     for (int a = 0; a < 3; ++a)
       if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
@@ -514,19 +431,6 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
   k.zeros = zeros;
-  k.bn_y = nullptr; k.bn_keep = nullptr; k.bn_scale = k.bn_shift = k.bn_mean = k.bn_invstd = k.bn_alpha = nullptr;
-  k.bn_sums = nullptr; k.bn_alpha_acc = nullptr; k.bn_y_vox_bytes = 0; k.bn_stride = 0; k.bn_inv_keep = 1.f;
-  if (d->bnred) {
-    const vsseg_bnred& b = *d->bnred;
-    VSSEG_CHECK(b.y && b.scale && b.shift && b.mean && b.invstd && b.alpha && b.sums && b.alpha_acc && b.stride >= d->out.c, "vsseg_igemm: incomplete bnred");
-    VSSEG_CHECK(d->out.dtype == VSSEG_BF16 && !d->out.ptr2 && d->out.c % 8 == 0 && d->out.c == d->nt * 16 && !d->stats && !d->accumulate && d->res_mode == VSSEG_RES_NONE && d->cout_mod == 0 && !d->scale && d->act == VSSEG_ACT_NONE,
-                "vsseg_igemm: bnred needs a plain bf16 data-gradient launch whose whole one-part output is the layer's dA");
-    VSSEG_CHECK(b.p_drop >= 0.f && b.p_drop < 1.f && (b.p_drop == 0.f || b.keep), "vsseg_igemm: bnred with dropout needs the stored keep-mask");
-    k.bn_y = reinterpret_cast<const char*>(b.y); k.bn_y_vox_bytes = b.y_pitch * 2;
-    k.bn_keep = b.p_drop > 0.f ? b.keep : nullptr;
-    k.bn_scale = b.scale; k.bn_shift = b.shift; k.bn_mean = b.mean; k.bn_invstd = b.invstd; k.bn_alpha = b.alpha;
-    k.bn_sums = b.sums; k.bn_alpha_acc = b.alpha_acc; k.bn_stride = b.stride; k.bn_inv_keep = 1.f / (1.f - b.p_drop);
-  }
   k.act = d->act; k.cout = d->depth == -4 ? d->nt * 16 : d->out.c; k.cout_mod = d->cout_mod;
   k.ps_cls0 = d->depth == -4 ? 2 * d->oo[0] : 0;
   k.ps_tpc_shift = (d->depth == -4 && d->out.c == 32) ? 1 : 0;
@@ -535,6 +439,6 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.mg_tx = magic(k.ntx); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);
   k.tiles = d->in.n * k.ntx * k.nty * k.ntz;
   k.per_xcd = (k.tiles + 7) / 8;
-  { static int walk = -1; if (walk < 0) { const char* e = getenv("VSSEG_SCONV_WALK"); walk = e ? atoi(e) : 1; } k.walk = walk; }
+  k.walk = 1;
   return e->fn(k, s);
 }

@@ -39,11 +39,7 @@ struct WgradK {
 typedef __attribute__((address_space(1))) const void wg_gvoid_t;
 typedef __attribute__((address_space(3))) void wg_lvoid_t;
 __device__ __forceinline__ void wg_dma16(const void* gsrc, char* lds_wave_base) {  // LDS address = wave-uniform base + lane*16
-#ifdef VSSEG_DMA_BUILTIN
-  __builtin_amdgcn_global_load_lds((wg_gvoid_t*)gsrc, (wg_lvoid_t*)lds_wave_base, 16, 0, 0);
-#else
   vsseg_dma16(gsrc, lds_wave_base);  // inline assembly: see common.h (the builtin made hipcc wait for tile s+1 before multiplying tile s)
-#endif
 }
 constexpr int WPP = 12;  // 16-byte pieces of the P tile per thread  (P tile <= 48 KiB)
 constexpr int WPH = 16;  // ... of the H halo tile per thread         (halo    <= 64 KiB)
@@ -516,7 +512,7 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   const int64_t cap = d->scratch_elems / ((int64_t)hchunks * k.slab_chunk);
   if (gx > cap) gx = cap;
   k.slab = d->scratch;
-  { static int walk = -1; if (walk < 0) { const char* e = getenv("VSSEG_WGRAD_WALK"); walk = e ? atoi(e) : 1; } k.walk = walk; }
+  k.walk = 1;
   if (k.wv != 1) hipMemsetAsync(d->scratch, 0, sizeof(float) * gx * hchunks * k.slab_chunk, as_stream(stream));
   dim3 grid((unsigned)gx, (unsigned)(hchunks / hg));
   int rc = d->p.dtype == VSSEG_F32 ? vsseg_wgrad_launch_f32(k, maxt, hg, grid, off, as_stream(stream)) : vsseg_wgrad_launch_bf16(k, maxt, hg, grid, off, as_stream(stream));

@@ -109,8 +109,6 @@ class _ConvPlans:
     dgrad: List[_Choice]
     wgrad: Optional[P.WgradPlan]
     fold_fwd: bool = False
-    fold_dgrad: bool = False
-    direct_fwd: bool = False  # forward runs as the direct 1-channel stencil (vsseg_conv1ch_fwd), not as an igemm launch
 
 
 class _Slot:
@@ -262,20 +260,16 @@ class Plan:
             # convolution 16->1 drops from 0.51 to 0.33 ms (its input is read as 128 real channels, the 1-channel map is written as
             # 32-byte rows).  On the narrow-INPUT side (network input 1->16, dY of the sigmoid conv) the folded output rows are 256 B
             # wide and every 16-channel N-tile stores 32-byte fragments of them: 0.46 -> 0.50 ms and 0.51 -> 0.70 ms, so those stay unfolded.
-            wide_n = eng.fold_all
-            fold_fwd = can_fold and (Lr.cout == 1 or (wide_n and op.x.root.name == eng.prog.input.name))
+            fold_fwd = can_fold and Lr.cout == 1
             fwd = choices(kind, Lr, dims_in if Lr.transposed else dims_out, op.x.c, aux_es, op.x.parts[0].c if op.x.parts else 0, absorbed, fold=fold_fwd)
-            dgrad, wg, fold_dgrad = [], None, False
+            dgrad, wg = [], None
             if self.train:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
                     q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                    fold_dgrad = wide_n and can_fold and Lr.cout == 1 and getattr(op, "act", "") == "sigmoid"  # dY of the sigmoid convolution is written compactly by att_apply_bwd
-                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed, fold=fold_dgrad)
+                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
-            direct = (eng.direct1 and not fold_fwd and absorbed is None and op.res is None and not Lr.transposed and Lr.cin == 1 and Lr.cout % 8 == 0 and Lr.kernel in ((3, 3, 1), (1, 1, 1))
-                      and tuple(Lr.stride) == (1, 1, 1) and dims_in[2] % 4 == 0 and op.x.root.name == eng.prog.input.name and op.out.base is None and getattr(op, "act", "none") == "none")
-            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd, fold_dgrad, direct)
+            self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd)
 
     def _register(self, ch: _Choice, pl: P.IgemmPlan):
         """Append the chosen plan's weight gather map(s) to the step's pack list."""
@@ -313,7 +307,7 @@ class Plan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
-               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|bnr" if bool(d.bnred) else ""))
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}")
         cache = _tune_cache()
         hit = cache.get(key)
         if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
@@ -373,26 +367,16 @@ class Plan:
         return r
 
     def _igemm_classes(self, lst, chs: List[_Choice], inp: L.Tensor, out: L.Tensor, *, res: Optional[L.Tensor] = None, **kw):
-        """All lattice classes of one convolution (the output-parity classes of a transposed convolution / of a strided data gradient: each
-        is its own launch and reads the WHOLE input: 2-3x the algorithmic bytes, profiles/r02_pmc_hbm.txt).  VSSEG_CLASS_INTERLEAVE=1 launches
-        them sample by sample, classes innermost, so that one sample of the input (25-100 MB) could be re-read out of the 256 MB memory-side
-        cache — measured SLOWER (36.4 -> 38.9 ms per step: four times the launches, each with its own weight staging and tail) and left off;
-        the fix is one launch for all classes."""
-        if len(chs) > 1 and self.n > 1 and self.eng.class_interleave and kw.get("gate", 0) == 0:
-            for b in range(self.n):
-                for ch in chs:
-                    self._igemm(lst, ch, self._sample(inp, b), self._sample(out, b), res=self._sample(res, b), nb=1, **kw)
-        else:
-            for ch in chs:
-                self._igemm(lst, ch, inp, out, res=res, **kw)
+        """All lattice classes of one convolution (the output-parity classes of a transposed convolution / of a strided data gradient): each is
+        its own launch and reads the WHOLE input (the stride-(2,2,1) transitions of levels 0-2 run all classes in one streaming-kernel launch
+        instead, planner.shuffle_plans)."""
+        for ch in chs:
+            self._igemm(lst, ch, inp, out, res=res, **kw)
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, bnred: Optional[L.BnRed] = None):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None):
         nb = self.n if nb is None else nb
         d = L.IgemmDesc()
-        if bnred is not None:  # fused first pass of the BatchNorm backward of the layer whose output gradient this launch produces
-            self.keep.append(bnred)
-            d.bnred = C.pointer(bnred)
         d.gate = gate or None
         if ch.fold:
             inp, out, res = self._fold_desc(inp, ch.fold), self._fold_desc(out, ch.fold), (self._fold_desc(res, ch.fold) if res is not None else None)
@@ -419,8 +403,6 @@ class Plan:
         if pl.depth == -4:
             nvalid = nb * out.x * out.y * out.z * (pl.nt * 16 // pl.nc) // 4  # the parity classes this launch writes
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
-        if bnred is not None:
-            accumulate = 1  # metadata only: the launch reads one more output-sized tensor (the layer's pre-activation)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
         meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma", flops=2.0 * nvalid * (2.25 if pl.depth == -4 else pl.ntaps) * pl.kreal * pl.nc / max(ch.fold, 1),
@@ -492,31 +474,6 @@ class Plan:
                     if pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None:
                         res1_fused[pr.layer.prefix] = pr
 
-        # BatchNorm layers whose output has exactly ONE consumer, a stride-1 convolution: that convolution's data gradient is the only
-        # producer of the layer's output gradient dA and can run the first pass of the layer's backward (sum(dz), sum(dz*xhat), PReLU-slope
-        # term) in its epilogue — vsseg_bnred, streaming / compute kernel plans only.  Intra-unit links
-        # unit0 -> unit1 of the encoder ResidualUnits.
-        uses: Dict[str, list] = {}
-        for op in ops:
-            if isinstance(op, (ConvBnAct, ConvPlain)):
-                for t in (op.x.parts or (op.x,)):
-                    uses.setdefault(t.root.name, []).append(("x" if op.x.parts is None else "part", op))
-                if op.res is not None:
-                    uses.setdefault(op.res.root.name, []).append(("res", op))
-            elif isinstance(op, AttGate):
-                for t in (op.x.parts or (op.x,)):
-                    uses.setdefault(t.root.name, []).append(("gate", op))
-                uses.setdefault(op.att.root.name, []).append(("att", op))
-        self.bnred_of: Dict[str, ConvBnAct] = {}  # consumer convolution prefix -> the BatchNorm layer in front of it
-        self.bnred_done: set = set()
-        if self.train and eng.bnred and eng.es == 2 and self.tune and (p_drop == 0.0 or eng.keepmask):
-            for opb in ops:
-                if not isinstance(opb, ConvBnAct) or opb.out.base is not None:
-                    continue
-                u = uses.get(opb.out.root.name, [])
-                if len(u) == 1 and u[0][0] == "x" and not u[0][1].layer.transposed and tuple(u[0][1].layer.stride) == (1, 1, 1) and u[0][1].x is opb.out:
-                    self.bnred_of[u[0][1].layer.prefix] = opb
-
         # ---- forward
         F = self.fwd
         grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
@@ -528,19 +485,7 @@ class Plan:
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
-                if cp.direct_fwd:  # one-channel network input: direct stencil instead of an MFMA launch on a zero-extended K-group
-                    x1 = self._xdesc(op.x, True)
-                    dt = L.BF16 if eng.es == 2 else L.F32
-                    if self.train:
-                        yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                        F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None, yd, sptr(0, pre), cpad[pre]]])
-                        F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
-                                                          self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
-                        F.append([lib.vsseg_bn_act_fwd, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], L.Tensor(), 0, out, keep_ptr(Lr)], self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout)])
-                    else:
-                        self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])
-                        F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, dt, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), vptr(2, pre), vptr(3, pre), alp, out, None, 0]])
-                elif self.train:
+                if self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
                     self._igemm_classes(F, cp.fwd, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
@@ -561,11 +506,6 @@ class Plan:
                 if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
-                if cp.direct_fwd:
-                    x1 = self._xdesc(op.x, True)
-                    F.append([lib.vsseg_conv1ch_fwd, [x1.ptr, L.BF16 if eng.es == 2 else L.F32, self.n, L.i3(self.lv[Lr.level]), self._pp(Lr.wkey), self._pp(Lr.bkey), L.i3(Lr.kernel), None, None, None,
-                                                      self._desc(op.out), None, 0]])
-                    continue
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for ch in cp.fwd:
@@ -575,7 +515,7 @@ class Plan:
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)], self._ew_meta("att_apply_fwd", op.x.level, 2 * op.x.c + 2)])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
-        if any((not self.cplans[op.layer.prefix].fold_fwd) and (not self.cplans[op.layer.prefix].direct_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
+        if any((not self.cplans[op.layer.prefix].fold_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
                and op.x.root.name == prog.input.name for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
             self.needs_padded_input = True
         self.out_logits = self._alloc(prog.logits, self.bufs)
@@ -747,19 +687,6 @@ class Plan:
 
         def conv_backward_data(Lr: Layer, x: TensorSpec, dy: L.Tensor, relumask, dy_compact, gate):
             cp = self.cplans[Lr.prefix]
-            opb = self.bnred_of.get(Lr.prefix)
-            if opb is not None and len(cp.dgrad) == 1 and gate is None and relumask is None and not cp.dgrad[0].fold:
-                ch0 = cp.dgrad[0]
-                spec = [c for c in ch0.cands if c.depth == -3 or (c.depth == -2 and c.nt <= 2 and c.ntaps == 9 and c.kc in (16, 32))]
-                if spec:
-                    lb, pb = opb.layer, opb.layer.prefix
-                    acc = contribution(x)
-                    assert acc == 0, "a fused BatchNorm reduction needs the only contribution to the gradient"
-                    br = L.BnRed(self.bufs["y:" + pb].data_ptr(), lb.cout, keep_ptr(lb), vptr(2, pb), vptr(3, pb), vptr(0, pb), vptr(1, pb), self._pp(pb + ".act.weight"), p_drop, sptr(1, pb), cpad[pb], aptr(pb))
-                    fused = _Choice(spec, ch0.woff, ch0.wshape2, ch0.woff2, wshape=ch0.wshape)
-                    self._igemm(B, fused, dy, gdesc(x), bnred=br)
-                    self.bnred_done.add(pb)
-                    return
             if cp.dgrad:
                 acc = contribution(x)
                 gx = gdesc(x)
@@ -783,8 +710,7 @@ class Plan:
                 yd = self._tdesc(self.bufs["y:" + pre], Lr.out_level)
                 dA = grad_of_out(op.out)
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
-                if pre not in self.bnred_done:  # else: reduced in the epilogue of the launch that produced dA
-                  B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre), keep_ptr(Lr)],
+                B.append([lib.vsseg_bn_act_bwd_reduce, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], sptr(1, pre), cpad[pre], aptr(pre), keep_ptr(Lr)],
                           self._ew_meta("bn_act_bwd_reduce", Lr.out_level, 2 * Lr.cout)])
                 dres_bias = None
                 if op.res is not None and op.res.name in producer:  # residual conv: d(out)/d(res) = 1, its bias gradient is sum(dA) (reduced above)
@@ -829,7 +755,7 @@ class Plan:
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
                 sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
                 folded_bias.add(sig.prefix)
-                want_c1 = self.cplans[sig.prefix].fold_dgrad or (eng.narrow_wgrad and sig.kernel in ((3, 3, 1), (1, 1, 1)) and sig.cin in (8, 16, 32, 64) and self.lv[sig.level][1] % 4 == 0)
+                want_c1 = (eng.narrow_wgrad and sig.kernel in ((3, 3, 1), (1, 1, 1)) and sig.cin in (8, 16, 32, 64) and self.lv[sig.level][1] % 4 == 0)
                 dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if want_c1 else None  # compact copy of d(pre-sigmoid): z-folded data gradient / narrow weight gradient
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
                 B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
@@ -908,10 +834,7 @@ class Plan:
         stream at the end of the list.  Under hipGraph capture the fork / join events become graph edges."""
         side = None
         overlap = self.eng.overlap
-        skip_side = os.environ.get("VSSEG_EXPERIMENT_SKIP_SIDE") == "1"
         for rec in lst:
-            if skip_side and len(rec) > 2 and rec[2].get("side"):
-                continue
             if overlap and len(rec) > 2 and rec[2].get("side"):
                 main = torch.cuda.current_stream()
                 if side is None:
@@ -968,18 +891,9 @@ class Engine:
             raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
         self.device = flat.device
         self.dry_run = dry_run
-        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launches (planner.FOLD); 0 disables, "all" also folds the narrow-input side
-        self.fold_all = os.environ.get("VSSEG_ZFOLD", "1") == "all"
-        # 1-channel-input convolutions as a direct VALU stencil (vsseg_conv1ch_fwd).  Off by default: measured 0.58 ms against 0.46 ms for the
-        # zero-extended MFMA launch on the full-resolution 1->16 3x3x1 layer (the stencil is issue-bound at ~16 % VALU utilisation).
-        self.direct1 = os.environ.get("VSSEG_DIRECT1", "0") == "1"
+        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launch of the attention sigmoid convolutions (planner.FOLD); 0 disables
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
-        self.class_interleave = os.environ.get("VSSEG_CLASS_INTERLEAVE", "0") == "1" and not dry_run  # experiment, off: multi-class convolutions launched sample by sample (measured 36.4 -> 38.9 ms per step)
         self.tune_reps = int(os.environ.get("VSSEG_TUNE_REPS", "5"))  # timed launches per candidate plan (best of)
-        # first pass of the BatchNorm backward fused into the producer of its output gradient (vsseg_bnred).  Correct (tests) but measured SLOWER than
-        # the separate pass, 36.4-36.6 -> 36.8 ms per step: the reduce kernel streams its two tensors at 5.2 TB/s, the convolution that takes over
-        # one of those reads runs at 3.5-4.5 TB/s and pays the dz arithmetic in its epilogue.  Off by default
-        self.bnred = os.environ.get("VSSEG_BNRED", "0") == "1"
         self.fuse_classes = os.environ.get("VSSEG_FUSE_CLASSES", "1") != "0" and not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
