@@ -92,6 +92,8 @@ typedef struct {
    * real channel c % cout_mod for bias / bias2 / scale / shift / stats.  0: off. */
   int32_t cout_mod;
   const float* gate;       /* VSSEG_RES_GATE: fp32 attention map [N][X][Y][Z] of the output tensor, or NULL */
+  const float* in_gate;    /* fp32 attention map [N][X][Y][Z] of the INPUT tensor, or NULL: input voxel v is multiplied by (1 + in_gate[v]) on load
+                            * (AttentionBlock2 folded into the convolution that reads its output; marching kernel, depth -5, only) */
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
@@ -117,6 +119,8 @@ typedef struct {
   float* dbias_p;          /* optional: dbias_p[cP] += sum_q P[q][cP] (bias gradient of a convolution without BatchNorm, P = dY) or NULL */
   int32_t march;           /* 1: the marching kernel (csrc/mwgrad.hip; stride-1 3x3x1 bf16 only, outside its domain is an error): tile = (x steps per
                             * workgroup, rows per workgroup, z slices per workgroup in {2, 4, 8}); persistent_blocks / single_buffer / hgroup unused */
+  const float* h_gate;     /* march = 1 only: fp32 attention map [N][X][Y][Z] of H, or NULL: H[v] is multiplied by (1 + h_gate[v]) on load (the gated
+                            * tensor `att.repeat(C) * x + x` of AttentionBlock2 as the convolution input, never materialised) */
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);

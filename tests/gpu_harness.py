@@ -91,7 +91,7 @@ def run_lattice_op(kind, w, x_cl, out_cl, stride, **epi):
     return keep
 
 
-def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid, hgroup=0, single_buffer=0, march_tile=None, dbias=None):
+def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid, hgroup=0, single_buffer=0, march_tile=None, dbias=None, h_gate=None):
     lib = L.lib()
     es = p_cl.element_size()
     wp = P.plan_wgrad(transposed, wshape, kernel, stride, tuple(p_cl.shape[1:4]), es)
@@ -111,6 +111,8 @@ def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid
         d.march, d.tile = 1, L.i3(march_tile)
     if dbias is not None:
         d.dbias_p = dbias.data_ptr()
+    if h_gate is not None:
+        d.h_gate = h_gate.data_ptr()
     scr = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device="cuda")
     d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
     L.check(lib.vsseg_wgrad(C.byref(d), stream()), "wgrad")

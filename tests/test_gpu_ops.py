@@ -576,6 +576,52 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
             np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dims,split,shape,lx", [((7, 128, 4), 16, (2, 4), 3), ((6, 64, 8), 16, (4, 4), 6), ((5, 64, 8), 0, (4, 2), 2)])
+def test_attention_gate_on_load_equals_materialised_gate(dims, split, shape, lx):
+    """in_gate / h_gate: the marching convolution and the marching weight gradient multiply the input voxels by (1 + att) in LDS (AttentionBlock2,
+    ref:params/networks/blocks/attentionblock.py:43-47) instead of reading a gated tensor written by vsseg_att_apply_fwd.  The forward must be
+    BIT-IDENTICAL to the same marching launch on the materialised tensor (same fp32 product, same bf16 rounding), the weight gradient too."""
+    lib = L.lib()
+    cin, cout, k = 32, 2, (3, 3, 1)
+    torch.manual_seed(13)
+    x_cl = H.to_cl(_round(torch.randn(2, cin, *dims), "bf16"), torch.bfloat16)
+    att = torch.rand(2, *dims, device="cuda")
+    gated = torch.empty_like(x_cl)
+    L.check(lib.vsseg_att_apply_fwd(H.tdesc(x_cl), att.data_ptr(), H.tdesc(gated), H.stream()), "att_apply_fwd")
+    w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, "bf16")
+    b = torch.randn(cout).cuda()
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    tz, mtw = shape
+    mp = [pl for pl in P.march_plans("conv_fwd", tuple(w.shape), cls, dims, 2, cin, cout, cin, n=2) if (pl.tile[2], pl.mtw) == (tz, mtw)][0]
+    mp = dataclasses.replace(mp, tile=(lx, mp.tile[1], tz))
+    mp.pack_map = P.pack_map(mp, tuple(w.shape))
+    wp = H.pack(mp, w, torch.bfloat16)
+    parts = H._split_cl(x_cl, split) if split else None  # (kept alive: the descriptor holds raw pointers)
+    xin = H.two_part(*parts) if split else H.tdesc(x_cl)
+    outs = []
+    for inp, kw in ((H.tdesc(gated), {}), (xin, dict(in_gate=att.data_ptr()))):
+        out = torch.zeros(2, *dims, cout, dtype=torch.float32, device="cuda")
+        d = H.igemm_desc(mp, wp, inp, H.tdesc(out), bias=b.data_ptr(), **kw)
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    # the general kernel refuses the field loudly
+    gen = P.plan_igemm("conv_fwd", tuple(w.shape), cls, dims, 2, kc_pad=cin, in_split=split)
+    gen.pack_map = P.pack_map(gen, tuple(w.shape))
+    d = H.igemm_desc(gen, H.pack(gen, w, torch.bfloat16), xin, H.tdesc(outs[0]), in_gate=att.data_ptr())
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) != 0 and b"in_gate" in lib.vsseg_last_error()
+    # weight gradient: P = dY of the 2 logits channels stored as one 8-channel group
+    gy = torch.zeros(2, *dims, 8, device="cuda")
+    gy[..., :cout] = torch.randn(2, *dims, cout, device="cuda")
+    gy = gy.to(torch.bfloat16)
+    tile = (lx, 32 if dims[0] == 5 else 64, 4)  # the gated weight gradient is instantiated for 4 z slices x 32 / 64 rows
+    h = parts if split else x_cl
+    dw_gate = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gy, h, cout, cin, march_tile=tile, h_gate=att)
+    dw_mat = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gy, gated, cout, cin, march_tile=tile)
+    assert torch.equal(dw_gate, dw_mat), float((dw_gate - dw_mat).abs().max())
+
+
 COMPUTE_CASES = [
     # kind, cin, cout, dims, input split
     ("conv_fwd", 32, 48, (8, 16, 32), 0),     # every tile touches the border

@@ -67,6 +67,7 @@ class IgemmDesc(C.Structure):
         ("stats_stride", C.c_int32),
         ("cout_mod", C.c_int32),
         ("gate", C.c_void_p),
+        ("in_gate", C.c_void_p),
     ]
 
 
@@ -94,6 +95,7 @@ class WgradDesc(C.Structure):
         ("hgroup", C.c_int32),
         ("dbias_p", C.c_void_p),
         ("march", C.c_int32),
+        ("h_gate", C.c_void_p),
     ]
 
 

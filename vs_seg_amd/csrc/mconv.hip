@@ -32,6 +32,7 @@ struct MconvK {
   char* out0; char* out1;
   const char* aux0; const char* aux1;
   const float* gate;
+  const float* in_gate;  // GIN: fp32 attention map of the INPUT tensor: voxel v is multiplied by (1 + in_gate[v]) on load
   const char* wpack;
   const float *bias, *bias2, *scale, *shift, *alpha;
   double* stats;
@@ -44,10 +45,13 @@ struct MconvK {
   int lx, nxs, nyb, nzb;  // x steps per workgroup; segments in x, blocks in y and z
 };
 
-// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16)
+// MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16), 3 plain + attention gate applied to the input on load (GIN):
+// AttentionBlock2's `att.repeat(C) * x + x` (ref:params/networks/blocks/attentionblock.py:43-47) is a per-voxel scalar on the convolution's input.
+// A thread multiplies the pieces IT fetched by (1 + att[voxel]) in LDS (fp32 product rounded to bf16: bit-identical to vsseg_att_apply_fwd) right
+// after its own DMA wait and in front of the step's barrier — no extra barrier, and the gated tensor is never written to HBM or read back.
 template <int CIN, int NT, int TZ, int MT, int MODE>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
-  constexpr bool STATS = MODE == 1, AUXM = MODE == 2;
+  constexpr bool STATS = MODE == 1, AUXM = MODE == 2, GIN = MODE == 3;
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
   constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = KSTEPS * NT * 1024;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
 
   // ---- this thread's DMA pieces: LDS slot j = (u*4 + wave)*64 + lane of a plane holds (row j / RS, piece' (j % RS) / TZ, z j % TZ)
-  int rel[NINST];
+  int rel[NINST], grel[GIN ? NINST : 1];
   unsigned okmask = 0, p1mask = 0;
 #pragma unroll
   for (int u = 0; u < NINST; ++u) {
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     const int gy = y0 + r - 1;
     const bool ok = j < PLANE_SLOTS && (unsigned)gy < (unsigned)Y;
     rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + pc * 16 : 0;
+    if constexpr (GIN) grel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) okmask |= 1u << u;
     if (ok && pc >= k.in_csplit_pc) p1mask |= 1u << u;
   }
@@ -104,6 +109,36 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
     for (int u = 0; u < NINST; ++u)
       if ((okmask >> u) & 1u) vsseg_dma16(inside ? (const void*)(((p1mask >> u) & 1u ? p1 : p0) + rel[u]) : k.zeros, dst + (u * 4 + wave) * 1024);
+  };
+
+  // GIN: the gate values of this thread's pieces of plane i (ordinary loads, issued in FRONT of the plane's DMAs), and the in-place product
+  const float* gcol = GIN ? k.in_gate + col0 : nullptr;
+  auto load_gate = [&](int i, float (&gv)[GIN ? NINST : 1]) {
+    if constexpr (GIN) {
+      const int x = xb - 1 + i;
+      const bool inside = (unsigned)x < (unsigned)X;
+      const float* gp = gcol + (int64_t)(inside ? x : 0) * Y * Z;
+#pragma unroll
+      for (int u = 0; u < NINST; ++u) gv[u] = gp[grel[u]];  // pieces outside the image read a valid voxel of the column and are never used
+    }
+  };
+  auto apply_gate = [&](int i, const float (&gv)[GIN ? NINST : 1]) {
+    if constexpr (GIN) {
+      char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES + lane * 16;
+#pragma unroll
+      for (int u = 0; u < NINST; ++u) {
+        if (!((okmask >> u) & 1u)) continue;
+        uint4* p = reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024);
+        const uint4 q = *p;
+        const float gg = 1.f + gv[u];
+        uint4 o;
+        o.x = f2bf2(__uint_as_float(q.x << 16) * gg, __uint_as_float(q.x & 0xffff0000u) * gg);
+        o.y = f2bf2(__uint_as_float(q.y << 16) * gg, __uint_as_float(q.y & 0xffff0000u) * gg);
+        o.z = f2bf2(__uint_as_float(q.z << 16) * gg, __uint_as_float(q.z & 0xffff0000u) * gg);
+        o.w = f2bf2(__uint_as_float(q.w << 16) * gg, __uint_as_float(q.w & 0xffff0000u) * gg);
+        *p = o;
+      }
+    }
   };
 
   // ---- MFMA operand addressing: K-group p = ks*4 + g -> (tap p / G, piece p % G); lane column l15 -> voxel (row l15 / TZ, z l15 % TZ) of the M-tile
@@ -157,15 +192,29 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // the ring is zeroed before any DMA writes it
   load_aux(1, auxv, gatev);
+  float gin0[GIN ? NINST : 1], gin1[GIN ? NINST : 1], gin[GIN ? NINST : 1];
+  load_gate(0, gin0);
+  load_gate(1, gin1);
+  load_gate(2, gin);
   issue(0);
   issue(1);
   issue(2);
+  if constexpr (GIN) {  // the three prologue planes are gated once they have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    apply_gate(0, gin0);
+    apply_gate(1, gin1);
+    apply_gate(2, gin);
+  }
 
   for (int i = 1; i <= steps; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of plane i+1 have landed (and the previous step's stores have left)
+    if constexpr (GIN) {
+      if (i > 1) apply_gate(i + 1, gin);                 // ... and are gated by the thread that fetched them
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                        // ... everybody's; and every wave has finished reading plane i-2
     if (i < steps) load_aux(i + 1, auxn, gaten);         // next step's auxiliary operand, in front of the DMAs
-    if (i + 2 <= steps + 1) issue(i + 2);
+    if (i + 2 <= steps + 1) { load_gate(i + 2, gin); issue(i + 2); }
     const int sm1 = ((i - 1) & (MC_NR - 1)) * PLANE_BYTES, s0 = (i & (MC_NR - 1)) * PLANE_BYTES, sp1 = ((i + 1) & (MC_NR - 1)) * PLANE_BYTES;
 
     f32x4 acc[MT][NT];
@@ -310,6 +359,10 @@ template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_mode(c
   return VSSEG_OK;
 }
 template <int CIN, int NT, int TZ, int MT> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
+  if (k.in_gate) {
+    if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
+    else { vsseg_set_error("vsseg_igemm: no marching-kernel instantiation with the input gate for this shape"); return VSSEG_EINVAL; }
+  }
   if (k.stats) return mc_launch_mode<CIN, NT, TZ, MT, 1>(k, grid, s);
   if (k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 2>(k, grid, s);
   return mc_launch_mode<CIN, NT, TZ, MT, 0>(k, grid, s);
@@ -322,6 +375,7 @@ struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); };
 static const McEntry mc_table[] = {
     MC_E(8, 1, 8, 8), MC_E(8, 2, 8, 8), MC_E(8, 1, 4, 8), MC_E(8, 2, 4, 8), MC_E(8, 1, 4, 4), MC_E(8, 2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
     MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
+    MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_E(16, 2, 4, 2), MC_E(16, 2, 8, 4), MC_E(32, 1, 4, 2), MC_E(32, 2, 4, 2), MC_E(8, 1, 8, 4), MC_E(8, 2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
     MC_E(32, 1, 2, 4), MC_E(32, 1, 4, 4), MC_E(32, 1, 2, 2), MC_E(32, 2, 4, 4), MC_E(32, 2, 2, 4), MC_E(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_E(32, 4, 2, 2), MC_E(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
     MC_E(64, 2, 2, 2), MC_E(64, 2, 2, 1), MC_E(64, 1, 2, 2), MC_E(64, 1, 2, 1)};                                                   // 64 -> 32 / 16
 
@@ -390,6 +444,8 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   }
   VSSEG_CHECK(k.aux_mode != 4 || d->gate, "vsseg_igemm: RES_GATE needs the gate map");
   k.gate = d->gate;
+  k.in_gate = d->in_gate;
+  VSSEG_CHECK(!d->in_gate || (!d->stats && !k.aux_mode), "vsseg_igemm: the input gate combines with a plain epilogue only");
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;

@@ -26,6 +26,7 @@ struct MwgradK {
   const char* p;                   // P (centre operand), one part
   float* slab;                     // [gridDim.x][NTH][9][NTP*16][16]
   float* dbias;                    // optional: dbias[cP] += sum_q P[q][cP]
+  const float* h_gate;             // GIN: fp32 attention map of H: voxel v of H is multiplied by (1 + h_gate[v]) on load (mconv.hip, MODE 3)
   const void* zeros;
   int h_csplit_pc, h_vox_bytes, p_vox_bytes, cp_valid;
   int X, Y, Z;
@@ -41,7 +42,7 @@ __device__ __forceinline__ bf16x8 mw_tr(const char* lo, const char* hi) {
 
 // CH: channels of H (16, 32, 64); CP: channels of P as stored (8, 16, 32: 8 = a 1/2-channel gradient zero-extended to one channel group);
 // UNITSPLIT: waves split the (tap, cH tile) units instead of the K-steps
-template <int CH, int CP, int TZ, int MT, bool UNITSPLIT>
+template <int CH, int CP, int TZ, int MT, bool UNITSPLIT, bool GIN>
 __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
   constexpr int GH = CH / 8, GP = CP / 8, RSH = TZ * GH, RSP = TZ * GP, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int NTH = CH / 16, NTP = CP >= 16 ? CP / 16 : 1;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
   for (int i = tid; i < (MW_NR * HPLANE + 2 * PPLANE) / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);  // H rows outside the image stay zero
 
   // ---- DMA pieces (mconv.hip's scheme): LDS slot j of a plane holds (row j / RS, piece' (j % RS) / TZ, z j % TZ)
-  int hrel[HINST], prel[PINST];
+  int hrel[HINST], prel[PINST], grel[GIN ? HINST : 1];
   unsigned hok = 0, h1m = 0, pok = 0;
 #pragma unroll
   for (int u = 0; u < HINST; ++u) {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
     const int gy = y0 + r - 1;
     const bool ok = j < HSLOTS && (unsigned)gy < (unsigned)Y;
     hrel[u] = ok ? ((r - 1) * Z + z) * k.h_vox_bytes + pc * 16 : 0;
+    if constexpr (GIN) grel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) hok |= 1u << u;
     if (ok && pc >= k.h_csplit_pc) h1m |= 1u << u;
   }
@@ -104,6 +106,33 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
 #pragma unroll
     for (int u = 0; u < HINST; ++u)
       if ((hok >> u) & 1u) vsseg_dma16(inside ? (const void*)(((h1m >> u) & 1u ? q1 : q0) + hrel[u]) : k.zeros, dst + (u * 4 + wave) * 1024);
+  };
+  const float* gcol = GIN ? k.h_gate + col0 : nullptr;
+  auto load_gate = [&](int i, float (&gv)[GIN ? HINST : 1]) {  // gate values of this thread's pieces of H plane i: ordinary loads in front of the plane's DMAs
+    if constexpr (GIN) {
+      const int x = xb - 1 + i;
+      const float* gp = gcol + (int64_t)((unsigned)x < (unsigned)X ? x : 0) * Y * Z;
+#pragma unroll
+      for (int u = 0; u < HINST; ++u) gv[u] = gp[grel[u]];
+    }
+  };
+  auto apply_gate = [&](int i, const float (&gv)[GIN ? HINST : 1]) {  // every thread gates the pieces IT fetched, in LDS, in front of the step's barrier
+    if constexpr (GIN) {
+      char* dst = Hl + (i & (MW_NR - 1)) * HPLANE + lane * 16;
+#pragma unroll
+      for (int u = 0; u < HINST; ++u) {
+        if (!((hok >> u) & 1u)) continue;
+        uint4* p = reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024);
+        const uint4 qv = *p;
+        const float gg = 1.f + gv[u];
+        uint4 o;
+        o.x = f2bf2(__uint_as_float(qv.x << 16) * gg, __uint_as_float(qv.x & 0xffff0000u) * gg);
+        o.y = f2bf2(__uint_as_float(qv.y << 16) * gg, __uint_as_float(qv.y & 0xffff0000u) * gg);
+        o.z = f2bf2(__uint_as_float(qv.z << 16) * gg, __uint_as_float(qv.z & 0xffff0000u) * gg);
+        o.w = f2bf2(__uint_as_float(qv.w << 16) * gg, __uint_as_float(qv.w & 0xffff0000u) * gg);
+        *p = o;
+      }
+    }
   };
   auto issue_p = [&](int i) {  // plane i of P (always inside the image) into buffer i & 1
     const char* q = porg + (int64_t)(xb - 1 + i) * pstride;
@@ -146,15 +175,29 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
 
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __syncthreads();  // the buffers are zeroed before any DMA writes them
+  float gin0[GIN ? HINST : 1], gin1[GIN ? HINST : 1], gin[GIN ? HINST : 1];
+  load_gate(0, gin0);
+  load_gate(1, gin1);
+  load_gate(2, gin);
   issue_h(0);
   issue_h(1);
   issue_h(2);
   issue_p(1);
+  if constexpr (GIN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    apply_gate(0, gin0);
+    apply_gate(1, gin1);
+    apply_gate(2, gin);
+  }
 
   for (int i = 1; i <= steps; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GIN) {
+      if (i > 1) apply_gate(i + 1, gin);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // H plane i+1 and P plane i have landed for every wave; every wave has finished step i-1
-    if (i + 2 <= steps + 1) issue_h(i + 2);
+    if (i + 2 <= steps + 1) { load_gate(i + 2, gin); issue_h(i + 2); }
     if (i + 1 <= steps) issue_p(i + 1);
     const char* Ps = Pl + (i & 1) * PPLANE;
     const char* Hs[3] = {Hl + ((i - 1) & (MW_NR - 1)) * HPLANE, Hl + (i & (MW_NR - 1)) * HPLANE, Hl + ((i + 1) & (MW_NR - 1)) * HPLANE};
@@ -261,16 +304,23 @@ template <int CH, int CP, int TZ, int MT> static int mw_lds() {
   constexpr int RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   return MW_NR * ((ROWS * TZ * (CH / 8) * 16 + 255) / 256 * 256) + 2 * ((TYB * TZ * (CP / 8) * 16 + 255) / 256 * 256);
 }
-template <int CH, int CP, int TZ, int MT, bool US> static int mw_launch(const MwgradK& k, int grid, hipStream_t s) {
+template <int CH, int CP, int TZ, int MT, bool US, bool GIN> static int mw_launch_g(const MwgradK& k, int grid, hipStream_t s) {
   static bool init = false;
   const int lds = mw_lds<CH, CP, TZ, MT>();
   if (!init) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     init = true;
   }
-  hipLaunchKernelGGL((mwgrad_kernel<CH, CP, TZ, MT, US>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  hipLaunchKernelGGL((mwgrad_kernel<CH, CP, TZ, MT, US, GIN>), dim3((unsigned)grid), dim3(256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (marching)");
   return VSSEG_OK;
+}
+template <int CH, int CP, int TZ, int MT, bool US> static int mw_launch(const MwgradK& k, int grid, hipStream_t s) {
+  if (k.h_gate) {
+    if constexpr (CH == 32 && CP == 8) return mw_launch_g<CH, CP, TZ, MT, US, true>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
+    else { vsseg_set_error("vsseg_wgrad: no marching-kernel instantiation with the gated H operand for this shape"); return VSSEG_EINVAL; }
+  }
+  return mw_launch_g<CH, CP, TZ, MT, US, false>(k, grid, s);
 }
 
 typedef int (*mw_fn_t)(const MwgradK&, int, hipStream_t);
@@ -322,6 +372,7 @@ int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_
   k.p_vox_bytes = d->p.pitch * 2;
   k.cp_valid = d->cp_valid;
   k.dbias = d->dbias_p;
+  k.h_gate = d->h_gate;
   k.zeros = zeros;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.lx = d->tile[0] > k.X ? k.X : d->tile[0];

@@ -447,6 +447,7 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
     VSSEG_CHECK(z, "vsseg_wgrad: could not allocate the zero page");
     return vsseg_mwgrad_launch(d, z, as_stream(stream));
   }
+  VSSEG_CHECK(!d->h_gate, "vsseg_wgrad: the gated H operand (h_gate) needs the marching kernel (march = 1)");
   VSSEG_CHECK(d->p.dtype == d->h.dtype, "vsseg_wgrad: dtype mismatch");
   VSSEG_CHECK(d->ntaps >= 1 && d->ntaps <= VSSEG_MAX_TAPS, "vsseg_wgrad: ntaps out of range");
   VSSEG_CHECK(d->p.c % 8 == 0 && d->p.pitch % 8 == 0 && d->h.c % 8 == 0 && d->h.pitch % 8 == 0, "vsseg_wgrad: channels/pitch must be multiples of 8");

@@ -307,7 +307,7 @@ class Plan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
-               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}")
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else ""))
         cache = _tune_cache()
         hit = cache.get(key)
         if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
@@ -374,10 +374,11 @@ class Plan:
             self._igemm(lst, ch, inp, out, res=res, **kw)
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0):
         nb = self.n if nb is None else nb
         d = L.IgemmDesc()
         d.gate = gate or None
+        d.in_gate = in_gate or None
         if ch.fold:
             inp, out, res = self._fold_desc(inp, ch.fold), self._fold_desc(out, ch.fold), (self._fold_desc(res, ch.fold) if res is not None else None)
             d.cout_mod = ch.cmod
@@ -474,6 +475,30 @@ class Plan:
                     if pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None:
                         res1_fused[pr.layer.prefix] = pr
 
+        # Attention gates applied ON LOAD (ref:params/networks/blocks/attentionblock.py:43-47: out = att.repeat(C) * x + x): where the gated tensor's only
+        # reader is ONE stride-1 3x3x1 convolution (with its merged 1x1x1 residual) that runs on the marching kernel, that convolution and its weight
+        # gradient read x and the attention map and multiply in LDS (csrc/mconv.hip MODE 3, csrc/mwgrad.hip GIN): vsseg_att_apply_fwd is not launched and
+        # the gated tensor (2c channels at the level's resolution) is neither written nor read back.  Level 0 of this network (the logits convolution).
+        self.gate_onload: Dict[str, AttGate] = {}
+        if eng.gate_onload and eng.es == 2 and self.tune:
+            for g in ops:
+                if not isinstance(g, AttGate):
+                    continue
+                readers = [o for o in ops if isinstance(o, (ConvBnAct, ConvPlain)) and (o.x is g.out or (o.x.parts is not None and g.out in o.x.parts) or o.res is g.out)]
+                readers += [o for o in ops if isinstance(o, AttGate) and (o.x is g.out or (o.x.parts is not None and g.out in o.x.parts))]
+                main = [o for o in readers if isinstance(o, ConvPlain) and o.layer.prefix not in self.merged]
+                if len(main) != 1 or any(o is not main[0] and not (isinstance(o, ConvPlain) and self.merged.get(o.layer.prefix) is main[0]) for o in readers):
+                    continue
+                c = main[0]
+                Lc, cpc = c.layer, self.cplans[c.layer.prefix]
+                if Lc.transposed or tuple(Lc.stride) != (1, 1, 1) or Lc.kernel != (3, 3, 1) or Lc.cin != 32 or Lc.cout > 8 or c.x is not g.out or len(cpc.fwd) != 1 or cpc.fold_fwd or g.x.c != Lc.cin:
+                    continue
+                if not any(pl.depth == -5 for pl in cpc.fwd[0].cands):
+                    continue
+                if self.train and not P.march_wgrad_tiles(Lc.cin, 8, self.lv[Lc.level], self.n, eng.wgrad_scratch().numel()):
+                    continue
+                self.gate_onload[g.out.name] = g
+
         # ---- forward
         F = self.fwd
         grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
@@ -506,12 +531,22 @@ class Plan:
                 if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
+                gl = self.gate_onload.get(op.x.name)
+                if gl is not None:  # the attention gate in front of this convolution is applied on load: read x and the attention map, marching plans only
+                    ch0 = cp.fwd[0]
+                    gch = _Choice([pl for pl in ch0.cands if pl.depth == -5], ch0.woff, ch0.wshape2, ch0.woff2, wshape=ch0.wshape)
+                    cp.fwd[0] = gch
+                    self._igemm(F, gch, self._desc(gl.x), self._desc(op.out), bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act],
+                                in_gate=self._alloc(gl.att, self.bufs).data_ptr())
+                    continue
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for ch in cp.fwd:
                     self._igemm(F, ch, xin, out, bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act], res=res,
                                 res_mode=L.RES_ADD if res is not None else L.RES_NONE)
             elif isinstance(op, AttGate):
+                if op.out.name in self.gate_onload:
+                    continue
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)], self._ew_meta("att_apply_fwd", op.x.level, 2 * op.x.c + 2)])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
@@ -583,8 +618,11 @@ class Plan:
                 assert not bias_grad, "the narrow weight-gradient path does not reduce a bias gradient"
                 conv_backward_data(Lr, x, dy, relumask, dy_compact, gate)
                 return
-            xin = self._desc(x)
+            gl = self.gate_onload.get(x.name)  # the convolution's input is an attention-gated tensor that was never materialised: H = x, gated on load
+            xin = self._desc(gl.x if gl is not None else x)
             d = L.WgradDesc()
+            if gl is not None:
+                d.h_gate = self._alloc(gl.att, self.bufs).data_ptr()
             if Lr.transposed:
                 d.p, d.h, d.cp_valid, d.ch_valid = xin, dy, Lr.cin, Lr.cout
             else:
@@ -623,7 +661,7 @@ class Plan:
                 mtiles = P.march_wgrad_tiles(Lr.cin, d.p.c, wg.q, self.n, scr.numel())
             live_tile = L.i3(wg.tile)
             if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU, and the marching kernel's tiles
-                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}"
+                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}" + ("|gin" if gl is not None else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     hit = cache[key]
@@ -656,7 +694,7 @@ class Plan:
                         return best
 
                     ms = {}
-                    for hg in hgs:
+                    for hg in (hgs if gl is None else []):  # (a gated H operand: marching kernel only)
                         for sb in (0, 1):
                             for w in (2, 3, 4):
                                 d.march, d.single_buffer, d.hgroup = 0, sb, hg
@@ -898,6 +936,7 @@ class Engine:
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
+        self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched
         # eagerly: replayed as ONE hipGraph the two branches ran no faster than serially (measured 37.6 ms)

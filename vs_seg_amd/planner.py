@@ -187,7 +187,7 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
 
 # ---- marching streaming kernel (csrc/mconv.hip): depth -5 ------------------------------------------------------------------
 # (input channels, 16-channel output tiles, TZ, M-tiles per wave) instantiated by mconv.hip; rows per workgroup TYB = 64 * mt / tz
-MARCH_SHAPES = {(8, 1, 8, 8), (8, 2, 8, 8), (8, 1, 4, 8), (8, 2, 4, 8), (8, 1, 4, 4), (8, 2, 4, 4), (16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
+MARCH_SHAPES = {(16, 1, 4, 2), (16, 1, 8, 4), (16, 2, 4, 2), (16, 2, 8, 4), (32, 1, 4, 2), (32, 2, 4, 2), (8, 1, 8, 4), (8, 2, 8, 4), (8, 1, 8, 8), (8, 2, 8, 8), (8, 1, 4, 8), (8, 2, 4, 8), (8, 1, 4, 4), (8, 2, 4, 4), (16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
                 (32, 1, 2, 4), (32, 1, 4, 4), (32, 1, 2, 2), (32, 2, 4, 4), (32, 2, 2, 4), (32, 2, 2, 2), (32, 4, 4, 4), (32, 4, 2, 2), (32, 4, 4, 2),
                 (64, 2, 2, 2), (64, 2, 2, 1), (64, 1, 2, 2), (64, 1, 2, 1)}
 MARCH_RING = 4
