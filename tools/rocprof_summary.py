@@ -26,12 +26,20 @@ def bench_name(short_name):
     m = re.match(r"sconv_kernel<(\d+), (\d+), (\d+), \d+>", short_name)  # streaming kernel: the MODE / tap / input-channel variants of one NT share a bench name
     if m:
         return f"sconv<bf16,{m.group(2)}>"
+    m = re.match(r"mconv_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short_name)  # marching kernel: (CIN, NT, TZ, MT, MODE) variants of one NT share a bench name
+    if m:
+        return f"mconv<bf16,{m.group(2)}>"
+    m = re.match(r"mwgrad_kernel<(\d+), (\d+), ", short_name)  # marching weight gradient: bench name by the P tiles (ntp = max(1, CP / 16))
+    if m:
+        return f"mwgrad<bf16,{max(1, int(m.group(2)) // 16)}>"
     m = re.match(r"cconv_kernel<(\d+), \d+>", short_name)  # compute-bound kernel: the MODE variants of one NT share a bench name
     if m:
         return f"cconv<bf16,{m.group(1)}>"
     m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)(, \d+)?>", short_name)  # MAXT / H-group variants of one (type, NTP) share a bench name
     if m:
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
+    if short_name.startswith("wgrad_narrow_kernel"):
+        return "wgrad_narrow"
     m = re.match(r"(bn_act_fwd|bn_act_bwd_reduce|bn_act_bwd_apply|att_apply_fwd|att_apply_bwd)_kernel<", short_name)  # streaming kernels: bench.py's group names
     if m:
         return m.group(1)

@@ -169,26 +169,32 @@ __device__ __forceinline__ void vsseg_dma16(const void* gsrc, const void* lds_wa
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory", "m0");
 }
 
-// Partial-sum slabs slab[b][i] (b = workgroup of the producing kernel, i = output element) summed over b in [b0, b1) by a 256-thread block that owns
-// 64 consecutive elements: thread (il = tid & 63, bl = tid >> 6) adds the slabs b0 + bl, b0 + bl + 4, ... with 8 independent loads in flight, the
-// four block-lanes are combined through LDS in a FIXED order (the result is run-to-run bit-identical).  Every thread returns the sum of element i.
-__device__ __forceinline__ float vsseg_slab_sum(const float* __restrict__ slab, int64_t total, int64_t i, int b0, int b1, float* lds256) {
+// Partial-sum slabs slab[b][i] (b = workgroup of the producing kernel, i = output element) summed over all b by a 1024-thread block that owns 64
+// consecutive elements: thread (il = tid & 63, bl = tid >> 6) adds the slabs bl, bl + 16, ... with 8 independent loads in flight (<= 2048 slabs: 16
+// dependent rounds), the sixteen block-lanes are combined through LDS in a FIXED order (the result is run-to-run bit-identical).  Threads of
+// block-lane 0 return the sum of element i.  One launch per layer: a two-stage tree cost a second ~15 us launch on the eager side stream.
+constexpr int VSSEG_SLAB_THREADS = 1024;
+__device__ __forceinline__ float vsseg_slab_sum(const float* __restrict__ slab, int64_t total, int64_t i, int nblk, float* lds1024) {
   const int il = threadIdx.x & 63, bl = threadIdx.x >> 6;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < total) {
     const float* p = slab + i;
-    int b = b0 + bl;
-    for (; b + 28 < b1; b += 32) {
+    int b = bl;
+    for (; b + 112 < nblk; b += 128) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += p[(int64_t)(b + 4 * j) * total];
+      for (int j = 0; j < 8; ++j) s[j] += p[(int64_t)(b + 16 * j) * total];
     }
-    for (; b < b1; b += 4) s[0] += p[(int64_t)b * total];
+    for (; b < nblk; b += 16) s[0] += p[(int64_t)b * total];
   }
-  lds256[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  lds1024[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
-  return (lds256[il] + lds256[64 + il]) + (lds256[128 + il] + lds256[192 + il]);
+  float r = 0.f;
+  if (bl == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r += lds1024[j * 64 + il];
+  }
+  return r;
 }
-constexpr int VSSEG_SLAB_SLICE = 32;  // slabs per first-stage block row: nblk slabs -> ceil(nblk / 32) partial rows -> the final sum
 
 static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -15,7 +15,7 @@
 //     256-byte bank row (they are row neighbours, and the layout's swizzle alternates with the row) — no bank conflicts
 //   * the accumulators (9 taps x cH tiles x cP tiles) live in registers over the whole march; waves split the K-steps (every wave all taps:
 //     no operand is read twice) or, where those accumulators do not fit, the (tap, cH tile) units (the P fragments are then read by every wave)
-//   * flush: cross-wave sum in a fixed order through LDS, one partial-sum slab per workgroup, the two-stage tree of wgrad.hip sums the slabs
+//   * flush: cross-wave sum in a fixed order through LDS, one partial-sum slab per workgroup, wgrad.hip's fixed-order reduction sums the slabs
 #include "common.h"
 #include "mwgrad.h"
 
@@ -380,10 +380,9 @@ int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_
   const int nth = d->h.c / 16, slab_chunk = 9 * d->ntp * 16 * 16;
   const int64_t per_blk = (int64_t)nth * slab_chunk;
   int64_t grid = (int64_t)d->p.n * k.nxs * k.nyb * k.nzb;
-  const int slices = (int)((grid + VSSEG_SLAB_SLICE - 1) / VSSEG_SLAB_SLICE);
   VSSEG_CHECK(grid > 0 && grid < (1ll << 24), "vsseg_wgrad: bad marching grid");
-  VSSEG_CHECK(d->scratch && d->scratch_elems >= (grid + slices) * per_blk, "vsseg_wgrad: scratch too small for %lld marching workgroups (%lld < %lld floats); use longer x segments", (long long)grid,
-              (long long)d->scratch_elems, (long long)((grid + slices) * per_blk));
+  VSSEG_CHECK(d->scratch && d->scratch_elems >= grid * per_blk, "vsseg_wgrad: scratch too small for %lld marching workgroups (%lld < %lld floats); use longer x segments", (long long)grid,
+              (long long)d->scratch_elems, (long long)(grid * per_blk));
   k.slab = d->scratch;
   int rc = e->fn(k, (int)grid, s);
   if (rc) return rc;

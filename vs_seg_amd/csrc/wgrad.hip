@@ -339,17 +339,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 }
 
 #ifndef WG_INST
-// dw[cp][ch][tap] += sum over workgroups of their slabs, as a two-stage tree (vsseg_slab_sum): stage 1 (partial != nullptr) sums slices of 32 slabs
-// into partial[slice][i] over a (elements / 64) x slices grid, stage 2 sums the <= 32 partial rows into dw.  (One thread per element walking all
-// <= 1024 slabs was a 41 us latency chain per layer: 1.9 ms per step in 45 launches, profiles/r02_kernel_stats.txt.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, float* __restrict__ partial, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
-  __shared__ float lds[256];
+// dw[cp][ch][tap] += sum over workgroups of their slabs (vsseg_slab_sum: 64 elements x 16 slab lanes per block, fixed summation order).
+// (One thread per element walking all <= 1024 slabs was a 41 us latency chain per layer: 1.9 ms per step in 45 launches, profiles/r02_kernel_stats.txt.)
+__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
+  __shared__ float lds[VSSEG_SLAB_THREADS];
   const int64_t total = (int64_t)hchunks * slab_chunk;
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int b0 = blockIdx.y * VSSEG_SLAB_SLICE, b1 = min(nblk, b0 + VSSEG_SLAB_SLICE);
-  const float s = vsseg_slab_sum(slab, total, i, partial ? b0 : 0, partial ? b1 : nblk, lds);
+  const float s = vsseg_slab_sum(slab, total, i, nblk, lds);
   if (threadIdx.x >= 64 || i >= total) return;
-  if (partial) { partial[(int64_t)blockIdx.y * total + i] = s; return; }
   const int chunk = (int)(i / slab_chunk), r = (int)(i - (int64_t)chunk * slab_chunk);
   const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
   const int ch = chunk * 16 + l15;
@@ -420,19 +417,10 @@ int vsseg_wgrad_launch_f32(WgradK& k, int maxt, int hg, dim3& grid, int lds, hip
 int vsseg_wgrad_launch_bf16(WgradK& k, int maxt, int hg, dim3& grid, int lds, hipStream_t s);
 
 #ifndef WG_INST
-// sums `nblk` partial-sum slabs [nblk][hchunks][slab_chunk] into d->dw (two-stage tree; the first-stage rows live behind the slabs)
+// sums `nblk` partial-sum slabs [nblk][hchunks][slab_chunk] into d->dw
 int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, int hchunks, int slab_chunk, hipStream_t s) {
   const int total = hchunks * slab_chunk;
-  const int slices = (nblk + VSSEG_SLAB_SLICE - 1) / VSSEG_SLAB_SLICE;
-  const float* src = slab;
-  int nsrc = nblk;
-  if (slices > 1 && d->scratch_elems - (slab - d->scratch) >= ((int64_t)nblk + slices) * total) {
-    float* partial = slab + (int64_t)nblk * total;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, slices), dim3(256), 0, s, src, nblk, partial, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
-    src = partial;
-    nsrc = slices;
-  }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, s, src, nsrc, (float*)nullptr, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)slab, nblk, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
   return VSSEG_OK;
 }

@@ -106,17 +106,15 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
   for (int i = tid; i < NT * C; i += 256) slab[i] = red[i];
 }
 
-// dw[c*stride_c + weight tap] += sum over workgroups of slab[b][t*C + c]: the same two-stage tree as wgrad.hip's (vsseg_slab_sum) — one thread per
-// element walking 1024 slabs cost 224 us per launch, as much as the reduction over the tensor itself
-__global__ __launch_bounds__(256) void wgrad_narrow_reduce_kernel(const float* __restrict__ slab, int nblk, float* __restrict__ partial, int C, int K3, int sign, float* __restrict__ dw, int64_t stride_c) {
-  __shared__ float lds[256];
+// dw[c*stride_c + weight tap] += sum over workgroups of slab[b][t*C + c] (vsseg_slab_sum, as wgrad.hip) — one thread per element walking 1024
+// slabs cost 224 us per launch, as much as the reduction over the tensor itself
+__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_narrow_reduce_kernel(const float* __restrict__ slab, int nblk, int C, int K3, int sign, float* __restrict__ dw, int64_t stride_c) {
+  __shared__ float lds[VSSEG_SLAB_THREADS];
   const int NT = K3 * K3, R = K3 / 2;
   const int64_t total = (int64_t)NT * C;
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int b0 = blockIdx.y * VSSEG_SLAB_SLICE, b1 = min(nblk, b0 + VSSEG_SLAB_SLICE);
-  const float s = vsseg_slab_sum(slab, total, i, partial ? b0 : 0, partial ? b1 : nblk, lds);
+  const float s = vsseg_slab_sum(slab, total, i, nblk, lds);
   if (threadIdx.x >= 64 || i >= total) return;
-  if (partial) { partial[(int64_t)blockIdx.y * total + i] = s; return; }
   const int t = (int)i / C, c = (int)i - t * C;
   const int dx = t / K3 - R, dy = t % K3 - R;  // s-offset (dx, dy) = sign * (weight tap offset)
   const int widx = (sign * dx + R) * K3 + (sign * dy + R);
@@ -138,7 +136,7 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
   VSSEG_CHECK((int64_t)t.n * t.x * t.y * t.z < (1ll << 31), "vsseg_wgrad_narrow: more than 2^31 voxels");
   // >= 16 items per thread before another workgroup is worth its flush; at most 4 workgroups per CU
   int grid = grid_for(k.items * k.cgs / 16, 256, 256 * 4);
-  const int64_t cap = scratch_elems / (k3 * k3 * t.c) - (256 * 4 + VSSEG_SLAB_SLICE - 1) / VSSEG_SLAB_SLICE;  // room for the first-stage partial rows behind the slabs
+  const int64_t cap = scratch_elems / (k3 * k3 * t.c);
   VSSEG_CHECK(cap >= 1, "vsseg_wgrad_narrow: scratch too small");
   if (grid > cap) grid = (int)cap;
   k.slab = scratch;
@@ -151,16 +149,7 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
   }
   VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow");
   const int total = k3 * k3 * t.c;
-  const int slices = (grid + VSSEG_SLAB_SLICE - 1) / VSSEG_SLAB_SLICE;
-  const float* src = scratch;
-  int nsrc = grid;
-  if (slices > 1) {
-    float* partial = scratch + (int64_t)grid * total;
-    hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64, slices), dim3(256), 0, as_stream(stream), src, grid, partial, (int)t.c, (int)k3, (int)sign, dw, stride_c);
-    src = partial;
-    nsrc = slices;
-  }
-  hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64, 1), dim3(256), 0, as_stream(stream), src, nsrc, (float*)nullptr, (int)t.c, (int)k3, (int)sign, dw, stride_c);
+  hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, as_stream(stream), (const float*)scratch, grid, (int)t.c, (int)k3, (int)sign, dw, stride_c);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow(reduce)");
   return VSSEG_OK;
 }

@@ -241,7 +241,7 @@ def march_wgrad_tiles(ch, cp, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tupl
             nxs = max(1, min(q[0] // 8, -(-target // cols)))
             lx = -(-q[0] // nxs)
             grid = cols * -(-q[0] // lx)
-            if (grid + -(-grid // 32)) * per_blk > scratch_elems or (lx, tyb, tz) in out:
+            if grid * per_blk > scratch_elems or grid > 2048 or (lx, tyb, tz) in out:
                 continue
             out.append((lx, tyb, tz))
     return out
