@@ -134,7 +134,8 @@ int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream);
  * t: the C-channel tensor (C = 8, 16, 32 or 64; y extent a multiple of 4), s: the one-channel field [N][X][Y][Z] in t's dtype.
  * Conv3d 1 -> C: t = dY, s = X, sign = +1.  Conv3d C -> 1: t = X, s = dY (its one real channel, compact), sign = -1.  stride_c = taps. */
 int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c,
-                       float* scratch /* partial-sum slabs: >= k3*k3*C floats per workgroup */, int64_t scratch_elems, void* stream);
+                       float* dbias /* sign = -1 only, or NULL: *dbias += sum_v s[v], the bias gradient of the C -> 1 convolution */,
+                       float* scratch /* partial-sum slabs: >= k3*k3*C + 1 floats per workgroup */, int64_t scratch_elems, void* stream);
 
 /* dst[i] = map[i] >= 0 ? cast(src[map[i]]) : 0 — (re)packs the fp32 master weights into MFMA fragment order. */
 int vsseg_gather_cast(const float* src, const int32_t* map, const int32_t* map2 /* optional second addend, or NULL */, void* dst, int64_t n, int32_t dst_dtype, void* stream);

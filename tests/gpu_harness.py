@@ -10,6 +10,19 @@ from vs_seg_amd import planner as P
 DT = {"fp32": torch.float32, "bf16": torch.bfloat16}
 
 
+FX_STAT = float(2 ** 20)  # csrc/common.h VSSEG_FX_STAT: the sharded statistics hold 64-bit fixed-point integers (order-independent atomics)
+
+
+def stat_decode(t: torch.Tensor) -> torch.Tensor:
+    """A statistics buffer of the C ABI (`double*`, filled by vsseg_fx_add) as real numbers."""
+    return t.view(torch.int64).double() / FX_STAT
+
+
+def stat_encode(t: torch.Tensor) -> torch.Tensor:
+    """Real numbers -> the fixed-point bit pattern the finalisation kernels read (for tests that fill a statistics buffer by hand)."""
+    return torch.round(t.double() * FX_STAT).to(torch.int64).view(torch.float64)
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -100,7 +100,7 @@ def test_igemm_epilogue_and_channel_chunks(dt):
     H.run_lattice_op("conv_fwd", w, H.to_cl(x, H.DT[dt]), out, s, bias=dev[0].data_ptr(), scale=dev[1].data_ptr(), shift=dev[2].data_ptr(), alpha=dev[3].data_ptr(), act=L.ACT_PRELU,
                      res_mode=L.RES_ADD, res=H.tdesc(rcl), stats=stats.data_ptr(), stats_stride=32, lds_budget=24 * 1024)
     np.testing.assert_allclose(H.from_cl(out).numpy(), y.float().numpy(), atol=_tol(dt, y))
-    st = stats.cpu().view(L.STAT_SHARDS, 2, 32).sum(0)
+    st = H.stat_decode(stats).cpu().view(L.STAT_SHARDS, 2, 32).sum(0)
     np.testing.assert_allclose(st[0].numpy(), pre.sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(st[1].numpy(), (pre * pre).sum((0, 2, 3, 4)).numpy(), rtol=1e-4)
 
@@ -193,11 +193,15 @@ def test_wgrad_narrow(k, cin, cout, dims, dt):
     else:  # t = x (cin channels), s = dY, sign -1: dw[0][c][tap]
         t_cl, s_cl, sign = H.to_cl(x, H.DT[dt]), H.to_cl(gy, H.DT[dt]), -1
     scr = torch.zeros(1 << 20, device="cuda")
+    db = torch.zeros(1, device="cuda") if sign == -1 else None  # C -> 1: the bias gradient sum(dY) rides in the same slabs
     for _ in range(2):  # accumulates into dw
-        L.check(lib.vsseg_wgrad_narrow(H.tdesc(t_cl), s_cl.data_ptr(), k[0], sign, dw.data_ptr(), k[0] * k[1], scr.data_ptr(), scr.numel(), H.stream()))
+        L.check(lib.vsseg_wgrad_narrow(H.tdesc(t_cl), s_cl.data_ptr(), k[0], sign, dw.data_ptr(), k[0] * k[1], db.data_ptr() if db is not None else None, scr.data_ptr(), scr.numel(), H.stream()))
     torch.cuda.synchronize()
     ref = 2 * w.grad.float()
     np.testing.assert_allclose(dw.cpu().numpy(), ref.numpy(), atol=(5e-5 if dt == "fp32" else 1e-4) * float(ref.abs().max()))
+    if db is not None:
+        want = 2 * float(gy.double().sum())
+        assert abs(float(db) - want) <= 1e-4 * float(gy.abs().sum()) + 1e-4, (float(db), want)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
@@ -238,7 +242,7 @@ def test_igemm_512_voxel_tiles(dims, dt):
     keep = H.run_lattice_op("conv_fwd", w, H.to_cl(x, H.DT[dt]), out, s, bias=bias.data_ptr(), stats=stats.data_ptr(), stats_stride=48, mtw=8)
     assert keep[0][1].mtw == 8 and keep[0][1].nt == 3
     np.testing.assert_allclose(H.from_cl(out).numpy(), y.detach().float().numpy(), atol=_tol(dt, y))
-    st = stats.cpu().view(L.STAT_SHARDS, 2, 48).sum(0)
+    st = H.stat_decode(stats).cpu().view(L.STAT_SHARDS, 2, 48).sum(0)
     np.testing.assert_allclose(st[0].numpy(), y.detach().sum((0, 2, 3, 4)).numpy(), rtol=1e-4, atol=2e-2)
     # data gradient (48 output channels, NT 3) with the same tile, no auxiliary operand
     gy = _round(torch.randn(*y.shape), dt)
@@ -270,8 +274,8 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop, stored):
     # statistics through the same sharded fp64 buffer the conv epilogue fills
     stats = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
     yf = H.from_cl(ycl).double()
-    stats[0, 0] = yf.sum((0, 2, 3, 4)).cuda()
-    stats[0, 1] = (yf * yf).sum((0, 2, 3, 4)).cuda()
+    stats[0, 0] = H.stat_encode(yf.sum((0, 2, 3, 4))).cuda()  # (fixed-point, as vsseg_fx_add leaves them)
+    stats[0, 1] = H.stat_encode((yf * yf).sum((0, 2, 3, 4))).cuda()
     g, be, al = sd["b.norm.weight"].cuda(), sd["b.norm.bias"].cuda(), sd["b.act.weight"].cuda()
     rm, rv, nb = sd["b.norm.running_mean"].cuda(), sd["b.norm.running_var"].cuda(), torch.zeros(1, dtype=torch.int64, device="cuda")
     vec = torch.zeros(6, c, device="cuda")
@@ -404,7 +408,7 @@ def test_every_candidate_plan_gives_the_same_convolution(kind, k, cin, cout, dim
             tag = f"{mode} tile={pl.tile} mtw={pl.mtw} ck={pl.ck} ns={pl.nsplit} D={pl.depth}"
             np.testing.assert_allclose(H.from_cl(out).numpy(), ref.float().numpy(), atol=_tol(dt, ref), err_msg=tag)
             if stats is not None:
-                st = stats.cpu().view(L.STAT_SHARDS, 2, -1).sum(0)[:, :nout]
+                st = H.stat_decode(stats).cpu().view(L.STAT_SHARDS, 2, -1).sum(0)[:, :nout]
                 np.testing.assert_allclose(st[0].numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2, err_msg=tag)
 
 
@@ -486,7 +490,7 @@ def test_streaming_kernel_equals_general_kernel(kind, k, cin, cout, dims, split)
         if mode == "plain":
             np.testing.assert_allclose(H.from_cl(os_).numpy(), want.float().numpy(), atol=_tol(dt, want))
         if mode == "stats":
-            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), ss.view(L.STAT_SHARDS, 2, -1).sum(0)
+            a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(ss).view(L.STAT_SHARDS, 2, -1).sum(0)
             np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
             np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
 
@@ -572,7 +576,7 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
         if mode == "plain":
             np.testing.assert_allclose(H.from_cl(om).numpy(), want.float().numpy(), atol=_tol(dt, want))
         if mode == "stats":
-            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), sm.view(L.STAT_SHARDS, 2, -1).sum(0)
+            a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
             np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
@@ -693,7 +697,7 @@ def test_compute_kernel_equals_general_kernel(kind, cin, cout, dims, split):
         if mode == "plain":
             np.testing.assert_allclose(H.from_cl(oc).numpy(), want.float().numpy(), atol=_tol(dt, want))
         if mode == "stats":
-            a, bb = sg.view(L.STAT_SHARDS, 2, -1).sum(0), sc.view(L.STAT_SHARDS, 2, -1).sum(0)
+            a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sc).view(L.STAT_SHARDS, 2, -1).sum(0)
             np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
             np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=2e-2)
 
@@ -749,7 +753,7 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
     np.testing.assert_allclose(H.from_cl(out_b).numpy(), want.float().numpy(), atol=_tol(dt, want))
     assert float((out_a.float() - out_b.float()).abs().max()) <= 2 * _tol(dt, want)  # same products, different fp32 summation order of the taps
     if mode == "stats":
-        a, bb = sa.view(L.STAT_SHARDS, 2, -1).sum(0), sb.view(L.STAT_SHARDS, 2, -1).sum(0)
+        a, bb = H.stat_decode(sa).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sb).view(L.STAT_SHARDS, 2, -1).sum(0)
         np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-2)
         np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2)
 

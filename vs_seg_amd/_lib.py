@@ -133,7 +133,7 @@ def lib():
         L.vsseg_igemm.argtypes = [C.POINTER(IgemmDesc), vp]
         L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
         L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
-        L.vsseg_wgrad_narrow.argtypes = [Tensor, vp, i32, i32, vp, C.c_int64, vp, C.c_int64, vp]
+        L.vsseg_wgrad_narrow.argtypes = [Tensor, vp, i32, i32, vp, C.c_int64, vp, vp, C.c_int64, vp]
         L.vsseg_gather_cast.argtypes = [vp, vp, vp, vp, i64, i32, vp]
         L.vsseg_merge_residual_grads.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
         L.vsseg_stage_input.argtypes = [vp, i32, I3, I3, Tensor, vp]

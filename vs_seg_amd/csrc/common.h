@@ -145,6 +145,20 @@ __device__ __forceinline__ void dropout_resolve_seed(uint64_t& seed, uint32_t& s
   }
 }
 
+// a*b + c that hipcc may NOT fuse with its neighbours into v_pk_fma_f32 with an op_sel broadcast of one half of a register pair.  That form — four
+// products of 4 channels with ONE per-voxel scalar (the attention gate) — returned the addend alone in the low halves of lanes 48-63 in a
+// timing-dependent ~1e-4 of the elements (gfx950, ROCm 7.2; found by the run-to-run bit-identity test, reproduced in isolation: the same source
+// with unfused v_fma_f32 is exact and deterministic).  The empty asm makes the multiplier opaque per element, so no broadcast pair is formed.
+__device__ __forceinline__ float vsseg_fma_unpacked(float a, float b, float c) {
+  asm volatile("" : "+v"(b));
+  return __builtin_fmaf(a, b, c);
+}
+
+__device__ __forceinline__ float vsseg_mul_unpacked(float a, float b) {  // same for a plain product with a broadcast scalar
+  asm volatile("" : "+v"(b));
+  return a * b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -168,6 +182,19 @@ __device__ __forceinline__ void vsseg_dma16(const void* gsrc, const void* lds_wa
   const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(vsseg_lds_cvoid_t*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory", "m0");
 }
+
+// Order-independent accumulation across workgroups: a partial sum is added as a 64-bit FIXED-POINT integer (integer addition is associative, so the
+// total does not depend on the order in which workgroups finish — fp64 atomics differ in the last bits from run to run, and training-mode BatchNorm
+// turns that into different bf16 roundings downstream).  The accumulator slots are the zeroed `double` buffers of the C ABI reinterpreted as int64.
+//   statistics (sum, sum of squares of a convolution output, Dice sums): 2^-20 resolution per addend — an absolute error of <= 1e-6 * addends / count in a
+//     mean / variance, far below BatchNorm's eps = 1e-5 and below the fp32 rounding of the partial sums themselves; range 2^43 = 8.8e12 per slot
+//   gradient sums (BatchNorm backward, PReLU slope, bias gradients): 2^-44 resolution, range 2^19 = 5e5 per slot (the gradients of an O(1) loss)
+constexpr double VSSEG_FX_STAT = 1048576.0;         // 2^20
+constexpr double VSSEG_FX_GRAD = 17592186044416.0;  // 2^44
+__device__ __forceinline__ void vsseg_fx_add(double* slot, double v, double scale) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * scale));
+}
+__device__ __forceinline__ double vsseg_fx_get(const double* slot, double scale) { return (double)*reinterpret_cast<const long long*>(slot) / scale; }
 
 // Partial-sum slabs slab[b][i] (b = workgroup of the producing kernel, i = output element) summed over all b by a 1024-thread block that owns 64
 // consecutive elements: thread (il = tid & 63, bl = tid >> 6) adds the slabs bl, bl + 16, ... with 8 independent loads in flight (<= 2048 slabs: 16
@@ -194,6 +221,14 @@ __device__ __forceinline__ float vsseg_slab_sum(const float* __restrict__ slab, 
     for (int j = 0; j < 16; ++j) r += lds1024[j * 64 + il];
   }
   return r;
+}
+
+// dst[i] += sum over rows b of slab[b][i], i < nvalid <= total (bias-gradient rows of the weight-gradient kernels): the same fixed-order sum
+static __global__ __launch_bounds__(VSSEG_SLAB_THREADS) void vsseg_slab_add_kernel(const float* __restrict__ slab, int nrows, int total, int nvalid, float* __restrict__ dst) {
+  __shared__ float lds[VSSEG_SLAB_THREADS];
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const float s = vsseg_slab_sum(slab, total, i, nrows, lds);
+  if (threadIdx.x < 64 && i < nvalid) dst[i] += s;
 }
 
 static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }

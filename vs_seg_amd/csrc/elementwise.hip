@@ -141,8 +141,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride,
   static_assert(VSSEG_STAT_SHARDS == 256, "thread = shard");
   __shared__ double part[4];
   const int ch = blockIdx.x, sh = threadIdx.x;
-  const double s = block256_sum_d(stats[(int64_t)sh * 2 * stride + ch], part);
-  const double q = block256_sum_d(stats[(int64_t)sh * 2 * stride + stride + ch], part);
+  const double s = block256_sum_d(vsseg_fx_get(&stats[(int64_t)sh * 2 * stride + ch], VSSEG_FX_STAT), part);  // fixed-point shards (vsseg_fx_add), fixed summation order
+  const double q = block256_sum_d(vsseg_fx_get(&stats[(int64_t)sh * 2 * stride + stride + ch], VSSEG_FX_STAT), part);
   if (threadIdx.x != 0) return;
   if (ch == 0 && num_batches) *num_batches += 1;
   double m = s / count;
@@ -388,9 +388,9 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
     const int which = i / C, ch = i % C;
     double val = (double)wsum(i);
     if (which == 1) val = (double)a.invstd[ch] * (val - (double)a.mean[ch] * (double)wsum(ch));  // sum(dz * xhat) of this workgroup
-    atomicAdd(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val);
+    vsseg_fx_add(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val, VSSEG_FX_GRAD);  // order-independent (fixed-point integer atomics)
   }
-  if (threadIdx.x == 0) atomicAdd(&alpha_acc[shard], (double)wsum(3 * C));
+  if (threadIdx.x == 0) vsseg_fx_add(&alpha_acc[shard], (double)wsum(3 * C), VSSEG_FX_GRAD);
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, const uint8_t* keep_in, void* stream) {
@@ -420,11 +420,11 @@ __global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int 
   __shared__ double part[4];
   const int ch = blockIdx.x, sh = threadIdx.x;  // one block per channel, thread = shard
   const double* base = sums + (int64_t)sh * 3 * stride + ch;
-  const double s = block256_sum_d(base[0], part);
-  const double q = block256_sum_d(base[stride], part);
-  const double r = block256_sum_d(base[2 * stride], part);
+  const double s = block256_sum_d(vsseg_fx_get(&base[0], VSSEG_FX_GRAD), part);  // fixed-point shards (vsseg_fx_add)
+  const double q = block256_sum_d(vsseg_fx_get(&base[stride], VSSEG_FX_GRAD), part);
+  const double r = block256_sum_d(vsseg_fx_get(&base[2 * stride], VSSEG_FX_GRAD), part);
   double a = 0.0;
-  if (ch == 0) a = block256_sum_d(alpha_acc[sh], part);  // block-uniform branch
+  if (ch == 0) a = block256_sum_d(vsseg_fx_get(&alpha_acc[sh], VSSEG_FX_GRAD), part);  // block-uniform branch
   if (threadIdx.x != 0) return;
   if (ch == 0) *dalpha += (float)a;
   if (dres_bias) dres_bias[ch] += (float)r;  // d(out)/d(residual) = 1: the residual convolution's bias gradient is sum(dout)

@@ -638,7 +638,8 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
             if (k.aux_mode == 3) {
               val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
             } else if (k.aux_mode == 4) {
-              val[0] += av.x * gate[m]; val[1] += av.y * gate[m]; val[2] += av.z * gate[m]; val[3] += av.w * gate[m];
+              val[0] = vsseg_fma_unpacked(av.x, gate[m], val[0]); val[1] = vsseg_fma_unpacked(av.y, gate[m], val[1]);  // (not v_pk_fma_f32 op_sel: common.h)
+              val[2] = vsseg_fma_unpacked(av.z, gate[m], val[2]); val[3] = vsseg_fma_unpacked(av.w, gate[m], val[3]);
             } else {
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             }
@@ -723,11 +724,10 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
     k.prof[8] = (unsigned long long)nstages;
   }
 #endif
-  if constexpr (STATS) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics
+  if constexpr (STATS) {  // per-channel sum / sum-of-squares of all this workgroup's tiles: shuffle tree -> one LDS row per consumer wave, summed in wave
+                          // order -> sharded statistics as fixed-point integer atomics (order-independent: vsseg_fx_add)
     __syncthreads();
-    float* red = epi;  // reuse [2][NT*16]
-    for (int i = tid; i < 2 * NT * 16; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(Wl);  // [4 consumer waves][2][NT*16]: the packed weights are no longer needed (>= 1 KiB per channel tile)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (l15 == 0 && !producer) {
-          atomicAdd(&red[t * 16 + g * 4 + r], s);
-          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
+          red[wave * (2 * NT * 16) + t * 16 + g * 4 + r] = s;
+          red[wave * (2 * NT * 16) + NT * 16 + t * 16 + g * 4 + r] = q;
         }
       }
     __syncthreads();
@@ -745,7 +745,8 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
     for (int i = tid + (producer ? 1 << 20 : 0); i < 2 * NT * 16; i += 256) {  // consumers only (the producer half would add the sums a second time)
       int which = i / (NT * 16), cc = i - which * NT * 16;
       int c = split * NT * 16 + cc;
-      if (c < cout) atomicAdd(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)red[i]);
+      const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
+      if (c < cout) vsseg_fx_add(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)v, VSSEG_FX_STAT);
     }
   }
 }

@@ -31,7 +31,10 @@ extern "C" int vsseg_maxpool_label(const float* src, int32_t n, const int32_t sd
   return VSSEG_OK;
 }
 
-__device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double* dst) {
+// `fx` > 0: the block's sums are added as fixed-point integers of that scale (vsseg_fx_add: order-independent); 0: fp64 atomics (the hard-Dice voxel
+// counts: integers, exact in fp64 whatever the order)
+constexpr double VSSEG_FX_DICE = 4294967296.0;  // 2^32: sums of at most 2^31 voxel weights in [0, 1], 2.3e-10 resolution
+__device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double* dst, double fx) {
   __shared__ double sh[16][8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = 0; k < nvals; ++k) {
@@ -42,7 +45,8 @@ __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double
   if (threadIdx.x < nvals) {
     double t = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w][threadIdx.x];
-    atomicAdd(&dst[threadIdx.x], t);
+    if (fx > 0.0) vsseg_fx_add(&dst[threadIdx.x], t, fx);
+    else atomicAdd(&dst[threadIdx.x], t);
   }
 }
 
@@ -64,7 +68,7 @@ __global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitc
     I1 += w1 * g1 * p1; G1 += w1 * g1; P1 += w1 * p1;
   }
   double vals[6] = {I0, G0, P0, I1, G1, P1};
-  block_reduce_add(vals, 6, sums + (int64_t)b * 6);
+  block_reduce_add(vals, 6, sums + (int64_t)b * 6, VSSEG_FX_DICE);
 }
 extern "C" int vsseg_dice_pred_sums(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, double* sums, void* stream) {
   VSSEG_CHECK(logits && label && sums && pitch >= 2 && pitch % 2 == 0 && n >= 1, "vsseg_dice_pred_sums: bad arguments");
@@ -85,7 +89,7 @@ __global__ void dice_att_sums_kernel(const float* __restrict__ att, const float*
     I += g * p; G += g; P += p;
   }
   double vals[3] = {I, G, P};
-  block_reduce_add(vals, 3, sums + (int64_t)b * 3);
+  block_reduce_add(vals, 3, sums + (int64_t)b * 3, VSSEG_FX_DICE);
 }
 extern "C" int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t nvox, double* sums, void* stream) {
   VSSEG_CHECK(att && label && sums && n >= 1, "vsseg_dice_att_sums: bad arguments");
@@ -101,7 +105,8 @@ __global__ void dice_finalize_kernel(const double* pred_sums, const double* att_
   double total = 0;
   for (int b = 0; b < n; ++b)
     for (int c = 0; c < 2; ++c) {
-      const double* s = pred_sums + (b * 2 + c) * 3;
+      const double* sp = pred_sums + (b * 2 + c) * 3;
+      const double s[3] = {vsseg_fx_get(sp, VSSEG_FX_DICE), vsseg_fx_get(sp + 1, VSSEG_FX_DICE), vsseg_fx_get(sp + 2, VSSEG_FX_DICE)};
       double D = s[1] + s[2] + SMOOTH, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / (2.0 * n);
       total += wgt * (1.0 - num / D);
       coef[(b * 2 + c) * 2 + 0] = (float)(-2.0 / D * wgt);
@@ -109,7 +114,8 @@ __global__ void dice_finalize_kernel(const double* pred_sums, const double* att_
     }
   for (int l = 0; l < nlevels; ++l)
     for (int b = 0; b < n; ++b) {
-      const double* s = att_sums + (l * n + b) * 3;
+      const double* sp = att_sums + (l * n + b) * 3;
+      const double s[3] = {vsseg_fx_get(sp, VSSEG_FX_DICE), vsseg_fx_get(sp + 1, VSSEG_FX_DICE), vsseg_fx_get(sp + 2, VSSEG_FX_DICE)};
       double D = s[1] + s[2] + SMOOTH, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / ((double)nlevels * n);
       total += wgt * (1.0 - num / D);
       coef[n * 4 + (l * n + b) * 2 + 0] = (float)(-2.0 / D * wgt);
@@ -185,7 +191,7 @@ __global__ void hard_dice_kernel(const float* __restrict__ logits, int pitch, co
     pg += pr * gg; p += pr; g += gg;
   }
   double vals[3] = {pg, p, g};
-  block_reduce_add(vals, 3, counts);
+  block_reduce_add(vals, 3, counts, 0.0);
 }
 extern "C" int vsseg_hard_dice_counts(const float* logits, int32_t pitch, const float* label, int64_t nvox, double* counts, void* stream) {
   VSSEG_CHECK(logits && label && counts && pitch >= 2 && pitch % 2 == 0, "vsseg_hard_dice_counts: bad arguments");

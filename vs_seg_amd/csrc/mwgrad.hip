@@ -25,7 +25,7 @@ struct MwgradK {
   const char* h0; const char* h1;  // H (ring operand): channels [0, csplit) / [csplit, c) biased by -csplit channels
   const char* p;                   // P (centre operand), one part
   float* slab;                     // [gridDim.x][NTH][9][NTP*16][16]
-  float* dbias;                    // optional: dbias[cP] += sum_q P[q][cP]
+  float* dbias;                    // optional: [gridDim.x][NTP*16] rows of partial bias gradients sum_q P[q][cP] (summed in a fixed order by vsseg_slab_add_kernel)
   const float* h_gate;             // GIN: fp32 attention map of H: voxel v of H is multiplied by (1 + h_gate[v]) on load (mconv.hip, MODE 3)
   const void* zeros;
   int h_csplit_pc, h_vox_bytes, p_vox_bytes, cp_valid;
@@ -126,10 +126,10 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
         const uint4 qv = *p;
         const float gg = 1.f + gv[u];
         uint4 o;
-        o.x = f2bf2(__uint_as_float(qv.x << 16) * gg, __uint_as_float(qv.x & 0xffff0000u) * gg);
-        o.y = f2bf2(__uint_as_float(qv.y << 16) * gg, __uint_as_float(qv.y & 0xffff0000u) * gg);
-        o.z = f2bf2(__uint_as_float(qv.z << 16) * gg, __uint_as_float(qv.z & 0xffff0000u) * gg);
-        o.w = f2bf2(__uint_as_float(qv.w << 16) * gg, __uint_as_float(qv.w & 0xffff0000u) * gg);
+        o.x = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.x << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.x & 0xffff0000u), gg));
+        o.y = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.y << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.y & 0xffff0000u), gg));
+        o.z = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.z << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.z & 0xffff0000u), gg));
+        o.w = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.w << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.w & 0xffff0000u), gg));
         *p = o;
       }
     }
@@ -274,17 +274,15 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
       __syncthreads();
     }
   }
-  if (k.dbias != nullptr) {  // every column of accb holds the same row sums
-    float* bred = red + UNITS * NTP * 256;  // behind the accumulator image (UNITSPLIT: unused ring space)
+  if (k.dbias != nullptr) {  // every column of accb holds the same row sums -> this workgroup's row of the bias slab
+    float* bred = red + UNITS * NTP * 256;  // behind the accumulator image
+    float* brow = k.dbias + (int64_t)blockIdx.x * (NTP * 16);
     if (UNITSPLIT) {
       if (wave == 0 && l15 == 0) {
 #pragma unroll
         for (int tp = 0; tp < NTP; ++tp)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int cp = tp * 16 + g * 4 + r;
-            if (cp < k.cp_valid) atomicAdd(&k.dbias[cp], accb[tp][r]);
-          }
+          for (int r = 0; r < 4; ++r) brow[tp * 16 + g * 4 + r] = accb[tp][r];
       }
     } else {
       if (l15 == 0) {
@@ -294,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
           for (int r = 0; r < 4; ++r) bred[wave * (NTP * 16) + tp * 16 + g * 4 + r] = accb[tp][r];
       }
       __syncthreads();
-      if (tid < NTP * 16 && tid < k.cp_valid) atomicAdd(&k.dbias[tid], (bred[tid] + bred[NTP * 16 + tid]) + (bred[2 * NTP * 16 + tid] + bred[3 * NTP * 16 + tid]));
+      if (tid < NTP * 16) brow[tid] = (bred[tid] + bred[NTP * 16 + tid]) + (bred[2 * NTP * 16 + tid] + bred[3 * NTP * 16 + tid]);  // the four waves' K-step shares, fixed order
     }
   }
 }
@@ -371,7 +369,6 @@ int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_
   k.p = reinterpret_cast<const char*>(d->p.ptr);
   k.p_vox_bytes = d->p.pitch * 2;
   k.cp_valid = d->cp_valid;
-  k.dbias = d->dbias_p;
   k.h_gate = d->h_gate;
   k.zeros = zeros;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
@@ -381,10 +378,16 @@ int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_
   const int64_t per_blk = (int64_t)nth * slab_chunk;
   int64_t grid = (int64_t)d->p.n * k.nxs * k.nyb * k.nzb;
   VSSEG_CHECK(grid > 0 && grid < (1ll << 24), "vsseg_wgrad: bad marching grid");
-  VSSEG_CHECK(d->scratch && d->scratch_elems >= grid * per_blk, "vsseg_wgrad: scratch too small for %lld marching workgroups (%lld < %lld floats); use longer x segments", (long long)grid,
+  const int brow = d->ntp * 16;
+  VSSEG_CHECK(d->scratch && d->scratch_elems >= grid * (per_blk + (d->dbias_p ? brow : 0)), "vsseg_wgrad: scratch too small for %lld marching workgroups (%lld < %lld floats); use longer x segments", (long long)grid,
               (long long)d->scratch_elems, (long long)(grid * per_blk));
   k.slab = d->scratch;
+  k.dbias = d->dbias_p ? d->scratch + grid * per_blk : nullptr;  // bias rows behind the slabs
   int rc = e->fn(k, (int)grid, s);
   if (rc) return rc;
-  return vsseg_wgrad_reduce_launch(d, d->scratch, (int)grid, nth, slab_chunk, s);
+  rc = vsseg_wgrad_reduce_launch(d, d->scratch, (int)grid, nth, slab_chunk, s);
+  if (rc || !d->dbias_p) return rc;
+  hipLaunchKernelGGL(vsseg_slab_add_kernel, dim3((brow + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)k.dbias, (int)grid, brow, d->cp_valid, d->dbias_p);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad (marching, bias)");
+  return VSSEG_OK;
 }

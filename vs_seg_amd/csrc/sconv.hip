@@ -257,7 +257,8 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
             } else if (KIND == 2 && k.aux_mode != 4) {
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             } else {
-              val[0] += av.x * gt; val[1] += av.y * gt; val[2] += av.z * gt; val[3] += av.w * gt;
+              val[0] = vsseg_fma_unpacked(av.x, gt, val[0]); val[1] = vsseg_fma_unpacked(av.y, gt, val[1]);  // (not v_pk_fma_f32 op_sel: common.h)
+              val[2] = vsseg_fma_unpacked(av.z, gt, val[2]); val[3] = vsseg_fma_unpacked(av.w, gt, val[3]);
             }
           }
           char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + out_vox(m, t) * k.out_vox_bytes + out_ch(t) * (int)out_es;
@@ -281,11 +282,10 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     else epilogue(std::integral_constant<int, 2>{});
   }
 
-  if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's tiles: shuffle tree -> LDS -> sharded fp64 atomics (layout of vsseg_igemm_desc.stats)
+  if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's voxels: shuffle tree -> one LDS row per wave, summed in wave order -> the layer's
+                          // sharded statistics as fixed-point integer atomics (order-independent: vsseg_fx_add; layout of vsseg_igemm_desc.stats)
     __syncthreads();
-    float* red = epi;
-    for (int i = tid; i < 2 * NT * 16; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][NT*16]: the weights are no longer needed
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -294,15 +294,16 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (l15 == 0) {
-          atomicAdd(&red[t * 16 + g * 4 + r], s);
-          atomicAdd(&red[NT * 16 + t * 16 + g * 4 + r], q);
+          red[wave * (2 * NT * 16) + t * 16 + g * 4 + r] = s;
+          red[wave * (2 * NT * 16) + NT * 16 + t * 16 + g * 4 + r] = q;
         }
       }
     __syncthreads();
     double* st = k.stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * k.stats_stride;
     for (int i = tid; i < 2 * NT * 16; i += 256) {
       const int which = i / (NT * 16), c = i - which * NT * 16;
-      if (c < cout) atomicAdd(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)red[i]);
+      const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
+      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)v, VSSEG_FX_STAT);
     }
   }
 }

@@ -32,7 +32,8 @@ struct WgradK {
   int hchunks;    // 16-channel chunks of H in total (slab layout); a workgroup owns HG consecutive ones
   int64_t total_tiles;
   const void* zeros;  // >= 16 zero bytes in global memory (source of out-of-bounds pieces)
-  float* slab;     // [gridDim.x][hchunks][ntaps][ntp*16][16] partial sums
+  float* slab;     // [gridDim.x * wv][hchunks][ntaps][ntp*16][16] partial sums (one slab per workgroup and K-step share: plain stores, no atomics)
+  float* bias_slab;  // [gridDim.x * wv][ntp*16] partial bias gradients (workgroups of H-chunk group 0), or nullptr
   int slab_chunk;  // ntaps * ntp*16 * 16
 };
 
@@ -307,20 +308,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     }
   }
 
-  if (do_bias && l15 == 0) {  // every column of accb holds the same row sums
+  if (do_bias && l15 == 0) {  // every column of accb holds the same row sums: this wave's row of the bias slab (summed in a fixed order by vsseg_slab_add_kernel)
+    float* brow = k.bias_slab + ((int64_t)blockIdx.x * k.wv + wv) * (NTP * 16);
 #pragma unroll
     for (int p = 0; p < NTP; ++p)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int cp = p * 16 + g * 4 + r;
-        if (cp < d.cp_valid) atomicAdd(&d.dbias_p[cp], accb[p][r]);
-      }
+      for (int r = 0; r < 4; ++r) brow[p * 16 + g * 4 + r] = accb[p][r];
   }
   // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) -> this workgroup's slab [tap][cP][16]
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     if (chunk0 + h >= k.hchunks) break;  // the last group may be short
-    float* slab = k.slab + ((int64_t)blockIdx.x * k.hchunks + chunk0 + h) * k.slab_chunk;
+    float* slab = k.slab + (((int64_t)blockIdx.x * k.wv + wv) * k.hchunks + chunk0 + h) * k.slab_chunk;  // K-steps split over waves (1x1x1 kernels): one slab per share
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       const int t = wt + i * k.wt;
@@ -331,8 +330,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
         for (int r = 0; r < 4; ++r) {
           const int cp = p * 16 + g * 4 + r;
           float* dst = slab + ((int64_t)t * (NTP * 16) + cp) * 16 + l15;
-          if (k.wv == 1) *dst = acc[i][h][p][r];
-          else atomicAdd(dst, acc[i][h][p][r]);  // K-steps split over waves (1x1x1 kernels): slab pre-zeroed by the host wrapper
+          *dst = acc[i][h][p][r];
         }
     }
   }
@@ -498,14 +496,19 @@ extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   VSSEG_CHECK(d->scratch && d->scratch_elems >= (int64_t)hchunks * k.slab_chunk, "vsseg_wgrad: scratch too small (%lld < %lld floats)", (long long)d->scratch_elems, (long long)hchunks * k.slab_chunk);
   int64_t gx = d->persistent_blocks > 0 ? d->persistent_blocks : 256;
   if (gx > k.total_tiles) gx = k.total_tiles;
-  const int64_t cap = d->scratch_elems / ((int64_t)hchunks * k.slab_chunk);
+  const int64_t per_blk = (int64_t)k.wv * ((int64_t)hchunks * k.slab_chunk + (d->dbias_p ? d->ntp * 16 : 0));  // slabs (+ bias rows) of one workgroup
+  const int64_t cap = d->scratch_elems / per_blk;
   if (gx > cap) gx = cap;
   k.slab = d->scratch;
+  k.bias_slab = d->dbias_p ? d->scratch + gx * k.wv * (int64_t)hchunks * k.slab_chunk : nullptr;
   k.walk = 1;
-  if (k.wv != 1) hipMemsetAsync(d->scratch, 0, sizeof(float) * gx * hchunks * k.slab_chunk, as_stream(stream));
   dim3 grid((unsigned)gx, (unsigned)(hchunks / hg));
   int rc = d->p.dtype == VSSEG_F32 ? vsseg_wgrad_launch_f32(k, maxt, hg, grid, off, as_stream(stream)) : vsseg_wgrad_launch_bf16(k, maxt, hg, grid, off, as_stream(stream));
   if (rc) return rc;
-  return vsseg_wgrad_reduce_launch(d, d->scratch, (int)grid.x, hchunks, k.slab_chunk, as_stream(stream));
+  rc = vsseg_wgrad_reduce_launch(d, d->scratch, (int)grid.x * k.wv, hchunks, k.slab_chunk, as_stream(stream));
+  if (rc || !d->dbias_p) return rc;
+  hipLaunchKernelGGL(vsseg_slab_add_kernel, dim3((d->ntp * 16 + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, as_stream(stream), (const float*)k.bias_slab, (int)grid.x * k.wv, d->ntp * 16, d->cp_valid, d->dbias_p);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad(bias)");
+  return VSSEG_OK;
 }
 #endif  // WG_INST

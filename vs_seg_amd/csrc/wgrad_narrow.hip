@@ -20,7 +20,8 @@ struct WnK {
   const void* t;
   const void* s;
   float* dw;
-  float* slab;  // [gridDim.x][NT * C] partial sums
+  float* slab;  // [gridDim.x][NT * C (+ 1)] partial sums (+ the bias gradient sum_v s[v] of the C -> 1 case)
+  int bias;     // 1: slab rows carry one more element, sum of the one-channel field over this workgroup's voxels
   int tpitch, C, cgs;
   int n, X, Y, Z, yq;  // yq = Y / 4
   int sign;
@@ -35,10 +36,9 @@ template <> __device__ __forceinline__ float wn_ld<bf16_t>(const bf16_t* p) { re
 template <typename T, int K3>  // K3: 3 = 3x3x1 taps, 1 = 1x1x1
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
   constexpr int NT = K3 * K3, ROWS = K3 == 3 ? 6 : 4, R = K3 / 2;
-  __shared__ float red[NT * 64];
+  __shared__ float red[4][NT * 64 + 1];  // one row per wave, summed in wave order (run-to-run bit-identical)
   const int tid = threadIdx.x, C = k.C, cgs = k.cgs;
-  for (int i = tid; i < NT * C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  float bsum = 0.f;
   const int64_t gt = blockIdx.x * 256ll + tid, nthreads = (int64_t)gridDim.x * 256;
   const int cg = (int)(gt % cgs);
   const int64_t step = nthreads / cgs;
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
         const float v = wn_ld<T>(s0 + (yok ? (j - R) * Z : 0));
         sr[j] = (xok && yok) ? v : 0.f;
       }
+      if (dxi == R) bsum += (sr[R] + sr[R + 1]) + (sr[R + 2] + sr[R + 3]);  // the four centre voxels of this item
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -93,35 +94,41 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
     x += sx; if (x >= X) { x -= X; ++n; }
     n += sn;
   }
+  const int wave = tid >> 6;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float v = acc[t][c];
       for (int o = 32; o >= cgs; o >>= 1) v += __shfl_xor(v, o, 64);  // lanes with the same channel group (lane % cgs): cgs divides 64
-      if ((tid & 63) < cgs) atomicAdd(&red[t * C + cg * 8 + c], v);
+      if ((tid & 63) < cgs) red[wave][t * C + cg * 8 + c] = v;
     }
+  bsum = wave_sum(cg == 0 ? bsum : 0.f);  // every voxel is visited once per channel group: group 0 carries the bias sum
+  if ((tid & 63) == 0) red[wave][NT * C] = bsum;
   __syncthreads();
-  float* slab = k.slab + (int64_t)blockIdx.x * (NT * C);
-  for (int i = tid; i < NT * C; i += 256) slab[i] = red[i];
+  const int row = NT * C + (k.bias ? 1 : 0);
+  float* slab = k.slab + (int64_t)blockIdx.x * row;
+  for (int i = tid; i < row; i += 256) slab[i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
 // dw[c*stride_c + weight tap] += sum over workgroups of slab[b][t*C + c] (vsseg_slab_sum, as wgrad.hip) — one thread per element walking 1024
 // slabs cost 224 us per launch, as much as the reduction over the tensor itself
-__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_narrow_reduce_kernel(const float* __restrict__ slab, int nblk, int C, int K3, int sign, float* __restrict__ dw, int64_t stride_c) {
+__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_narrow_reduce_kernel(const float* __restrict__ slab, int nblk, int C, int K3, int sign, float* __restrict__ dw, int64_t stride_c, float* __restrict__ dbias) {
   __shared__ float lds[VSSEG_SLAB_THREADS];
   const int NT = K3 * K3, R = K3 / 2;
-  const int64_t total = (int64_t)NT * C;
+  const int64_t total = (int64_t)NT * C + (dbias ? 1 : 0);
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const float s = vsseg_slab_sum(slab, total, i, nblk, lds);
   if (threadIdx.x >= 64 || i >= total) return;
+  if (i == (int64_t)NT * C) { *dbias += s; return; }
   const int t = (int)i / C, c = (int)i - t * C;
   const int dx = t / K3 - R, dy = t % K3 - R;  // s-offset (dx, dy) = sign * (weight tap offset)
   const int widx = (sign * dx + R) * K3 + (sign * dy + R);
   dw[(int64_t)c * stride_c + widx] += s;
 }
 
-extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* scratch, int64_t scratch_elems, void* stream) {
+extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* dbias, float* scratch, int64_t scratch_elems, void* stream) {
+  VSSEG_CHECK(!dbias || sign == -1, "vsseg_wgrad_narrow: the bias gradient (sum of the one-channel dY) belongs to the C -> 1 case (sign = -1)");
   VSSEG_CHECK(t.ptr && s && dw && scratch && !t.ptr2, "vsseg_wgrad_narrow: bad pointers (two-part tensors are not supported)");
   VSSEG_CHECK(k3 == 1 || k3 == 3, "vsseg_wgrad_narrow: 3x3x1 or 1x1x1 kernels only (k3 = %d)", k3);
   VSSEG_CHECK(sign == 1 || sign == -1, "vsseg_wgrad_narrow: sign must be +1 or -1");
@@ -136,7 +143,8 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
   VSSEG_CHECK((int64_t)t.n * t.x * t.y * t.z < (1ll << 31), "vsseg_wgrad_narrow: more than 2^31 voxels");
   // >= 16 items per thread before another workgroup is worth its flush; at most 4 workgroups per CU
   int grid = grid_for(k.items * k.cgs / 16, 256, 256 * 4);
-  const int64_t cap = scratch_elems / (k3 * k3 * t.c);
+  k.bias = dbias ? 1 : 0;
+  const int64_t cap = scratch_elems / (k3 * k3 * t.c + 1);
   VSSEG_CHECK(cap >= 1, "vsseg_wgrad_narrow: scratch too small");
   if (grid > cap) grid = (int)cap;
   k.slab = scratch;
@@ -148,8 +156,8 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
     else hipLaunchKernelGGL((wgrad_narrow_kernel<bf16_t, 1>), dim3(grid), dim3(256), 0, as_stream(stream), k);
   }
   VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow");
-  const int total = k3 * k3 * t.c;
-  hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, as_stream(stream), (const float*)scratch, grid, (int)t.c, (int)k3, (int)sign, dw, stride_c);
+  const int total = k3 * k3 * t.c + (dbias ? 1 : 0);
+  hipLaunchKernelGGL(wgrad_narrow_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, as_stream(stream), (const float*)scratch, grid, (int)t.c, (int)k3, (int)sign, dw, stride_c, dbias);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad_narrow(reduce)");
   return VSSEG_OK;
 }

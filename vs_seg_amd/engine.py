@@ -593,7 +593,7 @@ class Plan:
             assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
             return gdesc(t)
 
-        def narrow_wgrad(Lr: Layer, x: TensorSpec, dy: L.Tensor, dy_compact: Optional[L.Tensor]) -> bool:
+        def narrow_wgrad(Lr: Layer, x: TensorSpec, dy: L.Tensor, dy_compact: Optional[L.Tensor], bias_grad: bool = False) -> bool:
             """One input or one output channel, 3x3x1 / 1x1x1, stride 1: the weight gradient is a bandwidth reduction over the C-channel
             operand (vsseg_wgrad_narrow) instead of an MFMA launch on a zero-extended one (narrow-channel tails off the matrix cores)."""
             if not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel not in ((3, 3, 1), (1, 1, 1)) or self.lv[Lr.level][1] % 4:
@@ -602,11 +602,13 @@ class Plan:
             scr = self.eng.wgrad_scratch()  # partial-sum slabs (shared with vsseg_wgrad: the weight-gradient launches serialise on one stream)
             if Lr.cin == 1 and Lr.cout in (8, 16, 32, 64) and x.root.name == prog.input.name and dy.c == Lr.cout and not dy.ptr2:
                 x1 = self._xdesc(x, True)  # the compact one-channel copy of the network input
-                B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
+                assert not bias_grad, "the 1 -> C narrow weight gradient does not reduce a bias gradient (those convolutions sit in front of a BatchNorm)"
+                B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, None, scr.data_ptr(), scr.numel()],
                           dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
                 return True
             if Lr.cout == 1 and Lr.cin in (8, 16, 32, 64) and dy_compact is not None and x.parts is None and x.base is None:
-                B.append([lib.vsseg_wgrad_narrow, [self._desc(x), dy_compact.ptr, k3, -1, self._gp(Lr.wkey), k3 * k3, scr.data_ptr(), scr.numel()],
+                # (the bias gradient of the C -> 1 convolution = sum of its one-channel dY rides in the same slabs: fixed summation order)
+                B.append([lib.vsseg_wgrad_narrow, [self._desc(x), dy_compact.ptr, k3, -1, self._gp(Lr.wkey), k3 * k3, self._gp(Lr.bkey) if bias_grad else None, scr.data_ptr(), scr.numel()],
                           dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cin + 1), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel}")])
                 return True
             return False
@@ -614,8 +616,7 @@ class Plan:
         def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None, gate=None):
             cp = self.cplans[Lr.prefix]
             wg = cp.wgrad
-            if narrow_wgrad(Lr, x, dy, dy_compact):
-                assert not bias_grad, "the narrow weight-gradient path does not reduce a bias gradient"
+            if narrow_wgrad(Lr, x, dy, dy_compact, bias_grad):
                 conv_backward_data(Lr, x, dy, relumask, dy_compact, gate)
                 return
             gl = self.gate_onload.get(x.name)  # the convolution's input is an attention-gated tensor that was never materialised: H = x, gated on load
@@ -791,12 +792,11 @@ class Plan:
                 else:
                     acc = contribution(op.x)
                 dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
-                sig = producer[op.att.name].layer  # the sigmoid convolution: its bias gradient is sum(dpre), reduced inside this kernel
-                folded_bias.add(sig.prefix)
+                sig = producer[op.att.name].layer  # the sigmoid convolution (its bias gradient sum(dpre) is reduced by its weight-gradient launch, in a fixed order)
                 want_c1 = (eng.narrow_wgrad and sig.kernel in ((3, 3, 1), (1, 1, 1)) and sig.cin in (8, 16, 32, 64) and self.lv[sig.level][1] % 4 == 0)
                 dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if want_c1 else None  # compact copy of d(pre-sigmoid): z-folded data gradient / narrow weight gradient
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), self._gp(sig.bkey), dpre1],
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), None, dpre1],
                           self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + 8 + 4)])
         self._finish_pack()
 
