@@ -3,11 +3,13 @@
 # Counters are collected in their own runs (--pmc only, never combined with a trace).  The launch plans are the shipped ones (vs_seg_amd/tuned_gfx950.json).
 R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
 TRAIN="--swi-volumes 0 --swi-cases 0 --fp32-steps 0 --no-cpu-baseline --no-parity"
+# HBM traffic first: bench.py reads profiles/roofline_traffic.json, so the committed bench line and the traffic table come from the SAME build and run
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/write.log 2>&1
+(cd $R && python tools/rocprof_summary.py pmc $OUT/fetch/*/*.db $OUT/write/*/*.db $OUT/roofline_traffic.json > $OUT/pmc_hbm.txt && cp $OUT/roofline_traffic.json profiles/roofline_traffic.json)
 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --steps 5 --warmup 2 $TRAIN > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/kts -- python $R/tools/profile_eval.py 8 > $OUT/kts.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/sfetch -- python $R/tools/profile_eval.py 2 > $OUT/sfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/swrite -- python $R/tools/profile_eval.py 2 > $OUT/swrite.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/sq1 -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/sq1.log 2>&1
@@ -15,7 +17,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY S
 cd $R
 python tools/rocprof_summary.py kernel $OUT/kt/*/*.db > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py kernel $OUT/kts/*/*.db > $OUT/swi_kernel_stats.txt
-python tools/rocprof_summary.py pmc $OUT/fetch/*/*.db $OUT/write/*/*.db $OUT/roofline_traffic.json > $OUT/pmc_hbm.txt
 python tools/rocprof_summary.py pmc $OUT/sfetch/*/*.db $OUT/swrite/*/*.db > $OUT/swi_pmc_hbm.txt
 python tools/rocprof_summary.py sq $OUT/sq1/*/*.db $OUT/sq2/*/*.db > $OUT/pmc_sq.txt
 rm -rf $OUT/kt $OUT/kts $OUT/fetch $OUT/write $OUT/sfetch $OUT/swrite $OUT/sq1 $OUT/sq2
