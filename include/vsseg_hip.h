@@ -94,6 +94,15 @@ typedef struct {
   const float* gate;       /* VSSEG_RES_GATE: fp32 attention map [N][X][Y][Z] of the output tensor, or NULL */
   const float* in_gate;    /* fp32 attention map [N][X][Y][Z] of the INPUT tensor, or NULL: input voxel v is multiplied by (1 + in_gate[v]) on load
                             * (AttentionBlock2 folded into the convolution that reads its output; marching kernel, depth -5, only) */
+  /* All output-parity classes of a strided transposed convolution / data gradient in ONE launch of the general kernel (class_split = number of
+   * classes, 2..8; 0 = off): `nsplit` = class_split, workgroup row s of the grid computes class s — ALL output channels (out.c = nt*16) at output
+   * voxels q*os + class_oo[s] — from the class's own taps class_tap[s][0..class_ntaps[s]) (indices into tap_off, which lists the union of the classes'
+   * input offsets; oo must be 0).  wpack is [class][nchunks][ksteps][nt][64][8] with ksteps = the largest class's; a class runs only its own K-steps.
+   * One read of the halo table, one launch and one weight staging per class instead of 8 launches of 15-40 us on levels 3-5. */
+  int32_t class_split;
+  int32_t class_oo[8][3];
+  int32_t class_ntaps[8];
+  int32_t class_tap[8][8];
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).

@@ -67,6 +67,12 @@ def igemm_desc(plan: P.IgemmPlan, wpack: torch.Tensor, inp: L.Tensor, out: L.Ten
     d.tile = L.i3(plan.tile)
     d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = plan.mtw, plan.nt, plan.nsplit, plan.ck, plan.nchunks, plan.ksteps, plan.depth
     d.wpack = wpack.data_ptr()
+    d.class_split = len(plan.classes) if plan.classes is not None else 0
+    for s_, c_ in enumerate(plan.classes or ()):
+        d.class_oo[s_][0], d.class_oo[s_][1], d.class_oo[s_][2] = c_.oo
+        d.class_ntaps[s_] = len(c_.taps)
+        for i, t in enumerate(plan.class_taps(s_)):
+            d.class_tap[s_][i] = t
     for k, v in kw.items():
         setattr(d, k, v)
     return d

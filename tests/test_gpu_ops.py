@@ -758,6 +758,76 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
         np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2)
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("kind,cin,cout,fine,mode", [("convT_fwd", 96, 80, (8, 8, 8), "stats"), ("convT_fwd", 64, 48, (16, 8, 16), "plain"), ("convT_fwd", 80, 64, (4, 4, 4), "residual"),
+                                                     ("conv_dgrad", 48, 64, (16, 16, 8), "accumulate"), ("conv_dgrad", 80, 80, (7, 9, 6), "plain"), ("conv_dgrad", 64, 80, (8, 8, 8), "relumask"),
+                                                     ("conv_dgrad", 16, 16, (12, 6, 10), "plain")])
+def test_class_split_launch_equals_per_class_launches(kind, cin, cout, fine, mode, dt):
+    """vsseg_igemm_desc.class_split: the eight output-parity classes of a 3x3x3 stride-(2,2,2) transposed convolution / data gradient as ONE
+    launch of the general kernel (workgroup row = class, 1..8 taps each).  Every candidate must equal the eight per-class launches (same
+    products; the fp32 summation order may differ with the channel chunk) and torch's fp64 result, for each epilogue the network uses, also
+    where the fine lattice is odd-sized (the classes with offset 1 are one voxel shorter)."""
+    lib = L.lib()
+    k, st = (3, 3, 3), (2, 2, 2)
+    torch.manual_seed(23)
+    n = 2
+    tdt = H.DT[dt]
+    if kind == "convT_fwd":
+        coarse = tuple(f // 2 for f in fine)
+        x = _round(torch.randn(n, cin, *coarse), dt)
+        w = _round(torch.randn(cin, cout, *k) / (cin * 27 / 8) ** 0.5, dt)
+        want = F.conv_transpose3d(x.double(), w.double(), stride=st, padding=1, output_padding=1)
+        inp_cl, nout, q = H.to_cl(x, tdt, P.round_up(cin, 8)), cout, coarse
+    else:
+        w = _round(torch.randn(cout, cin, *k) / (cout * 27 / 8) ** 0.5, dt)
+        xd = torch.zeros(n, cin, *fine, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xd, w.double(), stride=st, padding=1)
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        want, inp_cl, nout, q = xd.grad, H.to_cl(gy, tdt, P.round_up(cout, 8)), cin, tuple((f + 1) // 2 for f in fine)
+    assert tuple(want.shape[2:]) == fine
+    prev = H.to_cl(_round(torch.randn(n, nout, *fine), dt), tdt)
+    side = H.to_cl(_round(torch.randn(n, nout, *fine), dt), tdt)
+    kw = {}
+    if mode == "accumulate":
+        kw, want = dict(accumulate=1), want + H.from_cl(prev).double()
+    elif mode == "residual":
+        kw, want = dict(res=H.tdesc(side), res_mode=L.RES_ADD), want + H.from_cl(side).double()
+    elif mode == "relumask":
+        kw, want = dict(res=H.tdesc(side), res_mode=L.RES_RELUMASK), want * (H.from_cl(side) > 0).double()
+
+    def stats_buf():
+        return torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+
+    def epi(sbuf):
+        return dict(stats=sbuf.data_ptr(), stats_stride=P.round_up(nout, 16)) if mode == "stats" else kw
+
+    out_a = prev.clone() if mode == "accumulate" else torch.zeros(n, *fine, nout, dtype=tdt, device="cuda")
+    sa = stats_buf()
+    H.run_lattice_op(kind, w, inp_cl, out_a, st, **epi(sa))
+    np.testing.assert_allclose(H.from_cl(out_a).numpy(), want.float().numpy(), atol=_tol(dt, want))
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    aux_es = 0 if mode in ("plain", "stats") else inp_cl.element_size()
+    pls = P.class_split_plans(kind, tuple(w.shape), k, st, q, inp_cl.element_size(), inp_cl.shape[-1], nreal, kreal, aux_es=aux_es)
+    assert pls and all(pl.nsplit == 8 and len(pl.cls.taps) == 8 for pl in pls)
+    for pl in pls:
+        out_b = prev.clone() if mode == "accumulate" else torch.zeros_like(out_a)
+        sb = stats_buf()
+        d = H.igemm_desc(pl, H.pack(pl, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_b), **epi(sb))
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "class split")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(H.from_cl(out_b).numpy(), want.float().numpy(), atol=_tol(dt, want), err_msg=f"{pl.tile} ck={pl.ck}")
+        assert float((out_a.float() - out_b.float()).abs().max()) <= 2 * _tol(dt, want)
+        if mode == "stats":
+            a, bb = H.stat_decode(sa).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sb).view(L.STAT_SHARDS, 2, -1).sum(0)
+            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol=1e-2)
+            np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2)
+    # a descriptor that mixes class_split with what it does not cover is rejected, not misread
+    bad = H.igemm_desc(pls[0], H.pack(pls[0], w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_a))
+    bad.nsplit = 4
+    assert lib.vsseg_igemm(C.byref(bad), H.stream()) == L.EINVAL and b"class_split" in lib.vsseg_last_error()
+
+
 def test_compute_kernel_rejects_what_it_does_not_cover():
     """depth -3 outside the compute kernel's domain is an error (no silent fallback to the general kernel)."""
     lib = L.lib()

@@ -84,6 +84,41 @@ def test_convT_fwd_and_dgrad(k, s, cin, cout, dims):
     np.testing.assert_allclose(got, _cl(x.grad), atol=1e-9)
 
 
+@pytest.mark.parametrize("k,s,cin,cout,dims", [((3, 3, 3), (2, 2, 2), 16, 24, (4, 2, 4)), ((3, 3, 3), (2, 2, 2), 48, 80, (2, 4, 2)), ((3, 3, 1), (2, 2, 1), 16, 8, (4, 4, 4)), ((3, 3, 3), (2, 2, 2), 8, 16, (3, 3, 3))])
+def test_class_split_plans_cover_every_parity_class_in_one_launch(k, s, cin, cout, dims):
+    """planner.class_split_plans: workgroup row = output-parity class, each with its own taps / K steps (the odd-sized case leaves the
+    last voxel of the classes with offset 1 outside the output)."""
+    torch.manual_seed(5)
+    pad = P.same_pad(k)
+    opad = tuple(ss + 2 * p - (kk - 1) - 1 for ss, p, kk in zip(s, pad, k))
+    x = torch.randn(2, cin, *dims, dtype=torch.float64)
+    w = torch.randn(cin, cout, *k, dtype=torch.float64)
+    y = F.conv_transpose3d(x, w, stride=s, padding=pad, output_padding=opad)
+    kreal, nreal = P.gemm_dims("convT_fwd", tuple(w.shape))
+    plans = P.class_split_plans("convT_fwd", tuple(w.shape), k, s, dims, 2, P.round_up(cin, 8), nreal, kreal)
+    assert plans
+    xc = np.zeros((2, *dims, P.round_up(cin, 8)))
+    xc[..., :cin] = _cl(x)
+    for pl in plans:
+        assert pl.nsplit == len(pl.classes) == int(np.prod(s)) and pl.cls.oo == (0, 0, 0) and pl.lds <= P.LDS_LIMIT
+        for c_i, c_ in enumerate(pl.classes):
+            assert [pl.cls.taps[i][0] for i in pl.class_taps(c_i)] == [off for off, _ in c_.taps]
+        got = P.simulate_igemm(pl, xc, w.numpy().reshape(-1), tuple(y.shape[2:]))
+        np.testing.assert_allclose(got, _cl(y), atol=1e-9)
+    # the data gradient of the strided convolution: same lattice, K = cout
+    w2 = torch.randn(cout, cin, *k, dtype=torch.float64)
+    x2 = torch.randn(1, cin, *[d * ss - (1 if d == 3 else 0) for d, ss in zip(dims, s)], dtype=torch.float64, requires_grad=True)
+    y2 = F.conv3d(x2, w2, stride=s, padding=pad)
+    gy = torch.randn_like(y2)
+    y2.backward(gy)
+    kreal, nreal = P.gemm_dims("conv_dgrad", tuple(w2.shape))
+    q = tuple((d + ss - 1) // ss for d, ss in zip(x2.shape[2:], s))
+    gyc = np.zeros((1, *y2.shape[2:], P.round_up(cout, 8)))
+    gyc[..., :cout] = _cl(gy)
+    for pl in P.class_split_plans("conv_dgrad", tuple(w2.shape), k, s, q, 2, P.round_up(cout, 8), nreal, kreal):
+        np.testing.assert_allclose(P.simulate_igemm(pl, gyc, w2.numpy().reshape(-1), tuple(x2.shape[2:])), _cl(x2.grad), atol=1e-9)
+
+
 def test_small_lds_budget_forces_channel_chunks():
     torch.manual_seed(2)
     k, s = (3, 3, 3), (1, 1, 1)

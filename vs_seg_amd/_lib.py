@@ -68,6 +68,10 @@ class IgemmDesc(C.Structure):
         ("cout_mod", C.c_int32),
         ("gate", C.c_void_p),
         ("in_gate", C.c_void_p),
+        ("class_split", C.c_int32),
+        ("class_oo", (C.c_int32 * 3) * 8),
+        ("class_ntaps", C.c_int32 * 8),
+        ("class_tap", (C.c_int32 * 8) * 8),
     ]
 
 

@@ -29,7 +29,9 @@ __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ t
       td.g0[a] = td.q0[a] * d.is[a] + k.off_min[a];
       interior = interior && td.g0[a] >= 0 && td.g0[a] + k.halo[a] <= dims_in[a];
       o0[a] = td.q0[a] * d.os[a] + d.oo[a];
-      whole = whole && td.q0[a] + d.tile[a] <= d.q[a] && (td.q0[a] + d.tile[a] - 1) * d.os[a] + d.oo[a] < dims_out[a];
+      int oo_hi = d.oo[a];  // class_split: the tile must be whole for every class (the largest class offset)
+      for (int c = 0; c < d.class_split; ++c) oo_hi = max(oo_hi, d.class_oo[c][a]);
+      whole = whole && td.q0[a] + d.tile[a] <= d.q[a] && (td.q0[a] + d.tile[a] - 1) * d.os[a] + oo_hi < dims_out[a];
     }
     td.in_vox = (((int64_t)n * d.in.x + td.g0[0]) * d.in.y + td.g0[1]) * d.in.z + td.g0[2];
     td.out_vox = (((int64_t)n * d.out.x + o0[0]) * d.out.y + o0[1]) * d.out.z + o0[2];
@@ -70,7 +72,8 @@ static const TileDesc* tile_table(const IgemmK& k, hipStream_t stream) {
   const vsseg_igemm_desc& d = k.d;
   int xb = 128 / k.ntile[2];  // ~2 scheduling steps of one XCD per (band, y) row
   xb = xb < 1 ? 1 : (xb > k.ntile[0] ? k.ntile[0] : xb);
-  std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles, xb};
+  std::vector<int64_t> key = {d.in.n, d.in.x, d.in.y, d.in.z, d.out.x, d.out.y, d.out.z, k.total_tiles, xb, d.class_split};
+  for (int c = 0; c < d.class_split; ++c) for (int a = 0; a < 3; ++a) key.push_back(d.class_oo[c][a]);
   for (int a = 0; a < 3; ++a) { key.push_back(d.q[a]); key.push_back(d.tile[a]); key.push_back(d.is[a]); key.push_back(d.os[a]); key.push_back(d.oo[a]); key.push_back(k.off_min[a]); key.push_back(k.halo[a]); }
   auto it = cache.find(key);
   if (it != cache.end()) return it->second;
@@ -96,7 +99,17 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d->ck >= 8 && d->ck % 8 == 0 && d->nchunks >= 1, "vsseg_igemm: bad channel chunking ck=%d nchunks=%d", d->ck, d->nchunks);
   VSSEG_CHECK(d->in.c % 8 == 0 && d->in.pitch % 8 == 0, "vsseg_igemm: input channels/pitch must be multiples of 8 (c=%d pitch=%d)", d->in.c, d->in.pitch);
   VSSEG_CHECK(d->tile[0] * d->tile[1] * d->tile[2] == 64 * d->mtw, "vsseg_igemm: tile %dx%dx%d != 64*mtw", d->tile[0], d->tile[1], d->tile[2]);
-  VSSEG_CHECK(d->nsplit >= 1 && d->nsplit * d->nt * 16 >= d->out.c, "vsseg_igemm: nsplit*nt*16 < cout");
+  VSSEG_CHECK(d->nsplit >= 1 && (d->class_split ? d->nt : d->nsplit * d->nt) * 16 >= d->out.c, "vsseg_igemm: nsplit*nt*16 < cout");
+  if (d->class_split) {  // all output-parity classes in one launch: workgroup row = class
+    VSSEG_CHECK(d->class_split >= 2 && d->class_split <= 8 && d->nsplit == d->class_split, "vsseg_igemm: class_split must be 2..8 and equal nsplit");
+    VSSEG_CHECK(d->oo[0] == 0 && d->oo[1] == 0 && d->oo[2] == 0 && d->cout_mod == 0 && d->depth >= -1 && !d->out.ptr2 && d->res_mode != VSSEG_RES_GATE,
+                "vsseg_igemm: class_split needs oo = 0, the general kernel (depth >= -1), a one-part output and no gated residual");
+    for (int c = 0; c < d->class_split; ++c) {
+      VSSEG_CHECK(d->class_ntaps[c] >= 1 && d->class_ntaps[c] <= 8 && d->class_ntaps[c] <= d->ntaps, "vsseg_igemm: class %d has %d taps", c, d->class_ntaps[c]);
+      for (int t = 0; t < d->class_ntaps[c]; ++t) VSSEG_CHECK(d->class_tap[c][t] >= 0 && d->class_tap[c][t] < d->ntaps, "vsseg_igemm: class %d tap %d out of range", c, t);
+      for (int a = 0; a < 3; ++a) VSSEG_CHECK(d->class_oo[c][a] >= 0 && d->class_oo[c][a] < d->os[a], "vsseg_igemm: class offset outside the output stride");
+    }
+  }
   for (const vsseg_tensor* t : {&d->in, &d->out, &d->res}) {
     if (t == &d->res && d->res_mode == VSSEG_RES_NONE) continue;
     if (t->ptr2) VSSEG_CHECK(t->csplit > 0 && t->csplit < t->c && t->csplit % 16 == 0 && t->pitch >= t->csplit && t->pitch >= t->c - t->csplit,
@@ -118,6 +131,7 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
     k.total_tiles *= k.ntile[a];
     VSSEG_CHECK(k.halo[a] <= 255 && d->tile[a] <= 255, "vsseg_igemm: tile/halo extent > 255");
   }
+  for (int c = 0; c < 8; ++c) k.class_vox[c] = c < d->class_split ? (d->class_oo[c][0] * d->out.y + d->class_oo[c][1]) * d->out.z + d->class_oo[c][2] : 0;
   k.w_bytes = d->ksteps * d->nt * 64 * 8 * es;
   k.h_bytes = k.halo[0] * k.halo[1] * k.halo[2] * d->ck * es;
   k.aux_mode = 0;

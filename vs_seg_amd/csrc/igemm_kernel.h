@@ -44,6 +44,7 @@ struct IgemmK {
   int aux_bytes;  // per buffer: tile voxels * NT*16 * aux element size (+ the gate floats) (0: aux handled by the slow path)
   int aux_gate_off;  // aux_mode 4 with the gate map DMA-prefetched: byte offset of the tile's 64*MTW gate floats inside an aux buffer; 0: ordinary loads
   int depth;      // prefetch distance in stages (1..3); the LDS rings hold depth+1 buffers
+  int class_vox[8];  // class_split: output voxel offset (oo_x*OY + oo_y)*OZ + oo_z of each class (workgroup row)
   vsseg_tensor aux;
   int64_t total_tiles;
   const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
@@ -189,19 +190,27 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
   const int wpieces = k.w_bytes >> 4;
   const int cout = d.out.c;
   const int nch = d.nchunks;
+  // class_split: workgroup row `split` is an output-parity class — all output channels (channel base 0), its own taps and K-step count, its own
+  // output voxel offset; otherwise `split` is a slice of the output channels
+  const bool csplit = d.class_split > 0;
+  const int cbase = csplit ? 0 : split * NT * 16;
+  const int64_t cvox = csplit ? k.class_vox[split] : 0;
+  const int my_ntaps = csplit ? d.class_ntaps[split] : d.ntaps;
+  const int my_ks = csplit ? (my_ntaps * k.cgs + 3) / 4 : d.ksteps;
 
   // ---- per-workgroup tables ----
-  for (int i = tid; i < d.ksteps * 4; i += 256) {
+  for (int i = tid; i < my_ks * 4; i += 256) {
     int off = 0;
-    if (i < d.ntaps * k.cgs) {
+    if (i < my_ntaps * k.cgs) {
       int t = i / k.cgs, cg = i - t * k.cgs;
+      if (csplit) t = d.class_tap[split][t];
       int hx = d.tap_off[t][0] - k.off_min[0], hy = d.tap_off[t][1] - k.off_min[1], hz = d.tap_off[t][2] - k.off_min[2];
       off = ((hx * HY + hy) * HZ + hz) * CK * ES + cg * GB;
     }
     ktab[i] = off;
   }
   for (int i = tid; i < NT * 16; i += 256) {
-    const int c = split * NT * 16 + i;
+    const int c = cbase + i;
     const bool ok = c < cout;
     const int cv = d.cout_mod > 0 ? c % d.cout_mod : c;  // z-folded launches: 8 z-neighbours x cout real channels share the per-channel vectors
     epi[i] = ((ok && d.bias) ? d.bias[cv] : 0.f) + ((ok && d.bias2) ? d.bias2[cv] : 0.f);
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
       const int v = j / ppa, c16 = j - v * ppa;
       int vz = v % d.tile[2], r = v / d.tile[2];
       int vy = r % d.tile[1], vx = r / d.tile[1];
-      rel = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]) * aux_vox_bytes + (unsigned)(split * NT * 16) * aux_es + (unsigned)c16 * 16u;
+      rel = (unsigned)((vx * d.os[0] * OY + vy * d.os[1]) * OZ + vz * d.os[2]) * aux_vox_bytes + (unsigned)cbase * aux_es + (unsigned)c16 * 16u;
     }
     arel[u] = rel;
   }
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
 #pragma unroll
     for (int u = 0; u < (AUXM ? AM : 1); ++u) {
       const int j = (u * 4 + wave) * 64 + lane;
-      if (j < apieces && split * NT * 16 + (j % ppa) * (16 / (int)aux_es) >= k.aux.csplit) a2mask |= 1u << u;
+      if (j < apieces && cbase + (j % ppa) * (16 / (int)aux_es) >= k.aux.csplit) a2mask |= 1u << u;
     }
   }
   const char* aux_base = reinterpret_cast<const char*>(k.aux.ptr);
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
   int nst_fast = 0;
   if (vec_store && !producer) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) nst_fast += (split * NT * 16 + t * 16 < cout) ? MTW : 0;
+    for (int t = 0; t < NT; ++t) nst_fast += (cbase + t * 16 < cout) ? MTW : 0;
   }
   int st_h0 = 0, st_h1 = 0, st_h2 = 0;
   // ---- LDS-DMA of one stage (halo chunk, auxiliary tile, weight chunk when the weights are not resident) ----
@@ -387,8 +396,8 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
       // partial tiles use the slow epilogue (ordinary loads) but still issue the same number of DMAs (from the zero page),
       // so that the per-stage instruction count the vmcnt arithmetic relies on stays exact
       const bool whole = (td.flags & 2) != 0;
-      const char* aorigin = aux_base + td.out_vox * aux_vox_bytes;
-      const char* aorigin1 = aux_base1 + td.out_vox * aux_vox_bytes;
+      const char* aorigin = aux_base + (td.out_vox + cvox) * aux_vox_bytes;
+      const char* aorigin1 = aux_base1 + (td.out_vox + cvox) * aux_vox_bytes;
       char* Adst = Al + abuf_issue * k.aux_stride;
 #pragma unroll
       for (int u = 0; u < (AUXM ? AM : 0); ++u) {
@@ -396,7 +405,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
         dma16(whole && arel[u] != 0xffffffffu ? (const void*)(((a2mask >> u) & 1u ? aorigin1 : aorigin) + arel[u]) : k.zeros, Adst + (u * 4 + wave) * 1024);  // padding lanes: zeros into the padding
       }
       if (gate_dma && wave == 0) {
-        if (lane < 16 * MTW) dma16(whole ? (const void*)(d.gate + td.out_vox + grel) : k.zeros, Adst + k.aux_gate_off);
+        if (lane < 16 * MTW) dma16(whole ? (const void*)(d.gate + td.out_vox + cvox + grel) : k.zeros, Adst + k.aux_gate_off);
       }
       if (++abuf_issue == nbuf) abuf_issue = 0;
     }
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
       // HBM-bound configurations (<= 32 output channels per workgroup): plain K loop — two resident workgroups per CU hide the
       // LDS latency, and the registers of a second fragment set would cost that second workgroup
       const char* Wlane = Ws + lane * GB;
-      const int nks = d.ksteps;
+      const int nks = my_ks;
       int koff_next = ktab[g];
       for (int ks = 0; ks < nks; ++ks) {
         const int koff = koff_next;
@@ -543,7 +552,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
        // (Two full A sets cost 4*MTW more VGPRs — MTW 8 spilled — and hipcc collapsed them into one quad anyway.)
       Frag<T> wa[NT], wb[NT], a[MTW];
       const char* Wlane = Ws + lane * GB;
-      const int nks = KS > 0 ? KS : d.ksteps;
+      const int nks = KS > 0 ? KS : my_ks;
       int ko1 = ktab[(nks > 1 ? 1 : 0) * 4 + g], ko2 = ktab[(nks > 2 ? 2 : 0) * 4 + g];  // tap offsets a whole step ahead of the reads that need them
       {
         const int koff = ktab[g];
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
     // ---- epilogue of the current tile ----
     ++ti_cur;
     const bool whole = (tc.flags & 2) != 0;
-    char* out_tile = out_base + tc.out_vox * out_vox_bytes;
+    char* out_tile = out_base + (tc.out_vox + cvox) * out_vox_bytes;
     const int64_t out_delta = out_base1 - out_base;  // 0 for an ordinary tensor
     const char* Aux = Al + abuf_cur * k.aux_stride;
     if (++abuf_cur == nbuf) abuf_cur = 0;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
         if (k.aux_mode == 4) {
 #pragma unroll
           for (int m = 0; m < MTW; ++m)
-            gate[m] = 1.f + (gate_dma ? reinterpret_cast<const float*>(Aux + k.aux_gate_off)[(wave * MTW + m) * 16 + l15] : d.gate[tc.out_vox + ovrel[m]]);
+            gate[m] = 1.f + (gate_dma ? reinterpret_cast<const float*>(Aux + k.aux_gate_off)[(wave * MTW + m) * 16 + l15] : d.gate[tc.out_vox + cvox + ovrel[m]]);
         }
       }
 #pragma unroll
@@ -610,7 +619,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int cl = t * 16 + g * 4;
-          const int c = split * NT * 16 + cl;
+          const int c = cbase + cl;
           if (c >= cout) continue;
           const float4 bi = *reinterpret_cast<const float4*>(epi + cl);
           float val[4] = {acc[m][t][0] + bi.x, acc[m][t][1] + bi.y, acc[m][t][2] + bi.z, acc[m][t][3] + bi.w};
@@ -644,7 +653,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             }
           }
-          char* opt = op + (split * NT * 16 + t * 16 >= out_csplit ? out_delta : 0);  // uniform per 16-channel block
+          char* opt = op + (cbase + t * 16 >= out_csplit ? out_delta : 0);  // uniform per 16-channel block
           if (vec_store) {
             if (out_es == 4) st4(reinterpret_cast<float*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
             else st4(reinterpret_cast<bf16_t*>(opt) + c, make_float4(val[0], val[1], val[2], val[3]));
@@ -663,13 +672,13 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
     for (int m = 0; m < MTW; ++m) {
       const unsigned vx_ = vxyz_l[(wave * MTW + m) * 16 + l15];
       const int qx = q0x + (int)(vx_ & 255u), qy = q0y + (int)((vx_ >> 8) & 255u), qz = q0z + (int)(vx_ >> 16);
-      const int ox = qx * d.os[0] + d.oo[0], oy = qy * d.os[1] + d.oo[1], oz = qz * d.os[2] + d.oo[2];
+      const int ox = qx * d.os[0] + (csplit ? d.class_oo[split][0] : d.oo[0]), oy = qy * d.os[1] + (csplit ? d.class_oo[split][1] : d.oo[1]), oz = qz * d.os[2] + (csplit ? d.class_oo[split][2] : d.oo[2]);
       const bool vok = qx < d.q[0] && qy < d.q[1] && qz < d.q[2] && ox < OX && oy < OY && oz < OZ;
       const int64_t ovox = (((int64_t)n * OX + ox) * OY + oy) * OZ + oz;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int cl = t * 16 + g * 4;  // channel inside this workgroup's NT*16 slice
-        const int c = split * NT * 16 + cl;
+        const int c = cbase + cl;
         if (!vok || c >= cout) continue;
         float val[4] = {acc[m][t][0], acc[m][t][1], acc[m][t][2], acc[m][t][3]};
         const int nc = min(4, cout - c);
@@ -744,7 +753,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
     double* st = d.stats + (int64_t)(blockIdx.x % VSSEG_STAT_SHARDS) * 2 * d.stats_stride;
     for (int i = tid + (producer ? 1 << 20 : 0); i < 2 * NT * 16; i += 256) {  // consumers only (the producer half would add the sums a second time)
       int which = i / (NT * 16), cc = i - which * NT * 16;
-      int c = split * NT * 16 + cc;
+      int c = cbase + cc;
       const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
       if (c < cout) vsseg_fx_add(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)v, VSSEG_FX_STAT);
     }
@@ -753,8 +762,8 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
 
 template <typename T, int NT, int MTW, int MODE, int KS = 0> static int launch_mode(const IgemmK& k, dim3 grid, int lds, hipStream_t s) {
   if constexpr (KS == 0 && NT >= 3 && NT <= 4 && MODE != IG_AUX) {  // unrolled K loops of the hot MFMA-bound shapes (3x3x3 taps, 8 / 16-channel chunks)
-    if (k.d.ksteps == 14) return launch_mode<T, NT, MTW, MODE, 14>(k, grid, lds, s);
-    if (k.d.ksteps == 7) return launch_mode<T, NT, MTW, MODE, 7>(k, grid, lds, s);
+    if (k.d.ksteps == 14 && !k.d.class_split) return launch_mode<T, NT, MTW, MODE, 14>(k, grid, lds, s);  // (class_split: the K-step count differs per workgroup row)
+    if (k.d.ksteps == 7 && !k.d.class_split) return launch_mode<T, NT, MTW, MODE, 7>(k, grid, lds, s);
   }
   static bool attr_set = false;
   if (!attr_set) {

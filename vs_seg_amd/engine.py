@@ -228,6 +228,12 @@ class Plan:
                 sps = P.shuffle_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
                 if sps is not None:
                     return [_Choice([sp], woff, wshape=tuple(Lr.wshape)) for sp in sps]
+            if eng.class_split and not fold and absorbed is None:
+                # ... and those of the 3x3x3 stride-(2,2,2) transitions of the deep levels as ONE launch of the general kernel (workgroup row = class)
+                kreal, nreal = P.gemm_dims(kind, Lr.wshape)
+                csp = P.class_split_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, aux_es=aux_es, in_split=in_split) if kind in ("convT_fwd", "conv_dgrad") else None
+                if csp:
+                    return [_Choice(csp if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))]
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -302,12 +308,18 @@ class Plan:
             d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
+        d.class_split = len(pl.classes) if pl.classes is not None else 0
+        for s_, c_ in enumerate(pl.classes or ()):  # workgroup row s_ = lattice class s_: its output offset and its taps (indices into the union tap table above)
+            d.class_oo[s_][0], d.class_oo[s_][1], d.class_oo[s_][2] = c_.oo
+            d.class_ntaps[s_] = len(c_.taps)
+            for i, t in enumerate(pl.class_taps(s_)):
+                d.class_tap[s_][i] = t
 
     def _choose(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
-               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else ""))
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else ""))
         cache = _tune_cache()
         hit = cache.get(key)
         if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
@@ -403,13 +415,16 @@ class Plan:
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
         if pl.depth == -4:
             nvalid = nb * out.x * out.y * out.z * (pl.nt * 16 // pl.nc) // 4  # the parity classes this launch writes
+        taps_eff = 2.25 if pl.depth == -4 else pl.ntaps
+        if pl.classes is not None:  # every output voxel, by the class it belongs to (27 / 8 taps per voxel on average for 3x3x3 stride 2)
+            nvalid, taps_eff = nb * out.x * out.y * out.z, sum(len(c_.taps) for c_ in pl.classes) / len(pl.classes)
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
-        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma", flops=2.0 * nvalid * (2.25 if pl.depth == -4 else pl.ntaps) * pl.kreal * pl.nc / max(ch.fold, 1),
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma", flops=2.0 * nvalid * taps_eff * pl.kreal * pl.nc / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
-                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / ncls)
+                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / (1 if pl.classes is not None else ncls))
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
     @staticmethod
@@ -932,6 +947,7 @@ class Engine:
         self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launch of the attention sigmoid convolutions (planner.FOLD); 0 disables
         self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.tune_reps = int(os.environ.get("VSSEG_TUNE_REPS", "5"))  # timed launches per candidate plan (best of)
+        self.class_split = os.environ.get("VSSEG_CLASS_SPLIT", "1") != "0"  # ... of the stride-(2,2,2) transitions as one launch of the general kernel (planner.class_split_plans)
         self.fuse_classes = os.environ.get("VSSEG_FUSE_CLASSES", "1") != "0" and not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions

@@ -113,6 +113,12 @@ class IgemmPlan:
     lds: int
     depth: int = 1
     pack_map: np.ndarray = field(repr=False, default=None)  # int32, -1 = zero
+    classes: Optional[List[LatticeClass]] = field(repr=False, default=None)  # class-split plan: workgroup row s computes lattice class s (cls = their union, oo = 0)
+
+    def class_taps(self, s: int) -> List[int]:
+        """Class-split plan: index into the union tap table (cls.taps) of each tap of class s."""
+        offs = [t[0] for t in self.cls.taps]
+        return [offs.index(off) for off, _ in self.classes[s].taps]
 
     @property
     def ntaps(self):
@@ -287,6 +293,37 @@ def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Opti
 # ---- compute-bound kernel (csrc/cconv.hip): depth -3 -----------------------------------------------------------------------
 COMPUTE_TILE = (4, 8, 16)
 _TAPS_3x3x3 = [(t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1) for t in range(27)]
+
+
+def class_split_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, aux_es=4, in_split=0, limit=6) -> Optional[List["IgemmPlan"]]:
+    """All output-parity classes of a transposed convolution / strided data gradient as ONE launch of the general kernel: workgroup
+    row s computes class s (all output channels) with its own taps and K-step count and stores to its own output offset
+    (vsseg_igemm_desc.class_split).  The union of the classes' input offsets is the halo every workgroup fetches ({0,1}^3 for the
+    3x3x3 stride-2 transitions of the deep levels: 8 launches of a few workgroups each become one)."""
+    classes = lattice_classes(kind, kernel, stride)
+    nt = (nreal + 15) // 16
+    if not 2 <= len(classes) <= 8 or nt > 6 or in_split_unsupported(in_split, kc):
+        return None
+    offs = sorted({off for c in classes for off, _ in c.taps})
+    if len(offs) > 8 or max(len(c.taps) for c in classes) > 8:
+        return None
+    union = LatticeClass(classes[0].os, (0, 0, 0), classes[0].is_, [(off, (0, 0, 0)) for off in offs])
+    nvox = q[0] * q[1] * q[2]
+    cks = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0 and (not in_split or c == kc or in_split % c == 0)}, reverse=True)
+    out = []
+    for mtw in (2, 4, 1):
+        if (nt >= 5 and mtw >= 4) or (mtw > 1 and nvox < 64 * mtw):
+            continue
+        tile = choose_tile(q, union.taps, 64 * mtw)
+        for ck in cks:
+            pl = _mk_plan(kind, wshape, union, q, es, kc, nreal, kreal, tile, mtw, nt, len(classes), ck, aux_es)
+            if pl is not None:
+                pl.classes = classes
+                pl.pack_map = pack_map(pl, wshape)
+                out.append(pl)
+                if len([p for p in out if p.mtw == mtw]) >= 2:
+                    break
+    return out[:limit] or None
 
 
 def compute_split(nreal):
@@ -471,11 +508,21 @@ def pack_map(plan: IgemmPlan, wshape) -> np.ndarray:
     tap = p // cgs
     cg = p % cgs
     c = ch * plan.ck + cg * 8 + j
-    n = (split * NT + t) * 16 + (lane & 15)
-    valid = (p < ntaps * cgs) & (c < kreal) & (n < nreal)
-    tapc = np.clip(tap, 0, ntaps - 1)
-    widx = np.array([(w[0] * kdims[1] + w[1]) * kdims[2] + w[2] for _, w in plan.cls.taps], dtype=np.int64)
-    d = widx[tapc]
+    if plan.classes is not None:  # class-split: row `split` is lattice class `split` (its own taps, every output channel)
+        n = t * 16 + (lane & 15)
+        cnt = np.array([len(c_.taps) for c_ in plan.classes])[split]
+        widx = np.zeros((S, 8), np.int64)
+        for s_, c_ in enumerate(plan.classes):
+            for i, (_, w) in enumerate(c_.taps):
+                widx[s_, i] = (w[0] * kdims[1] + w[1]) * kdims[2] + w[2]
+        valid = (tap < cnt) & (c < kreal) & (n < nreal)
+        d = widx[split, np.clip(tap, 0, 7)]
+    else:
+        n = (split * NT + t) * 16 + (lane & 15)
+        valid = (p < ntaps * cgs) & (c < kreal) & (n < nreal)
+        tapc = np.clip(tap, 0, ntaps - 1)
+        widx = np.array([(w[0] * kdims[1] + w[1]) * kdims[2] + w[2] for _, w in plan.cls.taps], dtype=np.int64)
+        d = widx[tapc]
     flat = weight_flat_index(plan.kind, wshape, np.where(valid, c, 0), np.where(valid, n, 0), d)
     return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
 
@@ -562,8 +609,17 @@ def simulate_igemm(plan: IgemmPlan, x: np.ndarray, wflat: np.ndarray, out_shape)
     cls = plan.cls
     q = plan.q
     cgs = plan.ck // 8
-    acc = np.zeros((N, *q, plan.nsplit * plan.nt * 16), np.float64)
     qi = [np.arange(q[a]) for a in range(3)]
+    if plan.classes is not None:  # class-split: each workgroup row is a launch of its own class with the row's slice of the packed weights
+        out = np.zeros((N, *out_shape, plan.nc), np.float64)
+        for s_, c_ in enumerate(plan.classes):
+            ks_c = (len(c_.taps) * cgs + 3) // 4  # the K steps this row runs (the kernel's my_ks)
+            sub = dataclasses.replace(plan, cls=c_, classes=None, nsplit=1, ksteps=ks_c, pack_map=plan.pack_map.reshape(plan.nsplit, plan.nchunks, plan.ksteps, -1)[s_, :, :ks_c].reshape(-1))
+            o = simulate_igemm(sub, x, wflat, out_shape)
+            sel = np.ix_(np.arange(N), *[np.arange(c_.oo[a], out_shape[a], c_.os[a]) for a in range(3)], np.arange(plan.nc))
+            out[sel] = o[sel]
+        return out
+    acc = np.zeros((N, *q, plan.nsplit * plan.nt * 16), np.float64)
     for ch in range(plan.nchunks):
         for ks in range(plan.ksteps):
             for g in range(4):
