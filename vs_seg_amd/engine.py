@@ -101,6 +101,7 @@ class _Choice:
     cached: bool = False  # the choice came from the tuned-plan cache, nothing was measured
     fold: int = 0  # z-folded formulation (planner.FOLD z-neighbours as channels): the launch runs on reinterpreted tensors
     cmod: int = 0  # ... and output channel c is real channel c % cmod for the per-channel vectors
+    alt: Optional["_Choice"] = None  # on the first lattice class of a multi-class op: all classes as ONE launch (planner.class_split_plans)
 
 
 @dataclass
@@ -228,12 +229,13 @@ class Plan:
                 sps = P.shuffle_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
                 if sps is not None:
                     return [_Choice([sp], woff, wshape=tuple(Lr.wshape)) for sp in sps]
+            alt = None
             if eng.class_split and not fold and absorbed is None:
                 # ... and those of the 3x3x3 stride-(2,2,2) transitions of the deep levels as ONE launch of the general kernel (workgroup row = class)
                 kreal, nreal = P.gemm_dims(kind, Lr.wshape)
                 csp = P.class_split_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, aux_es=aux_es, in_split=in_split) if kind in ("convT_fwd", "conv_dgrad") else None
-                if csp:
-                    return [_Choice(csp if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))]
+                if csp:  # an alternative to the per-class launches below, decided per op at lowering time (Plan._use_class_split)
+                    alt = _Choice(csp if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -244,6 +246,7 @@ class Plan:
                 else:
                     cands = [P.plan_igemm(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)]
                 out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0, wshape=tuple(Lr.wshape)))
+            out[0].alt = alt
             return out
 
         self.cplans: Dict[str, _ConvPlans] = {}
@@ -382,8 +385,60 @@ class Plan:
         """All lattice classes of one convolution (the output-parity classes of a transposed convolution / of a strided data gradient): each is
         its own launch and reads the WHOLE input (the stride-(2,2,1) transitions of levels 0-2 run all classes in one streaming-kernel launch
         instead, planner.shuffle_plans)."""
+        if chs[0].alt is not None and self._use_class_split(chs, inp, out, res, kw):
+            chs = [chs[0].alt]  # ... or every class in one launch of the general kernel, where that is faster (the deep levels)
         for ch in chs:
             self._igemm(lst, ch, inp, out, res=res, **kw)
+
+    CLASS_SPLIT_MAX_VOXELS = 100_000  # heuristic of the untuned lowering: class-split launches below this many coarse voxels (measured: tools/bench_class_split.py)
+
+    def _use_class_split(self, chs: List[_Choice], inp: L.Tensor, out: L.Tensor, res, kw) -> bool:
+        """One class-split launch or one launch per class?  The split launch wins where the per-class launches are a handful of workgroups each
+        (levels 3-5: 0.23 -> 0.09 ms, 0.18 -> 0.03 ms); at level 2 with batch 4 every workgroup of the split launch fetches the union halo and
+        keeps the LDS of the 8-tap class, and the tuned per-class launches are faster (0.27 against 0.38 ms).  Measured once per launch signature."""
+        alt = chs[0].alt
+        p0 = alt.cands[0]
+        nb = kw.get("nb") or self.n
+        if not self.tune:
+            return nb * p0.q[0] * p0.q[1] * p0.q[2] <= self.CLASS_SPLIT_MAX_VOXELS
+        if alt.chosen is not None or chs[0].chosen is not None:  # a further launch of the same op (another sample): same decision
+            return alt.chosen is not None
+        key = (f"use_cs|{p0.kind}|w{alt.wshape}|q{p0.q}|n{nb}|es{self.eng.es}|kc{p0.kc}|acc{int(kw.get('accumulate', 0))}|res{int(kw.get('res_mode', 0))}"
+               f"|st{int(bool(kw.get('stats')))}|two{int(bool(inp.ptr2))}{int(bool(out.ptr2))}")
+        cache = _tune_cache()
+        if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+            return bool(cache[key])
+        eng, lib = self.eng, self.eng.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        times = []
+        for variant in (chs, [alt]):  # lower both into scratch lists (this chooses and registers their plans), pack their weights, time the launches
+            tmp, packs = [], []
+            for ch in variant:
+                self._igemm(tmp, ch, inp, out, res=res, **kw)
+                m = torch.from_numpy(np.where(ch.chosen.pack_map >= 0, ch.chosen.pack_map + ch.woff, -1).astype(np.int32)).to(eng.device)
+                wp = torch.empty(m.numel(), dtype=eng.tdtype, device=eng.device)
+                L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), m.data_ptr(), None, wp.data_ptr(), m.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
+                tmp[-1][1][0]._obj.wpack = wp.data_ptr()
+                packs.append(wp)
+            best = float("inf")
+            for _ in range(1 + eng.tune_reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for fn, args, _meta in tmp:
+                    L.check(fn(*args, stream), "class-split decision")
+                e1.record()
+                e1.synchronize()
+                best = min(best, e0.elapsed_time(e1))
+            times.append(best)
+        use = times[1] < times[0]
+        (chs[0] if use else alt).chosen = None  # the variant that lost is not part of the step (its packed weights stay allocated: a few hundred KiB)
+        if use:
+            for ch in chs:
+                ch.chosen = None
+        cache[key] = int(use)
+        _tune_cache.dirty = True
+        self.class_split_ms = getattr(self, "class_split_ms", []) + [(key, times)]
+        return use
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
                res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0):
