@@ -338,13 +338,13 @@ def main():
         model.eval()
         vol = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal((1, 1, 512, 512, 120), dtype=np.float32)).to(dev)
         pred = lambda w: model(w)[0]  # noqa: E731
-        def time_swi(swb):
+        def time_swi(swb, lanes=2):
             with torch.no_grad():
-                V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian")
+                V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian", concurrent_groups=lanes)
                 barrier()
                 s0 = time.perf_counter()
                 for _ in range(args.swi_volumes):
-                    V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian")
+                    V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian", concurrent_groups=lanes)
                 barrier()
                 sdt = time.perf_counter() - s0
             if world > 1:
@@ -355,7 +355,9 @@ def main():
 
         sdt = time_swi(1)  # the reference's setting (ref:params/VSparams.py:571)
         swi = dict(volumes_per_sec=args.swi_volumes * world / sdt, ms_per_volume=1e3 * sdt / args.swi_volumes, volume="512x512x120", roi="384x128x128", overlap=0.5, windows=14, sw_batch_size=1,
-                   mode="gaussian", sharding="volumes round-robin over ranks")
+                   mode="gaussian", sharding="volumes round-robin over ranks", concurrent_groups=2)
+        t = time_swi(1, lanes=1)
+        swi["serial_schedule"] = dict(volumes_per_sec=args.swi_volumes * world / t, ms_per_volume=1e3 * t / args.swi_volumes, note="concurrent_groups=1: one window's forward at a time")
         # per window: one eval forward of the 384x128x128 patch = 685.31 GFLOP and 5.63 GB of convolution-boundary bytes + the blend (2 RMW passes of 50.3 MB)
         wms = 1e3 * sdt / args.swi_volumes / 14
         swi["roofline"] = dict(ms_per_window=wms, alg_gflop_per_window=685.31, alg_gb_per_window=5.63, mfma_frac=685.31 / wms / PEAK[args.dtype], hbm_frac=5.63 / wms / 8.0,

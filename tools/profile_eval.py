@@ -6,7 +6,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 m = bench.build_model("bf16", torch.device("cuda")).eval()
-x = torch.randn(1, 1, 384, 128, 128, device="cuda")
+NB = int(os.environ.get("EVAL_BATCH", "1"))  # windows per forward (sw_batch_size)
+x = torch.randn(NB, 1, 384, 128, 128, device="cuda")
 with torch.no_grad():
     for _ in range(3): m(x)
     plan = next(p for k, p in m._engine.plans.items() if not k[2])
@@ -23,7 +24,7 @@ with torch.no_grad():
     print(f"eval forward: {(time.perf_counter() - t) / 20 * 1e3:.3f} ms wall; kernel sum {sum(a['ms'] for a in agg.values()):.3f} ms over {sum(a['n'] for a in agg.values())} launches")
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
     print(f"{k:28s} n={a['n']:3d} {a['ms']:7.3f} ms")
-for ms, name, tag in rows[:25]:
+for ms, name, tag in rows[:int(os.environ.get("EVAL_ROWS", "25"))]:
     print(f"{ms:7.3f} {name:18s} {tag[:170]}")
 
 nvol = int(sys.argv[1]) if len(sys.argv) > 1 else 0

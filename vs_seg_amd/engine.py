@@ -1034,14 +1034,16 @@ class Engine:
             self._wg_scratch = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 192 MB of partial-sum slabs, shared by all layers
         return self._wg_scratch
 
-    def plan(self, n, dims, train) -> Plan:
-        key = (int(n), tuple(int(d) for d in dims), bool(train))
+    def plan(self, n, dims, train, slot: int = 0) -> Plan:
+        """The lowered launch lists + activation buffers for one (batch, size, mode).  `slot` > 0: a further, independent set of buffers for
+        the same signature (eval forwards issued on different HIP streams run concurrently: sliding-window windows, inferers.py)."""
+        key = (int(n), tuple(int(d) for d in dims), bool(train), int(slot))
         pl = self.plans.get(key)
         if pl is None:
             for d, m in zip(key[1], self.min_multiple()):
                 if d % m:
                     raise ValueError(f"spatial size {key[1]} must be a multiple of {self.min_multiple()} (product of the network strides)")
-            pl = Plan(self, *key)
+            pl = Plan(self, *key[:3])
             self.plans[key] = pl
         return pl
 

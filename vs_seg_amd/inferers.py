@@ -112,8 +112,21 @@ def crop_all_windows(vol: torch.Tensor, b_and_starts, roi, pad_before) -> torch.
     return out
 
 
+_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(device, i: int) -> "torch.cuda.Stream":
+    key = (str(device), i)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable, overlap: float = 0.25, mode: str = "constant", padding_mode: str = "constant",
-                             cval: float = 0.0, device=None) -> torch.Tensor:
+                             cval: float = 0.0, device=None, concurrent_groups: int = 2) -> torch.Tensor:
+    """`concurrent_groups` (not a MONAI argument; 1 = strictly serial): consecutive window groups run their predictor on that many HIP streams, so
+    the latency-bound deep levels of one window's forward overlap the bandwidth-bound outer levels of the next; the blend (`out += map*seg`) stays
+    on the caller's stream in window order, so the result is bit-identical to the serial schedule."""
     if not inputs.is_cuda:
         raise RuntimeError("vs_seg_amd.sliding_window_inference runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
     if inputs.dim() != 5 or inputs.shape[1] != 1:
@@ -134,10 +147,25 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     stream = torch.cuda.current_stream().cuda_stream
     per_win = roi[0] * roi[1] * roi[2] * 4
     windows = crop_all_windows(vol, slices, roi, pad_before) if len(slices) * per_win <= (8 << 30) else None  # one crop launch per call (<= 8 GB of windows), else per group
-    for g in range(0, len(slices), sw_batch_size):
+    main = torch.cuda.current_stream()
+    ngroups = -(-len(slices) // sw_batch_size)
+    lanes = [_side_stream(inputs.device, i) for i in range(min(int(concurrent_groups), ngroups))] if concurrent_groups > 1 and ngroups > 1 else []
+    ready = main.record_event() if lanes else None  # the windows (and the volume) are complete on the caller's stream
+    blended: Dict[int, "torch.cuda.Event"] = {}  # lane -> its previous group's segmentation has been blended (the predictor may reuse its output buffers)
+    for gi, g in enumerate(range(0, len(slices), sw_batch_size)):
         grp = slices[g : g + sw_batch_size]
-        win = windows[g : g + len(grp)] if windows is not None else crop_windows(vol, grp, roi, pad_before)
-        seg = _as_cl(predictor(win))  # [n,rx,ry,rz,C]
+        if lanes:
+            lane = lanes[gi % len(lanes)]
+            lane.wait_event(blended.get(gi % len(lanes), ready))
+            with torch.cuda.stream(lane):
+                win = windows[g : g + len(grp)] if windows is not None else crop_windows(vol, grp, roi, pad_before)
+                seg = _as_cl(predictor(win))  # [n,rx,ry,rz,C]
+                done = lane.record_event()
+            seg.record_stream(main)
+            main.wait_event(done)
+        else:
+            win = windows[g : g + len(grp)] if windows is not None else crop_windows(vol, grp, roi, pad_before)
+            seg = _as_cl(predictor(win))  # [n,rx,ry,rz,C]
         C = seg.shape[-1]
         if out is None:
             out = torch.zeros((B, *padded, C), dtype=torch.float32, device=inputs.device)
@@ -146,6 +174,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         pvox = padded[0] * padded[1] * padded[2]
         for i, (b, s) in enumerate(grp):
             L.check(lib.vsseg_swi_accumulate(seg.data_ptr() + 4 * i * per * C, imap.data_ptr(), L.i3(roi), L.i3(s), C, out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr() + 4 * b * pvox, L.i3(padded), stream), "swi_accumulate")
+        if lanes:
+            blended[gi % len(lanes)] = main.record_event()
     C = out.shape[-1]
     final = torch.empty((B, *img, C), dtype=torch.float32, device=inputs.device)
     pvox, ivox = padded[0] * padded[1] * padded[2], img[0] * img[1] * img[2]

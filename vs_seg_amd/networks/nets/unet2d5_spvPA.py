@@ -59,6 +59,7 @@ class UNet2d5_spvPA(nn.Module):
         self._engine: Optional[Engine] = None
         self._anchor: Optional[torch.Tensor] = None
         self._step = 0
+        self._eval_slots = {}  # HIP stream -> eval plan slot
         self._seed_base = int(torch.initial_seed()) & 0xFFFFFFFF
         self._params: Dict[str, nn.Parameter] = {}
         self._register_state()
@@ -205,11 +206,26 @@ class UNet2d5_spvPA(nn.Module):
             self.att_maps = atts
         return logits, self.att_maps
 
+    MAX_EVAL_SLOTS = 4  # independent sets of eval activation buffers (one per HIP stream that runs eval forwards)
+
+    def _eval_slot(self, stream: int) -> int:
+        slots = self._eval_slots
+        if stream not in slots:
+            if len(slots) >= self.MAX_EVAL_SLOTS:  # a fifth stream takes over the buffers of the stream seen longest ago, once that one has drained
+                torch.cuda.synchronize()
+                slots[stream] = slots.pop(next(iter(slots)))
+            else:
+                slots[stream] = len(slots)
+        return slots[stream]
+
     def _run_forward(self, x: torch.Tensor, train: bool):
         eng = self._engine
         n, _, X, Y, Z = x.shape
-        plan: Plan = eng.plan(n, (X, Y, Z), train)
         stream = torch.cuda.current_stream().cuda_stream
+        # eval forwards on different HIP streams may overlap (the sliding-window inferer issues consecutive windows on two streams):
+        # each stream gets its own plan (activation buffers, packed weights, hipGraph); training plans are stream-independent
+        slot = 0 if train else self._eval_slot(stream)
+        plan: Plan = eng.plan(n, (X, Y, Z), train, slot)
         xin = x.detach()
         if xin.dtype != torch.float32 or not xin.is_contiguous():
             xin = xin.to(torch.float32).contiguous()
