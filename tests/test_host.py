@@ -74,7 +74,7 @@ def test_shipped_tuned_plans_still_name_existing_candidates():
     from vs_seg_amd import planner as P
 
     data = json.load(open(E.TUNED_DEFAULTS))
-    ig = {k: v for k, v in data.items() if not k.startswith("wgrad")}
+    ig = {k: v for k, v in data.items() if not k.startswith(("wgrad", "use_cs"))}  # (use_cs|...: per-class or class-split launch, 0 / 1)
     assert len(ig) > 150 and sum(1 for k in data if k.startswith("wgrad")) >= 40
     checked = hits = 0
     for key, choice in list(ig.items())[::5]:
