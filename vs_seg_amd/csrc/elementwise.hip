@@ -289,9 +289,10 @@ __device__ __forceinline__ float bn_bwd_elem8(const f8& y, const f8& da, int c, 
 }
 
 // Pass 1 of the BatchNorm + dropout + PReLU backward.  Per thread: one 8-channel group, U voxels in flight (2*U independent 16-byte loads).
-// The loop keeps only the forward's folded affine (scale, shift: the PReLU branch is re-decided on the SAME fp32 value) in registers and
-// accumulates sum(dz), sum(dz*y), sum(dout); sum(dz*xhat) = invstd * (sum(dz*y) - mean * sum(dz)) is formed once per workgroup, in fp64, from
-// the workgroup's partial sums (16 fewer live registers and 2 fewer VALU per element than normalising inside the loop).
+// The loop keeps the forward's folded affine (scale, shift: the PReLU branch is re-decided on the SAME fp32 value) and the channel means in
+// registers and accumulates sum(dz), sum(dz*(y - mean)), sum(dout); sum(dz*xhat) = invstd * sum(dz*(y - mean)) is formed once per workgroup.
+// (Centred per element: sum(dz*y) - mean*sum(dz) from fp32 partial sums cancels when |mean| >> std; the extra subtract is free — A/B 32.1 ms
+// per step either way, tests/test_gpu_ops.py::test_bn_dropout_prelu_forward_backward[(10, 0.05)].)
 // 8 channels as loaded (bf16: 4 registers) — converted to fp32 only when consumed, so that U voxels in flight cost 8*U registers, not 16*U
 template <typename T> struct Raw8;
 template <> struct Raw8<bf16_t> {
@@ -332,9 +333,9 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs);
   const int c = cg * 8;
-  float sc[8], sh[8];
+  float sc[8], sh[8], mu[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = a.scale[c + j]; sh[j] = a.shift[c + j]; }
+  for (int j = 0; j < 8; ++j) { sc[j] = a.scale[c + j]; sh[j] = a.shift[c + j]; mu[j] = a.mean[c + j]; }
   const bool drop = a.p_drop > 0.f;
   const float inv_keep = 1.f / (1.f - a.p_drop);
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s3[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dal = 0.f;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
       const float dd = d > 0.f ? g : alpha * g;
       if (d < 0.f) dal += g * d;
       const float dz = k ? dd * inv_keep : 0.f;
-      s1[j] += dz; s2[j] += dz * yy.v[j]; s3[j] += g;
+      s1[j] += dz; s2[j] += dz * (yy.v[j] - mu[j]); s3[j] += g;  // centred per element: sum(dz*y) - mean*sum(dz) in fp32 cancels when |mean| >> std
     }
   };
   // The source of the keep-mask is decided ONCE, outside the loop: 0 no dropout, 1 the stored bytes, 2 Philox.  A per-element
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
   for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) {
     const int which = i / C, ch = i % C;
     double val = (double)wsum(i);
-    if (which == 1) val = (double)a.invstd[ch] * (val - (double)a.mean[ch] * (double)wsum(ch));  // sum(dz * xhat) of this workgroup
+    if (which == 1) val *= (double)a.invstd[ch];  // sum(dz * xhat) of this workgroup
     vsseg_fx_add(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val, VSSEG_FX_GRAD);  // order-independent (fixed-point integer atomics)
   }
   if (threadIdx.x == 0) vsseg_fx_add(&alpha_acc[shard], (double)wsum(3 * C), VSSEG_FX_GRAD);

@@ -927,9 +927,15 @@ class Plan:
                     self._graphs[graph_key] = g
                     g.replay()  # the capture recorded the launches without executing them
                     return
-                except Exception as e:  # capture is an optimisation of HOW the same kernels are launched: fall back to the eager loop, loudly
+                except RuntimeError as e:  # capture is an optimisation of HOW the same kernels are launched: fall back to the eager loop, loudly
                     import warnings
 
+                    self._graphs.pop(graph_key, None)
+                    if str(e).startswith("vsseg "):  # a launch the library rejected (L.check) is an error of the step, not of the capture
+                        raise
+                    torch.cuda.synchronize()
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError(f"vs_seg_amd: hipGraph capture of the {graph_key} launch list failed ({e}) and left the stream capturing") from e
                     warnings.warn(f"vs_seg_amd: hipGraph capture of the {graph_key} launch list failed ({e}); launching eagerly")
                     self.eng.use_graphs = False
         self._run_eager(lst, stream)
