@@ -779,6 +779,10 @@ template <typename T, int NT, int MTW, int MODE, int KS = 0> static int launch_m
     cached_lds = lds;
   }
   int64_t gx = 256ll * cached_per_cu;
+  // class_split: the rows of all classes resident together (each row its share of the CUs, a multiple of 8 so that the rows agree on the
+  // tile -> XCD map): the classes of a tile then run at about the same time on the same XCD — one halo fetch from HBM instead of one per
+  // class, and their interleaved output voxels meet in that XCD's L2 before they are written back
+  if (k.d.class_split) gx = std::max<int64_t>(8, (gx / k.d.class_split) & ~7ll);
   if (gx > k.total_tiles) gx = k.total_tiles;
   grid.x = (unsigned)gx;
   hipLaunchKernelGGL((igemm_kernel<T, NT, MTW, MODE, KS>), grid, dim3(ig_spec(NT) ? 512 : 256), lds, s, k);
