@@ -340,7 +340,8 @@ def main():
         pred = lambda w: model(w)[0]  # noqa: E731
         def time_swi(swb, lanes=2):
             with torch.no_grad():
-                V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian", concurrent_groups=lanes)
+                for _ in range(3):  # every (lane, group size) plan has had its eager runs and its hipGraph capture (third run) before the timed region
+                    V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian", concurrent_groups=lanes)
                 barrier()
                 s0 = time.perf_counter()
                 for _ in range(args.swi_volumes):
