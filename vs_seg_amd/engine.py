@@ -831,7 +831,14 @@ class Plan:
                 B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd, keep_ptr(Lr)],
                           self._ew_meta("bn_act_bwd_apply", Lr.out_level, 3 * Lr.cout)])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
-                    if contribution(op.res):
+                    r, o = op.res, grad_alias.get(op.out.name, op.out)
+                    if (r.parts is None and r.base is None and o.parts is None and o.base is None and r.kind == o.kind == "act" and (r.level, r.c) == (o.level, o.c)
+                            and not written.get(r.name) and r.name not in self.grads and o.name in self.grads):
+                        # first contribution to d(res), and d(out) is dead from here on (reduce / apply above were its last readers): d(res) IS the
+                        # buffer of d(out) — later contributions accumulate into it in place — instead of a copy of it (one tensor round trip less)
+                        self.grads[r.name] = self.grads[o.name]
+                        written[r.name] = True
+                    elif contribution(op.res):
                         B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA], self._ew_meta("grad_add/copy", Lr.out_level, 3 * Lr.cout)])
                     else:
                         B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)], self._ew_meta("grad_add/copy", Lr.out_level, 2 * Lr.cout)])
