@@ -102,6 +102,7 @@ class _Choice:
     fold: int = 0  # z-folded formulation (planner.FOLD z-neighbours as channels): the launch runs on reinterpreted tensors
     cmod: int = 0  # ... and output channel c is real channel c % cmod for the per-channel vectors
     alt: Optional["_Choice"] = None  # on the first lattice class of a multi-class op: all classes as ONE launch (planner.class_split_plans)
+    probe_plan: Optional[P.IgemmPlan] = None  # plan of the last probe lowering (Plan._igemm(probe=True))
 
 
 @dataclass
@@ -411,11 +412,11 @@ class Plan:
         eng, lib = self.eng, self.eng.lib
         stream = torch.cuda.current_stream().cuda_stream
         times = []
-        for variant in (chs, [alt]):  # lower both into scratch lists (this chooses and registers their plans), pack their weights, time the launches
+        for variant in (chs, [alt]):  # lower both into scratch lists (plans chosen as usual, nothing registered), pack their weights, time the launches
             tmp, packs = [], []
             for ch in variant:
-                self._igemm(tmp, ch, inp, out, res=res, **kw)
-                m = torch.from_numpy(np.where(ch.chosen.pack_map >= 0, ch.chosen.pack_map + ch.woff, -1).astype(np.int32)).to(eng.device)
+                self._igemm(tmp, ch, inp, out, res=res, probe=True, **kw)
+                m = torch.from_numpy(np.where(ch.probe_plan.pack_map >= 0, ch.probe_plan.pack_map + ch.woff, -1).astype(np.int32)).to(eng.device)
                 wp = torch.empty(m.numel(), dtype=eng.tdtype, device=eng.device)
                 L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), m.data_ptr(), None, wp.data_ptr(), m.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
                 tmp[-1][1][0]._obj.wpack = wp.data_ptr()
@@ -431,17 +432,15 @@ class Plan:
                 best = min(best, e0.elapsed_time(e1))
             times.append(best)
         use = times[1] < times[0]
-        (chs[0] if use else alt).chosen = None  # the variant that lost is not part of the step (its packed weights stay allocated: a few hundred KiB)
-        if use:
-            for ch in chs:
-                ch.chosen = None
         cache[key] = int(use)
         _tune_cache.dirty = True
         self.class_split_ms = getattr(self, "class_split_ms", []) + [(key, times)]
         return use
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False):
+        """probe: build the launch (plan chosen / measured as usual) WITHOUT making it part of the step — no packed-weight registration, the descriptor
+        is only referenced by `lst` (Plan._use_class_split times two alternative lowerings of an op this way; ch.probe_plan = the plan it used)."""
         nb = self.n if nb is None else nb
         d = L.IgemmDesc()
         d.gate = gate or None
@@ -459,12 +458,16 @@ class Plan:
             pl = ch.chosen
         else:
             pl = self._choose(ch, d) if (self.tune and len(ch.cands) > 1) else ch.cands[0]
-            self._register(ch, pl)
+            if probe:
+                ch.probe_plan = pl
+            else:
+                self._register(ch, pl)
         self._fill_desc(d, pl)
         if pl.depth == -4:  # fused output-parity classes: output channel tile t is class t, its channels are the real channels 0..nc-1
             d.cout_mod = pl.nc
-        self._wpack_fixups.append((d, ch.map_off))
-        self.keep.append(d)
+        if not probe:
+            self._wpack_fixups.append((d, ch.map_off))
+            self.keep.append(d)
         nvalid = nb  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
