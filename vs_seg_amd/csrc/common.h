@@ -231,6 +231,12 @@ static __global__ __launch_bounds__(VSSEG_SLAB_THREADS) void vsseg_slab_add_kern
   if (threadIdx.x < 64 && i < nvalid) dst[i] += s;
 }
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch).  Work item of workgroup b such that XCD x owns the contiguous item range
+// [x*G/8, (x+1)*G/8) and walks it in dispatch order: neighbouring items (z-columns of the marching kernels: they share the 128-byte lines of
+// every tensor with < 128 bytes per z-row — the fp32 attention map, the 2-channel logits) then run at about the same time on the SAME L2
+// instead of on eight different ones (PMC: the gate map was fetched 8x, r03_pmc_hbm.txt).  Identity when the grid is not a multiple of 8.
+__device__ __forceinline__ int vsseg_xcd_contiguous(int b, int grid) { return (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b; }
+
 static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   const int X = k.X, Y = k.Y, Z = k.Z, cout = k.cout;
 
   // ---- workgroup -> column segment
-  int b = blockIdx.x;
+  int b = vsseg_xcd_contiguous(blockIdx.x, gridDim.x);
   const int zb = b % k.nzb; b /= k.nzb;
   const int yb = b % k.nyb; b /= k.nyb;
   const int xs = b % k.nxs; const int n = b / k.nxs;

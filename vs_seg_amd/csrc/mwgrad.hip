@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int X = k.X, Y = k.Y, Z = k.Z;
 
-  int b = blockIdx.x;
+  int b = vsseg_xcd_contiguous(blockIdx.x, gridDim.x);
   const int zb = b % k.nzb; b /= k.nzb;
   const int yb = b % k.nyb; b /= k.nyb;
   const int xs = b % k.nxs; const int n = b / k.nxs;
