@@ -141,8 +141,9 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
   k.sign = sign; k.stride_c = stride_c;
   k.items = (int64_t)t.n * t.x * k.yq * t.z;
   VSSEG_CHECK((int64_t)t.n * t.x * t.y * t.z < (1ll << 31), "vsseg_wgrad_narrow: more than 2^31 voxels");
-  // >= 16 items per thread before another workgroup is worth its flush; at most 4 workgroups per CU
-  int grid = grid_for(k.items * k.cgs / 16, 256, 256 * 4);
+  // >= 16 items per thread before another workgroup is worth its flush; at most 3 workgroups per CU (the step's 4 launches: 0.68 ms with
+  // 1024 workgroups, 0.62 with 512-768, 0.72 with 384, 0.74 with 4096)
+  int grid = grid_for(k.items * k.cgs / 16, 256, 256 * 3);
   k.bias = dbias ? 1 : 0;
   const int64_t cap = scratch_elems / (k3 * k3 * t.c + 1);
   VSSEG_CHECK(cap >= 1, "vsseg_wgrad_narrow: scratch too small");
