@@ -407,11 +407,12 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   // 0.185 ms with 1536 workgroups, 0.151 ms = 5.3 TB/s with 682; a 151 MB 48-channel tensor 0.133 ms with 1536, 0.070 ms with 455).  Giving
   // every workgroup its own row and plain read-modify-writes instead of atomics measured no better: it is the number of flushes, not the
   // atomics.  So the grid is sized by a flush budget (~64 K adds per launch beyond 16 channels: 682 workgroups at 32 channels, 455 at 48),
+  // 768 workgroups on the 16-channel full-resolution tensors (the step's 26 launches: 2.36 ms with 2048 there, 2.25 with 512-1024),
   // never below 192 workgroups (the 6 MB tensors of level 4: 27 us with a floor of 384, 19 us with 192, no better below) and never with fewer
   // than 16 voxel groups per thread.
   const int64_t items = nv * cgs;
   const int budget = 65536;  // fp64 flush atomics per launch the grid is sized for (measured)
-  const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(192, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 8 : budget / (3 * y.c))));
+  const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(192, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 3 : budget / (3 * y.c))));
   int grid = grid_for((nv * cgs + 1) / 2, blk, cap);  // 2 voxels in flight per thread (measured: 2 beats 4)
   DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
