@@ -54,8 +54,9 @@ typedef struct {
    * rejects it with VSSEG_EINVAL. */
   void* ptr2;
   int32_t csplit;
-  int32_t reserved;
+  int32_t reserved;  /* 0, or VSSEG_ZERO_PADDED on a destination: its channels c .. pitch-1 are zero padding the call may rewrite with zeros */
 } vsseg_tensor;
+#define VSSEG_ZERO_PADDED 1
 
 /* One implicit-GEMM launch over an output lattice q in [0,q): out[q*os+oo][n] = epi( sum_t sum_c in[q*is+off_t][c] * W[t][c][n] ).
  * Covers Conv3d forward, every parity class of ConvTranspose3d forward, and both data-gradients
@@ -203,7 +204,7 @@ int vsseg_memset_zero(void* dst, int64_t bytes, void* stream);                  
 int vsseg_copy_bytes(const void* src, void* dst, int64_t bytes, void* stream);    /* device-to-device hipMemcpyAsync */
 int vsseg_channel_sum(vsseg_tensor t, float* out /* [c], += */, void* stream);
 int vsseg_add_inplace(vsseg_tensor dst, vsseg_tensor src, void* stream); /* dst += src */
-int vsseg_copy_cast(vsseg_tensor src, vsseg_tensor dst, void* stream);
+int vsseg_copy_cast(vsseg_tensor src, vsseg_tensor dst, void* stream);  /* dst[v][0..c) = src[v][0..c) (fp32 / bf16 either side); fp32 [v][2] -> VSSEG_ZERO_PADDED bf16 rows of 8: one full-row store per voxel */
 
 /* Dice_spvPA (ref:params/losses/dice_spvPA.py:238-297).  sums layout: see loss.hip. */
 int vsseg_maxpool_label(const float* src, int32_t n, const int32_t sdims[3], const int32_t ratio[3], float* dst, void* stream);

@@ -960,6 +960,23 @@ def test_two_part_attention_gate(dt, c0):
     np.testing.assert_allclose(H.from_cl(dpre, 1).numpy(), pre.grad.float().numpy(), atol=_tol(dt, pre.grad))
 
 
+def test_logits_gradient_staging_copy_fast_path_equals_the_generic_copy():
+    """vsseg_copy_cast fp32 [voxel][2] -> bf16 rows of 8: with VSSEG_ZERO_PADDED the call writes whole rows (channels 2..7 = 0); without the flag it
+    must leave the other channels of the row alone.  Same values either way."""
+    lib = L.lib()
+    torch.manual_seed(3)
+    n, dims = 2, (5, 6, 7)
+    src = torch.randn(n, *dims, 2, device="cuda")
+    sd = L.Tensor(src.data_ptr(), L.F32, 2, 2, n, *dims)
+    a = torch.full((n, *dims, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    b = a.clone()
+    L.check(lib.vsseg_copy_cast(sd, L.Tensor(a.data_ptr(), L.BF16, 2, 8, n, *dims), H.stream()), "copy")
+    L.check(lib.vsseg_copy_cast(sd, L.Tensor(b.data_ptr(), L.BF16, 2, 8, n, *dims, None, 0, L.ZERO_PADDED), H.stream()), "copy (zero-padded rows)")
+    torch.cuda.synchronize()
+    assert torch.equal(a[..., :2], src.to(torch.bfloat16)) and torch.equal(b[..., :2], a[..., :2])
+    assert float(a[..., 2:].float().min()) == 7.0 and float(b[..., 2:].float().abs().max()) == 0.0
+
+
 def test_two_part_tensors_are_rejected_where_unsupported():
     lib = L.lib()
     a = torch.zeros(1, 4, 4, 4, 16, device="cuda")

@@ -17,6 +17,7 @@ MAX_TAPS = 27
 STAT_SHARDS = 256
 SEED_INDIRECT = 0x80000000
 EINVAL, ELAUNCH = -1, -2
+ZERO_PADDED = 1  # vsseg_tensor.reserved of a destination whose channels c .. pitch-1 are zero padding
 
 
 class Tensor(C.Structure):

@@ -637,7 +637,7 @@ class Plan:
         written: Dict[str, bool] = {}
         dlog8 = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
         x0, y0, z0 = self.lv[0]
-        self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0)]])
+        self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0, None, 0, L.ZERO_PADDED)]])
 
         def gdesc(spec: TensorSpec) -> L.Tensor:
             return self._desc(spec, self.grads)
