@@ -86,6 +86,38 @@ def test_bf16_batch4_dropout_matches_fp32_path_with_same_masks(monkeypatch):
     assert cos > 0.97, cos
 
 
+def test_reference_default_patch_tuned_plans_equal_heuristic_plans(monkeypatch):
+    """SELF-comparison at the reference's own training shape (VSparams defaults: batch 1 of 384x384x64, ref:params/VSparams.py:76-96): the
+    shipped measured plans (marching / streaming / compute / class-split kernels) against the heuristic plans of the general kernel on the same
+    bf16 step — same products, different fp32 summation orders — and every launch of that shape must come from the shipped plan file."""
+    seed, shape = 29, (1, 1, 384, 384, 64)
+    x, y = synth_input(seed, shape).cuda(), synth_label(seed, shape).cuda()
+    res = {}
+    for tune in ("0", "1"):
+        monkeypatch.setenv("VSSEG_AUTOTUNE", tune)
+        m = make_model("bf16", seed).train()
+        loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=True, hardness_weighting=True)
+        logits, atts = m(x)
+        loss = loss_fn((logits, atts), y)
+        loss.backward()
+        if tune == "1":
+            plan, chs = _plan_sources(m)
+            assert plan.tune and all(c.cached for c in chs if len(c.cands) > 1), "a launch of the 1x384x384x64 step is missing from vs_seg_amd/tuned_gfx950.json"
+            alts = [c.alt for cp in plan.cplans.values() for c in cp.fwd + cp.dgrad if c.alt is not None and c.alt.chosen is not None]
+            assert any(c.chosen.depth == -5 for c in chs) and alts and all(a.chosen.classes is not None and a.cached for a in alts)
+        res[tune] = (float(loss), logits.detach().float().flatten()[::4099].cpu().double(), {k: p.grad.detach().double().flatten().cpu() for k, p in m.named_parameters()})
+        del m, logits, atts, loss
+        torch.cuda.empty_cache()
+    assert abs(res["0"][0] - res["1"][0]) < 2e-3, (res["0"][0], res["1"][0])
+    rel = float((res["1"][1] - res["0"][1]).norm() / res["0"][1].norm())
+    assert rel < 1e-2, rel
+    g1 = torch.cat([g / (res["0"][2][k].norm() + 1e-30) for k, g in res["1"][2].items() if g.numel() > 1])
+    g0 = torch.cat([g / (g.norm() + 1e-30) for k, g in res["0"][2].items() if g.numel() > 1])
+    cos = float((g1 * g0).sum() / (g1.norm() * g0.norm()))
+    print("1x384x384x64 tuned vs heuristic plans: loss", res["0"][0], res["1"][0], "logits rel", rel, "grad cos", cos)
+    assert cos > 0.985, cos
+
+
 def _blob(shape, centre, radius):
     X, Y, Z = shape
     gx, gy, gz = np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij")
