@@ -186,15 +186,13 @@ def sharded_cases(model, n_cases, rank, world, dev, barrier, t2_shape=(448, 448,
     reference, SURVEY §8d: fixed at 448x448x80 here; z pads to 128 -> 12 windows at roi 384x128x128 / overlap 0.5) sharded round-robin over the
     ranks (`shard_indices`, as VSparams.run_inference does), hard Dice per case, the scores all-gathered INSIDE the timed region.  242 = the
     size of params/split_TCIA.csv.  Returns the `sharded_cases` block of the bench line (every rank takes part; all ranks return it)."""
-    import torch.distributed as dist
-
     import vs_seg_amd as V
     from vs_seg_amd import parallel as DP
 
     was_training = model.training
     model.eval()
     mine = DP.shard_indices(n_cases, rank, world)
-    pred = lambda w: model(w)[0]  # noqa: E731
+    pred = model.segmentation_predictor()  # `lambda x: model(x)[0]`, stream-safe: two window groups in flight (the product's default for this model)
     vols = [torch.from_numpy(np.random.default_rng(100 + i % 4).standard_normal((1, 1, *t2_shape), dtype=np.float32)).to(dev) for i in range(4)]  # 4 distinct volumes reused round-robin (HBM-resident inputs)
     lab = torch.zeros((1, 1, *t2_shape), device=dev)
     lab[..., 200:260, 210:250, 30:50] = 1.0
@@ -210,14 +208,35 @@ def sharded_cases(model, n_cases, rank, world, dev, barrier, t2_shape=(448, 448,
         all_scores = DP.all_gather_scalars(scores.double().cpu().tolist(), n_cases, device=dev if on_device else "cpu")  # one host read per rank, then the gather
         barrier()
         cdt = time.perf_counter() - s0
-    if world > 1:
-        t = torch.tensor([cdt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cdt = float(t)
+    cdt = DP.allreduce_max_float(cdt, dev)
     if was_training:
         model.train()
     return dict(volumes_per_sec=n_cases / cdt, cases=n_cases, volume="x".join(str(v) for v in t2_shape) + " (synthetic T2 shape)", roi="384x128x128", overlap=0.5, windows=12, mean_dice=float(np.mean(all_scores)),
                 scores=[round(float(v), 6) for v in all_scores][:16], sharding="cases round-robin over ranks (shard_indices), Dice scalars all-gathered inside the timed region")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a torchrun environment starts its own N ranks: the process replaces itself by
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`
+    (one rank per GPU over RCCL; rank 0 prints the one JSON line with n_gpus = N).  Fewer than N visible GPUs is an error, not a warning —
+    except with VSSEG_SHARE_DEVICE=1 (+ VSSEG_DIST_BACKEND=gloo), the smoke-test mode in which the ranks share the GPUs that are there."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and os.environ.get("VSSEG_SHARE_DEVICE") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible")
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {args.gpus} without a launcher environment: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -236,6 +255,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked configuration against the reference golden")
     ap.add_argument("--profile", action="store_true", help="print the per-kernel HIP-event breakdown of one step to stderr")
     args = ap.parse_args()
+    self_launch(args)
 
     import torch.distributed as dist
 
@@ -244,8 +264,7 @@ def main():
 
     rank, world, local = DP.init_distributed()
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -300,10 +319,7 @@ def main():
         loss = trainer.step(img, lab)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+    dt = DP.allreduce_max_float(dt, dev)
     dom = summarize_events(plan.timer["events"])[dominant]
     plan.timer = None
     phase(f"timed region done ({dt:.2f} s)")
@@ -348,11 +364,7 @@ def main():
                     V.sliding_window_inference(vol, PATCH, swb, pred, overlap=0.5, mode="gaussian", concurrent_groups=lanes)
                 barrier()
                 sdt = time.perf_counter() - s0
-            if world > 1:
-                t = torch.tensor([sdt], device=dev, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                sdt = float(t)
-            return sdt
+            return DP.allreduce_max_float(sdt, dev)
 
         sdt = time_swi(1)  # the reference's setting (ref:params/VSparams.py:571)
         swi = dict(volumes_per_sec=args.swi_volumes * world / sdt, ms_per_volume=1e3 * sdt / args.swi_volumes, volume="512x512x120", roi="384x128x128", overlap=0.5, windows=14, sw_batch_size=1,

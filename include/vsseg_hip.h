@@ -134,7 +134,39 @@ typedef struct {
 } vsseg_wgrad_desc;
 
 const char* vsseg_last_error(void);
-int vsseg_version(void);
+int vsseg_version(void); /* 2: fixed-point accumulators documented + vsseg_fx_status (1: the buffers below were described as plain doubles) */
+
+/* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------
+ * Every `double*` accumulator of this ABI — vsseg_igemm_desc.stats and vsseg_bn_finalize's `stats`, the `sums` / `alpha_acc` of
+ * vsseg_bn_act_bwd_reduce / _finalize, the `pred_sums` / `att_sums` of vsseg_dice_* — is declared `double*` for its size and alignment only:
+ * each 8-byte slot holds a two's-complement int64 = round(value * scale), added to with integer atomics so that the total does not depend on
+ * the order in which workgroups finish (a training step is run-to-run bit-identical).  Zero bytes are the value 0, so callers keep zero-filling
+ * the buffers (vsseg_memset_zero) exactly as before; callers that READ or PRE-FILL a slot must use the scale of its family:
+ *     VSSEG_FX_STAT_SCALE  2^20  BatchNorm forward statistics (sum, sum of squares)         per-workgroup partial |v| < 4.3e9
+ *     VSSEG_FX_GRAD_SCALE  2^44  BatchNorm / PReLU backward sums (sums, alpha_acc)           per-workgroup partial |v| < 256
+ *     VSSEG_FX_DICE_SCALE  2^32  Dice sums (pred_sums, att_sums)                              per-workgroup partial |v| < 1.0e6
+ * (vsseg_hard_dice_counts keeps REAL doubles: its sums are integers, exact in fp64 in any order.)
+ * A partial sum outside its range, or a NaN / Inf one, is clamped and sets a sticky per-process device flag; while the flag is set the decoding
+ * kernels (vsseg_bn_finalize, vsseg_bn_act_bwd_finalize, vsseg_dice_finalize) return NaN, so a diverging run or an out-of-range loss scale
+ * surfaces as NaN in the loss / statistics / gradients instead of as wrapped integers.  vsseg_fx_status reads (and optionally clears) the flag. */
+typedef double vsseg_fx_acc; /* one accumulator slot (reinterpret as int64_t) */
+#define VSSEG_FX_STAT_SCALE 1048576.0
+#define VSSEG_FX_GRAD_SCALE 17592186044416.0
+#define VSSEG_FX_DICE_SCALE 4294967296.0
+static inline vsseg_fx_acc vsseg_fx_encode(double value, double scale) {
+  union { int64_t i; double d; } u;
+  double s = value * scale;
+  u.i = (int64_t)(s < 0 ? s - 0.5 : s + 0.5);
+  return u.d;
+}
+static inline double vsseg_fx_decode(vsseg_fx_acc slot, double scale) {
+  union { int64_t i; double d; } u;
+  u.d = slot;
+  return (double)u.i / scale;
+}
+/* Returns 1 if a fixed-point partial sum was non-finite or out of range since the last reset, 0 if not, < 0 on error.  Synchronises `stream`.
+ * reset != 0 clears the flag (after the caller has handled the diverged step). */
+int vsseg_fx_status(int32_t reset, void* stream);
 
 int vsseg_igemm(const vsseg_igemm_desc* d, void* stream);
 int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d);

@@ -332,6 +332,78 @@ def test_bn_dropout_prelu_forward_backward(dt, p_drop, stored, centre):
     np.testing.assert_allclose(drb.cpu().numpy(), H.from_cl(gcl).double().sum((0, 2, 3, 4)).float().numpy(), rtol=1e-4, atol=1e-3)  # bias gradient of a residual conv
 
 
+@pytest.mark.parametrize("bad", ["nan", "large"])
+def test_fixed_point_sums_flag_non_finite_and_out_of_range_partials(bad):
+    """The order-independent accumulators are 64-bit fixed point (include/vsseg_hip.h): a NaN gradient, or one whose per-workgroup sum leaves the
+    documented range (|v| < 256 for the BatchNorm backward sums), must not come back as a finite wrapped integer.  The partial is clamped, the
+    sticky flag is set, and the kernels that decode the sums return NaN — as floating-point atomics would have — until the flag is cleared."""
+    import vs_seg_amd as V
+
+    lib = L.lib()
+    torch.manual_seed(9)
+    c, dims, n = 16, (8, 8, 4), 2
+    nvox = n * int(np.prod(dims))
+    ycl = H.to_cl(torch.randn(n, c, *dims), torch.float32)
+    gout = torch.randn(n, c, *dims)
+    if bad == "nan":
+        gout[0, 3, 1, 2, 3] = float("nan")
+    else:
+        gout *= 1.0e6  # sum(dout) of a workgroup ~ 1e6 * sqrt(voxels) >> 256
+    gcl = H.to_cl(gout, torch.float32)
+    g, be, al = torch.rand(c, device="cuda") + 0.5, torch.zeros(c, device="cuda"), torch.tensor([0.2], device="cuda")
+    vec = torch.zeros(6, c, device="cuda")
+    vec[1] = 1.0  # invstd
+    vec[2] = g    # scale (mean 0, invstd 1)
+    S = H.stream()
+    assert V.fx_status(reset=True) in (False, True)  # start from a cleared flag whatever ran before
+    assert V.fx_status() is False
+
+    def backward_sums():
+        sums = torch.zeros(L.STAT_SHARDS, 3, c, dtype=torch.float64, device="cuda")
+        aacc = torch.zeros(L.STAT_SHARDS, dtype=torch.float64, device="cuda")
+        L.check(lib.vsseg_bn_act_bwd_reduce(H.tdesc(ycl), H.tdesc(gcl), vec[0].data_ptr(), vec[1].data_ptr(), g.data_ptr(), be.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), 0.0, 0, 1, sums.data_ptr(), c, aacc.data_ptr(), None, S))
+        dg, db, da = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda"), torch.zeros(1, device="cuda")
+        L.check(lib.vsseg_bn_act_bwd_finalize(sums.data_ptr(), c, aacc.data_ptr(), c, float(nvox), dg.data_ptr(), db.data_ptr(), da.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(), None, S))
+        torch.cuda.synchronize()
+        return dg, db, da
+
+    dg, db, da = backward_sums()
+    assert V.fx_status() is True
+    assert torch.isnan(dg).all() and torch.isnan(db).all() and torch.isnan(da).all() and torch.isnan(vec[4]).all()
+    # sticky: the forward statistics and the loss of the same process are poisoned too, until the host clears the flag
+    stats = torch.zeros(L.STAT_SHARDS, 2, c, dtype=torch.float64, device="cuda")
+    rm, rv, nb = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda"), torch.zeros(1, dtype=torch.int64, device="cuda")
+    L.check(lib.vsseg_bn_finalize(stats.data_ptr(), c, c, float(nvox), g.data_ptr(), be.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), nb.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), S))
+    torch.cuda.synchronize()
+    assert torch.isnan(vec[0]).all() and torch.isnan(rm).all()
+    assert V.fx_status(reset=True) is True and V.fx_status() is False
+    # after the reset, well-scaled gradients give finite sums again
+    gcl.copy_(H.to_cl(torch.randn(n, c, *dims), torch.float32))
+    vec[1] = 1.0
+    vec[2] = g
+    vec[0] = 0.0
+    vec[3] = 0.0
+    dg, db, da = backward_sums()
+    assert V.fx_status() is False and torch.isfinite(dg).all() and torch.isfinite(db).all() and torch.isfinite(da).all()
+
+
+def test_dice_loss_of_nan_logits_is_nan():
+    """A diverged network (NaN logits) must show as a NaN loss, as in the reference (ref:params/VSparams.py:463 reads loss.item() every step): the Dice
+    sums are fixed-point integers, a NaN partial sum sets the flag and vsseg_dice_finalize returns NaN."""
+    import vs_seg_amd as V
+
+    V.fx_status(reset=True)
+    y = synth_label(31, (2, 1, 32, 32, 8)).cuda()
+    logits = (2.0 * synth_input(32, (2, 2, 32, 32, 8))).cuda()
+    logits[1, 0, 5, 6, 7] = float("nan")
+    loss = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=False, hardness_weighting=True)((logits.requires_grad_(True), []), y)
+    assert torch.isnan(loss).item()
+    assert V.fx_status(reset=True) is True
+    logits = (2.0 * synth_input(32, (2, 2, 32, 32, 8))).cuda().requires_grad_(True)
+    loss = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=False, hardness_weighting=True)((logits, []), y)
+    assert torch.isfinite(loss).item() and V.fx_status() is False
+
+
 @pytest.mark.parametrize("c", [32, 96, 160])
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_attention_gate_forward_backward(dt, c):

@@ -5,8 +5,11 @@ data-parallel semantics the 8-GPU runs rely on: the all-r
 single-rank gradients (per-rank BatchNorm statistics), fused Adam applies its mean so parameters stay identical across ranks,
 and the window-sharded sliding-window inference is bit-identical to the single-process result.
 """
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -162,7 +165,7 @@ def _rccl_worker(out_path, dtype):
         return out
 
     plain = run()
-    plain2 = run()  # run-to-run noise of the atomics' summation order (bf16 amplifies it): the yardstick for the comparison below
+    plain2 = run()  # a second non-distributed run: the step is run-to-run bit-identical, with or without the collectives
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), VSSEG_FORCE_COLLECTIVES="1")
     r, w, local = DP.init_distributed()
     assert (r, w, local) == (0, 1, 0) and dist.is_initialized() and dist.get_backend() == "nccl" and DP._collectives_on()
@@ -181,21 +184,14 @@ def test_rccl_branch_world_size_one_matches_the_non_distributed_run(tmp_path, dt
     assert p.exitcode == 0, p.exitcode
     res = torch.load(out)
     a, a2, b = res["plain"], res["plain2"], res["forced"]
-    # the collectives are identities at world size 1: what can differ is only the summation order of the fp32 atomics from run to run, which
-    # two non-distributed runs differ by as well — that run-to-run difference is the yardstick (a race between the side-stream weight
-    # gradients and the all-reduce would show as an O(1) difference)
-    noise = float((a["g"] - a2["g"]).norm() / a["g"].norm())
-    rel = float((a["g"] - b["g"]).norm() / a["g"].norm())
-    assert rel <= max(5.0 * noise, 2e-2 if dtype == "bf16" else 2e-3), (rel, noise)  # (the yardstick is one pair of runs: itself noisy)
-    assert abs(a["losses"][0] - b["losses"][0]) < (2e-3 if dtype == "bf16" else 1e-5), (a["losses"], b["losses"])
-    for la, lb in zip(a["losses"], b["losses"]):
-        assert abs(la - lb) < (2e-2 if dtype == "bf16" else 1e-4), (a["losses"], b["losses"])
-    relp = float((a["p"] - b["p"]).norm() / a["p"].norm())
-    # 3 Adam steps of lr 1e-3 on parameters of O(0.1 .. 1): an element whose gradient sign differs between the runs ends 6e-3 away
-    assert relp < (3e-2 if dtype == "bf16" else 5e-3), relp
-    # eval forward + blend are deterministic given the parameters: compare each run with its own parameters' result only through the Dice
-    assert a["swi"].shape == b["swi"].shape and torch.isfinite(b["swi"]).all()
-    assert len(b["dice"]) == 1 and abs(b["dice"][0] - b["mean"]) < 1e-6 and abs(a["dice"][0] - b["dice"][0]) < 5e-2
+    # The collectives are identities at world size 1 and every reduction of a step is order-independent (fixed-point statistics, fixed-order slab
+    # sums: tests/test_gpu_network.py::test_training_step_is_run_to_run_bit_identical), so the run through RCCL must reproduce the non-distributed
+    # run BIT FOR BIT: a race between the side-stream weight gradients and the all-reduce that corrupts any part of the gradient fails here.
+    for k in ("g", "p", "swi"):
+        assert torch.equal(a[k], a2[k]), f"two non-distributed runs differ in {k}"
+        assert torch.equal(a[k], b[k]), f"the world-size-1 RCCL run differs from the non-distributed run in {k}: max |d| {float((a[k] - b[k]).abs().max())}"
+    assert a["losses"] == a2["losses"] == b["losses"], (a["losses"], a2["losses"], b["losses"])
+    assert len(b["dice"]) == 1 and abs(b["dice"][0] - b["mean"]) < 1e-6 and a["dice"][0] == b["dice"][0]
 
 
 # ---- BASELINE config 5's harness (bench.py --swi-cases) at 6 cases, Dice scalars gathered through RCCL --------------------------------
@@ -239,3 +235,23 @@ def test_config5_harness_six_cases_through_rccl(tmp_path):
     assert s[0] == s[4] and s[1] == s[5]  # cases 0 / 4 and 1 / 5 are the same volume: eval forward + blend are deterministic
     assert abs(s[0] - res["direct"]) < 1e-6
     assert abs(b["mean_dice"] - float(np.mean(s))) < 1e-6
+
+
+# ---- `python bench.py --gpus 2` as the driver invokes it: no launcher environment, bench.py starts its own ranks -----------------------------
+def test_bench_gpus_2_starts_two_ranks_and_prints_one_line():
+    """SURVEY §8(e) / BASELINE configs 4-5: `python bench.py --gpus N` must run N ranks.  Two ranks share the one GPU of the test box
+    (VSSEG_SHARE_DEVICE=1, gloo): what is checked is the launch path and the `world > 1` branches of bench.py (barriers, max-over-ranks timing,
+    sharded cases, rank-0-only output), not a measurement."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VSSEG_SHARE_DEVICE="1", VSSEG_DIST_BACKEND="gloo", VSSEG_NO_POISON="1", VSSEG_AUTOTUNE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VSSEG_FORCE_COLLECTIVES", "VSSEG_TUNE_CACHE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--swi-volumes", "1", "--swi-cases", "2"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 alone prints
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
+    assert r["sharded_cases"]["cases"] == 2 and len(r["sharded_cases"]["scores"]) == 2
+    assert r["value"] > 0 and r["sliding_window"]["volumes_per_sec"] > 0 and "cpu_baseline" not in r

@@ -1,5 +1,6 @@
 """CPU tests of the host side: the C-ABI library loads and exports every declared symbol, plans lower without a GPU."""
 import ctypes
+import os
 import re
 
 import pytest
@@ -13,6 +14,7 @@ from vs_seg_amd.graph import build_program, state_manifest
 def test_library_exports_every_declared_symbol():
     lib = L.lib()
     header = open("include/vsseg_hip.h").read()
+    header = re.sub(r"static inline[^{]*\{.*?\n\}", "", header, flags=re.S)  # (the inline fixed-point encode / decode helpers are not exports)
     declared = set(re.findall(r"\b(vsseg_[a-z0-9_]+)\s*\(", header))
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     for name in declared:
@@ -100,3 +102,21 @@ def test_shipped_tuned_plans_still_name_existing_candidates():
         want = choice if len(choice) > 4 else choice + [1]
         hits += any([list(c.tile), c.nt, c.nsplit, c.ck, c.depth] == want for c in cands)
     assert checked >= 30 and hits >= 0.9 * checked, (hits, checked)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` outside a launcher environment starts its own ranks (bench.self_launch) — and fails loudly, before anything is
+    launched, when the box has fewer GPUs than ranks (there is none in the build container)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "VSSEG_SHARE_DEVICE")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--gpus 2 but only" in p.stderr and not p.stdout.strip()

@@ -106,7 +106,7 @@ class WgradDesc(C.Structure):
 
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_wgrad_narrow", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_wgrad_narrow", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -131,6 +131,7 @@ def lib():
         vp, i32, i64, f32, f64, u64, u32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64, C.c_uint32
         I3 = C.POINTER(C.c_int32)
         L.vsseg_store_u64.argtypes = [vp, u64, vp]
+        L.vsseg_fx_status.argtypes = [i32, vp]
         L.vsseg_memset_zero.argtypes = [vp, i64, vp]
         L.vsseg_copy_bytes.argtypes = [vp, vp, i64, vp]
         L.vsseg_crop_flip.argtypes = [vp, i32, vp, I3, vp]
@@ -170,9 +171,35 @@ def lib():
     return _lib
 
 
+class VssegError(RuntimeError):
+    """A library call returned a VSSEG_E* code: `rc` is the code (EINVAL = the library rejected the arguments, ELAUNCH = HIP refused the launch),
+    `detail` the library's message (for ELAUNCH it ends with HIP's own error string)."""
+
+    def __init__(self, rc: int, what: str, detail: str):
+        super().__init__(f"vsseg {what} failed ({rc}): {detail}")
+        self.rc, self.what, self.detail = rc, what, detail
+
+    @property
+    def during_capture(self) -> bool:
+        """HIP refused the call only because the stream is being captured into a graph (an allocation, attribute change or synchronisation inside
+        the captured region): the same launch list is fine when launched eagerly."""
+        return self.rc == ELAUNCH and "capture" in self.detail.lower()
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
-        raise RuntimeError(f"vsseg {what} failed ({rc}): {lib().vsseg_last_error().decode()}")
+        raise VssegError(rc, what, lib().vsseg_last_error().decode())
+
+
+def fx_status(reset: bool = False) -> bool:
+    """True if a fixed-point partial sum (BatchNorm statistics / backward sums, Dice sums) was non-finite or out of range since the last reset
+    (include/vsseg_hip.h: the kernels that decode those sums return NaN while the flag is set).  Synchronises the current stream."""
+    import torch
+
+    rc = lib().vsseg_fx_status(1 if reset else 0, torch.cuda.current_stream().cuda_stream)
+    if rc < 0:
+        check(rc, "fx_status")
+    return bool(rc)
 
 
 def i3(v):

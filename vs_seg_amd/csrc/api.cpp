@@ -13,7 +13,27 @@ extern "C" void vsseg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vsseg_last_error(void) { return g_err; }
-extern "C" int vsseg_version(void) { return 1; }
+extern "C" int vsseg_version(void) { return 2; }
+
+// Sticky flag of the fixed-point accumulators (csrc/common.h, vsseg_fx_add): one word of device memory per process (one process per GPU).
+unsigned* vsseg_fx_flag() {
+  static unsigned* f = nullptr;
+  if (!f) {
+    if (hipMalloc(reinterpret_cast<void**>(&f), 256) != hipSuccess || hipMemset(f, 0, 256) != hipSuccess) f = nullptr;
+  }
+  return f;
+}
+extern "C" int vsseg_fx_status(int32_t reset, void* stream) {
+  unsigned* f = vsseg_fx_flag();
+  if (!f) { vsseg_set_error("vsseg_fx_status: could not allocate the flag word"); return VSSEG_ELAUNCH; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  unsigned h = 0;
+  hipError_t e = hipMemcpyAsync(&h, f, sizeof(h), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess && reset && h) e = hipMemsetAsync(f, 0, sizeof(h), s);
+  if (e != hipSuccess) { vsseg_set_error("vsseg_fx_status: %s", hipGetErrorString(e)); return VSSEG_ELAUNCH; }
+  return (int)(h & 1u);
+}
 
 // Zero-fill / device copy on the caller's stream (replace the torch fill / clone kernels the step used to issue: per-step
 // statistics, the flat gradient buffer, gradient slices that receive their first contribution as a partial write).

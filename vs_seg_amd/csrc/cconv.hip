@@ -42,6 +42,7 @@ struct CconvK {
   const char* wpack;
   const float *bias, *bias2, *scale, *shift, *alpha;
   double* stats;
+  unsigned* fxflag;  // sticky range / non-finite flag of the fixed-point statistics (common.h)
   const void* zeros;
   int in_csplit_ch;  // first 16-channel chunk that lives in part 1 (>= nch for an ordinary tensor)
   int in_vox_bytes, out_vox_bytes, aux_vox_bytes;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) v += red[w * (2 * NT * 16) + i];
-      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + c], (double)v, VSSEG_FX_STAT);
+      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + c], (double)v, VSSEG_FX_STAT, k.fxflag);
     }
   }
 }
@@ -421,6 +422,7 @@ int vsseg_cconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
+  k.fxflag = vsseg_fx_flag();
   k.zeros = zeros;
   k.act = d->act; k.cout = d->out.c;
   k.nch = d->nchunks;

@@ -189,12 +189,27 @@ __device__ __forceinline__ void vsseg_dma16(const void* gsrc, const void* lds_wa
 //   statistics (sum, sum of squares of a convolution output, Dice sums): 2^-20 resolution per addend — an absolute error of <= 1e-6 * addends / count in a
 //     mean / variance, far below BatchNorm's eps = 1e-5 and below the fp32 rounding of the partial sums themselves; range 2^43 = 8.8e12 per slot
 //   gradient sums (BatchNorm backward, PReLU slope, bias gradients): 2^-44 resolution, range 2^19 = 5e5 per slot (the gradients of an O(1) loss)
+// RANGE AND NON-FINITE VALUES.  An addend (one workgroup's partial sum) must satisfy |v * scale| < 2^52 — then up to 2048 addends per slot cannot wrap the
+// 64-bit accumulator: statistics |v| < 4.3e9, gradient sums |v| < 256, Dice sums |v| < 1.0e6 per workgroup.  An addend outside that range, or a NaN / Inf
+// (a diverging run), is CLAMPED (NaN -> 0) and sets the library's sticky device flag (vsseg_fx_flag(), api.cpp); every kernel that DECODES fixed-point
+// sums (vsseg_bn_finalize, vsseg_bn_act_bwd_finalize, vsseg_dice_loss_fwd / _bwd) returns NaN while the flag is set, so that divergence or an
+// out-of-range loss scale shows up as NaN in the loss, the statistics and dgamma / dbeta / dalpha exactly as it did with floating-point atomics,
+// instead of as silently wrapped integers.  The host reads / clears the flag with vsseg_fx_status().
 constexpr double VSSEG_FX_STAT = 1048576.0;         // 2^20
 constexpr double VSSEG_FX_GRAD = 17592186044416.0;  // 2^44
-__device__ __forceinline__ void vsseg_fx_add(double* slot, double v, double scale) {
-  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(v * scale));
+constexpr double VSSEG_FX_LIMIT = 4503599627370496.0;  // 2^52, in fixed-point units
+unsigned* vsseg_fx_flag();  // api.cpp: the sticky range / non-finite flag word in device memory (nullptr if it could not be allocated)
+__device__ __forceinline__ void vsseg_fx_add(double* slot, double v, double scale, unsigned* flag) {
+  double s = v * scale;
+  if (!(fabs(s) < VSSEG_FX_LIMIT)) {  // out of range or not finite
+    atomicOr(flag, 1u);
+    s = s >= VSSEG_FX_LIMIT ? VSSEG_FX_LIMIT : (s <= -VSSEG_FX_LIMIT ? -VSSEG_FX_LIMIT : 0.0);
+  }
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double2ll_rn(s));
 }
 __device__ __forceinline__ double vsseg_fx_get(const double* slot, double scale) { return (double)*reinterpret_cast<const long long*>(slot) / scale; }
+// value a decoding kernel adds to its results: 0, or NaN while the flag is set
+__device__ __forceinline__ double vsseg_fx_poison(const unsigned* flag) { return *flag ? __longlong_as_double(0x7ff8000000000000ll) : 0.0; }
 
 // Partial-sum slabs slab[b][i] (b = workgroup of the producing kernel, i = output element) summed over all b by a 1024-thread block that owns 64
 // consecutive elements: thread (il = tid & 63, bl = tid >> 6) adds the slabs bl, bl + 16, ... with 8 independent loads in flight (<= 2048 slabs: 16

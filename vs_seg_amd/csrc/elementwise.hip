@@ -150,7 +150,7 @@ __device__ __forceinline__ double block256_sum_d(double v, double* part) {
 // one 256-thread block per channel: thread = statistics shard (a 64-thread block walking the 256 shards serially cost ~30 us
 // per layer, 1.6 ms per step over the 52 forward/backward finalisations)
 __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride, int c, double count, const float* gamma, const float* beta, float eps, float momentum,
-                                   float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift) {
+                                   float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift, const unsigned* fxflag) {
   static_assert(VSSEG_STAT_SHARDS == 256, "thread = shard");
   __shared__ double part[4];
   const int ch = blockIdx.x, sh = threadIdx.x;
@@ -158,7 +158,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride,
   const double q = block256_sum_d(vsseg_fx_get(&stats[(int64_t)sh * 2 * stride + stride + ch], VSSEG_FX_STAT), part);
   if (threadIdx.x != 0) return;
   if (ch == 0 && num_batches) *num_batches += 1;
-  double m = s / count;
+  double m = s / count + vsseg_fx_poison(fxflag);  // NaN while a partial sum was non-finite / out of range (common.h)
   double var = q / count - m * m;
   if (var < 0) var = 0;
   float is = (float)(1.0 / sqrt(var + (double)eps));
@@ -176,7 +176,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride,
 extern "C" int vsseg_bn_finalize(const double* stats, int32_t stride, int32_t c, double count, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift, void* stream) {
   VSSEG_CHECK(stats && gamma && beta && mean && invstd && scale && shift && c > 0 && c <= stride, "vsseg_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), stats, stride, c, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), stats, stride, c, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd, scale, shift, vsseg_fx_flag());
   VSSEG_LAUNCH_CHECK("vsseg_bn_finalize");
   return VSSEG_OK;
 }
@@ -334,7 +334,7 @@ template <> struct Raw8<float> {
 
 template <typename T, int U>
 __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __restrict__ y, int yp, const T* __restrict__ dout, int dp, BnBwdArgs a, int cgs, int64_t nvox, double* __restrict__ sums, int stride, double* __restrict__ alpha_acc,
-                                                               const uint8_t* __restrict__ keep_in) {
+                                                               const uint8_t* __restrict__ keep_in, unsigned* fxflag) {
   // one [3][c] + [1] region per WAVE: with a single region every thread of the workgroup added its 24 partial sums to the same 3*C
   // addresses (64 .. 128 lanes per address, serialised by the LDS): on a 48-channel 151 MB tensor that tail cost as much as the pass itself
   extern __shared__ float red[];
@@ -402,9 +402,9 @@ __global__ __launch_bounds__(1024) void bn_act_bwd_reduce_kernel(const T* __rest
     const int which = i / C, ch = i % C;
     double val = (double)wsum(i);
     if (which == 1) val *= (double)a.invstd[ch];  // sum(dz * xhat) of this workgroup
-    vsseg_fx_add(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val, VSSEG_FX_GRAD);  // order-independent (fixed-point integer atomics)
+    vsseg_fx_add(&sums[(int64_t)shard * 3 * stride + which * stride + ch], val, VSSEG_FX_GRAD, fxflag);  // order-independent (fixed-point integer atomics)
   }
-  if (threadIdx.x == 0) vsseg_fx_add(&alpha_acc[shard], (double)wsum(3 * C), VSSEG_FX_GRAD);
+  if (threadIdx.x == 0) vsseg_fx_add(&alpha_acc[shard], (double)wsum(3 * C), VSSEG_FX_GRAD, fxflag);
 }
 extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const float* mean, const float* invstd, const float* gamma, const float* beta, const float* scale, const float* shift, const float* alpha,
                                        float p_drop, uint64_t seed, uint32_t salt, double* sums, int32_t stride, double* alpha_acc, const uint8_t* keep_in, void* stream) {
@@ -427,22 +427,22 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   const int budget = 65536;  // fp64 flush atomics per launch the grid is sized for (measured)
   const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(192, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 3 : budget / (3 * y.c))));
   int grid = grid_for((nv * cgs + 1) / 2, blk, cap);  // 2 voxels in flight per thread (measured: 2 beats 4)
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in));
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in, vsseg_fx_flag()));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }
 
-__global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int stride, const double* __restrict__ alpha_acc, int c, double count, float* dgamma, float* dbeta, float* dalpha, float* mean_dz, float* mean_dzx, float* dres_bias) {
+__global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int stride, const double* __restrict__ alpha_acc, int c, double count, float* dgamma, float* dbeta, float* dalpha, float* mean_dz, float* mean_dzx, float* dres_bias, const unsigned* fxflag) {
   __shared__ double part[4];
   const int ch = blockIdx.x, sh = threadIdx.x;  // one block per channel, thread = shard
   const double* base = sums + (int64_t)sh * 3 * stride + ch;
-  const double s = block256_sum_d(vsseg_fx_get(&base[0], VSSEG_FX_GRAD), part);  // fixed-point shards (vsseg_fx_add)
-  const double q = block256_sum_d(vsseg_fx_get(&base[stride], VSSEG_FX_GRAD), part);
-  const double r = block256_sum_d(vsseg_fx_get(&base[2 * stride], VSSEG_FX_GRAD), part);
+  const double s = block256_sum_d(vsseg_fx_get(&base[0], VSSEG_FX_GRAD), part) + vsseg_fx_poison(fxflag);  // fixed-point shards (vsseg_fx_add); NaN while poisoned
+  const double q = block256_sum_d(vsseg_fx_get(&base[stride], VSSEG_FX_GRAD), part) + vsseg_fx_poison(fxflag);
+  const double r = block256_sum_d(vsseg_fx_get(&base[2 * stride], VSSEG_FX_GRAD), part) + vsseg_fx_poison(fxflag);
   double a = 0.0;
   if (ch == 0) a = block256_sum_d(vsseg_fx_get(&alpha_acc[sh], VSSEG_FX_GRAD), part);  // block-uniform branch
   if (threadIdx.x != 0) return;
-  if (ch == 0) *dalpha += (float)a;
+  if (ch == 0) *dalpha += (float)(a + vsseg_fx_poison(fxflag));
   if (dres_bias) dres_bias[ch] += (float)r;  // d(out)/d(residual) = 1: the residual convolution's bias gradient is sum(dout)
   dbeta[ch] += (float)s;
   dgamma[ch] += (float)q;
@@ -452,7 +452,7 @@ __global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int 
 extern "C" int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
                                          float* mean_dz, float* mean_dzx, float* dres_bias, void* stream) {
   VSSEG_CHECK(sums && alpha_acc && dgamma && dbeta && dalpha && mean_dz && mean_dzx && c > 0, "vsseg_bn_act_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx, dres_bias);
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx, dres_bias, vsseg_fx_flag());
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_finalize");
   return VSSEG_OK;
 }

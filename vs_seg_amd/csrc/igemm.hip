@@ -213,7 +213,8 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   int lds = igemm_prepare(d, k);
   if (lds < 0) return lds;
   k.zeros = zero_page();
-  VSSEG_CHECK(k.zeros, "vsseg_igemm: could not allocate the zero page");
+  k.fxflag = vsseg_fx_flag();
+  VSSEG_CHECK(k.zeros && k.fxflag, "vsseg_igemm: could not allocate the zero page / flag word");
   VSSEG_CHECK(k.total_tiles > 0 && k.total_tiles < (1ll << 31), "vsseg_igemm: bad tile count");
   k.tiles = tile_table(k, as_stream(stream));
   VSSEG_CHECK(k.tiles, "vsseg_igemm: could not allocate the tile table");

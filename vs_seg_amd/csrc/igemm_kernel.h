@@ -48,6 +48,7 @@ struct IgemmK {
   vsseg_tensor aux;
   int64_t total_tiles;
   const void* zeros;  // >= 16 bytes of zeros in global memory (source of out-of-bounds halo pieces)
+  unsigned* fxflag;   // sticky range / non-finite flag of the fixed-point statistics (common.h)
   const struct TileDesc* tiles;
 #ifdef VSSEG_IG_PROF
   unsigned long long* prof;  // tuning build only: per-phase shader-cycle sums of workgroup 0 / wave 0
@@ -755,7 +756,7 @@ __global__ __launch_bounds__(ig_spec(NT) ? 512 : 256, NT == 1 ? 4 : (NT == 2 ? (
       int which = i / (NT * 16), cc = i - which * NT * 16;
       int c = cbase + cc;
       const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
-      if (c < cout) vsseg_fx_add(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)v, VSSEG_FX_STAT);
+      if (c < cout) vsseg_fx_add(&st[which * d.stats_stride + (d.cout_mod > 0 ? c % d.cout_mod : c)], (double)v, VSSEG_FX_STAT, k.fxflag);
     }
   }
 }

@@ -34,7 +34,7 @@ extern "C" int vsseg_maxpool_label(const float* src, int32_t n, const int32_t sd
 // `fx` > 0: the block's sums are added as fixed-point integers of that scale (vsseg_fx_add: order-independent); 0: fp64 atomics (the hard-Dice voxel
 // counts: integers, exact in fp64 whatever the order)
 constexpr double VSSEG_FX_DICE = 4294967296.0;  // 2^32: sums of at most 2^31 voxel weights in [0, 1], 2.3e-10 resolution
-__device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double* dst, double fx) {
+__device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double* dst, double fx, unsigned* fxflag) {
   __shared__ double sh[16][8];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = 0; k < nvals; ++k) {
@@ -45,13 +45,13 @@ __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double
   if (threadIdx.x < nvals) {
     double t = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w][threadIdx.x];
-    if (fx > 0.0) vsseg_fx_add(&dst[threadIdx.x], t, fx);
+    if (fx > 0.0) vsseg_fx_add(&dst[threadIdx.x], t, fx, fxflag);
     else atomicAdd(&dst[threadIdx.x], t);
   }
 }
 
 // sums[b][c][0..2] = (I, G, P) of the (optionally hardness-weighted) 2-class soft Dice
-__global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, double* __restrict__ sums) {
+__global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, double* __restrict__ sums, unsigned* fxflag) {
   const int b = blockIdx.y;
   const float* lg = logits + (int64_t)b * nvox * pitch;
   const float* lb = label + (int64_t)b * nvox;
@@ -68,18 +68,18 @@ __global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitc
     I1 += w1 * g1 * p1; G1 += w1 * g1; P1 += w1 * p1;
   }
   double vals[6] = {I0, G0, P0, I1, G1, P1};
-  block_reduce_add(vals, 6, sums + (int64_t)b * 6, VSSEG_FX_DICE);
+  block_reduce_add(vals, 6, sums + (int64_t)b * 6, VSSEG_FX_DICE, fxflag);
 }
 extern "C" int vsseg_dice_pred_sums(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, double* sums, void* stream) {
   VSSEG_CHECK(logits && label && sums && pitch >= 2 && pitch % 2 == 0 && n >= 1, "vsseg_dice_pred_sums: bad arguments");
   dim3 g(grid_for(nvox, 256, 1024), n);
-  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums);
+  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums, vsseg_fx_flag());
   VSSEG_LAUNCH_CHECK("vsseg_dice_pred_sums");
   return VSSEG_OK;
 }
 
 // sums[b][0..2] = (I, G, P) of the single-channel Dice between an attention map and the pooled label
-__global__ void dice_att_sums_kernel(const float* __restrict__ att, const float* __restrict__ label, int64_t nvox, double* __restrict__ sums) {
+__global__ void dice_att_sums_kernel(const float* __restrict__ att, const float* __restrict__ label, int64_t nvox, double* __restrict__ sums, unsigned* fxflag) {
   const int b = blockIdx.y;
   const float* a = att + (int64_t)b * nvox;
   const float* lb = label + (int64_t)b * nvox;
@@ -89,25 +89,25 @@ __global__ void dice_att_sums_kernel(const float* __restrict__ att, const float*
     I += g * p; G += g; P += p;
   }
   double vals[3] = {I, G, P};
-  block_reduce_add(vals, 3, sums + (int64_t)b * 3, VSSEG_FX_DICE);
+  block_reduce_add(vals, 3, sums + (int64_t)b * 3, VSSEG_FX_DICE, fxflag);
 }
 extern "C" int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t nvox, double* sums, void* stream) {
   VSSEG_CHECK(att && label && sums && n >= 1, "vsseg_dice_att_sums: bad arguments");
   dim3 g(grid_for(nvox, 256, 1024), n);
-  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(256), 0, as_stream(stream), att, label, nvox, sums);
+  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(256), 0, as_stream(stream), att, label, nvox, sums, vsseg_fx_flag());
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_sums");
   return VSSEG_OK;
 }
 
 // loss = mean_{b,c} f_pred + sum_l (1/L) mean_b f_att,  f = 1 - (2I+eps)/(G+P+eps).  coef holds d(loss)/dI and d(loss)/dG(=dP).
-__global__ void dice_finalize_kernel(const double* pred_sums, const double* att_sums, int n, int nlevels, float* loss, float* coef) {
+__global__ void dice_finalize_kernel(const double* pred_sums, const double* att_sums, int n, int nlevels, float* loss, float* coef, const unsigned* fxflag) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double total = 0;
+  double total = vsseg_fx_poison(fxflag);  // NaN while a partial sum of this process was non-finite / out of range (common.h)
   for (int b = 0; b < n; ++b)
     for (int c = 0; c < 2; ++c) {
       const double* sp = pred_sums + (b * 2 + c) * 3;
       const double s[3] = {vsseg_fx_get(sp, VSSEG_FX_DICE), vsseg_fx_get(sp + 1, VSSEG_FX_DICE), vsseg_fx_get(sp + 2, VSSEG_FX_DICE)};
-      double D = s[1] + s[2] + SMOOTH, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / (2.0 * n);
+      double D = s[1] + s[2] + SMOOTH + total * 0.0, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / (2.0 * n);  // (+ NaN when poisoned: the coefficients too)
       total += wgt * (1.0 - num / D);
       coef[(b * 2 + c) * 2 + 0] = (float)(-2.0 / D * wgt);
       coef[(b * 2 + c) * 2 + 1] = (float)(num / (D * D) * wgt);
@@ -116,7 +116,7 @@ __global__ void dice_finalize_kernel(const double* pred_sums, const double* att_
     for (int b = 0; b < n; ++b) {
       const double* sp = att_sums + (l * n + b) * 3;
       const double s[3] = {vsseg_fx_get(sp, VSSEG_FX_DICE), vsseg_fx_get(sp + 1, VSSEG_FX_DICE), vsseg_fx_get(sp + 2, VSSEG_FX_DICE)};
-      double D = s[1] + s[2] + SMOOTH, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / ((double)nlevels * n);
+      double D = s[1] + s[2] + SMOOTH + total * 0.0, num = 2.0 * s[0] + SMOOTH, wgt = 1.0 / ((double)nlevels * n);
       total += wgt * (1.0 - num / D);
       coef[n * 4 + (l * n + b) * 2 + 0] = (float)(-2.0 / D * wgt);
       coef[n * 4 + (l * n + b) * 2 + 1] = (float)(num / (D * D) * wgt);
@@ -125,7 +125,7 @@ __global__ void dice_finalize_kernel(const double* pred_sums, const double* att_
 }
 extern "C" int vsseg_dice_finalize(const double* pred_sums, const double* att_sums, int32_t n, int32_t nlevels, float* loss, float* coef, void* stream) {
   VSSEG_CHECK(pred_sums && loss && coef && (nlevels == 0 || att_sums), "vsseg_dice_finalize: bad arguments");
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), pred_sums, att_sums, n, nlevels, loss, coef);
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), pred_sums, att_sums, n, nlevels, loss, coef, vsseg_fx_flag());
   VSSEG_LAUNCH_CHECK("vsseg_dice_finalize");
   return VSSEG_OK;
 }
@@ -191,7 +191,7 @@ __global__ void hard_dice_kernel(const float* __restrict__ logits, int pitch, co
     pg += pr * gg; p += pr; g += gg;
   }
   double vals[3] = {pg, p, g};
-  block_reduce_add(vals, 3, counts, 0.0);
+  block_reduce_add(vals, 3, counts, 0.0, nullptr);
 }
 extern "C" int vsseg_hard_dice_counts(const float* logits, int32_t pitch, const float* label, int64_t nvox, double* counts, void* stream) {
   VSSEG_CHECK(logits && label && counts && pitch >= 2 && pitch % 2 == 0, "vsseg_hard_dice_counts: bad arguments");

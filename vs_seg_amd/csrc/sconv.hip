@@ -38,6 +38,7 @@ struct SconvK {
   const char* wpack;
   const float *bias, *bias2, *scale, *shift, *alpha;
   double* stats;
+  unsigned* fxflag;  // sticky range / non-finite flag of the fixed-point statistics (common.h)
   const void* zeros;
   int in_csplit_pc;  // first 16-byte piece of a voxel row that lives in part 1 (>= pieces per voxel for an ordinary tensor)
   int in_vox_bytes, out_vox_bytes, aux_vox_bytes;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256, NT >= 4 ? 2 : 3) void sconv_kernel(const Sconv
     for (int i = tid; i < 2 * NT * 16; i += 256) {
       const int which = i / (NT * 16), c = i - which * NT * 16;
       const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
-      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)v, VSSEG_FX_STAT);
+      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)v, VSSEG_FX_STAT, k.fxflag);
     }
   }
 }
@@ -431,6 +432,7 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
+  k.fxflag = vsseg_fx_flag();
   k.zeros = zeros;
   k.act = d->act; k.cout = d->depth == -4 ? d->nt * 16 : d->out.c; k.cout_mod = d->cout_mod;
   k.ps_cls0 = d->depth == -4 ? 2 * d->oo[0] : 0;

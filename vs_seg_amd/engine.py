@@ -405,7 +405,7 @@ class Plan:
         if alt.chosen is not None or chs[0].chosen is not None:  # a further launch of the same op (another sample): same decision
             return alt.chosen is not None
         key = (f"use_cs|{p0.kind}|w{alt.wshape}|q{p0.q}|n{nb}|es{self.eng.es}|kc{p0.kc}|acc{int(kw.get('accumulate', 0))}|res{int(kw.get('res_mode', 0))}"
-               f"|st{int(bool(kw.get('stats')))}|two{int(bool(inp.ptr2))}{int(bool(out.ptr2))}")
+               f"|st{int(bool(kw.get('stats')))}|two{int(bool(inp.ptr2))}{int(bool(out.ptr2))}" + ("|gate" if kw.get("gate") else ""))
         cache = _tune_cache()
         if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
             return bool(cache[key])
@@ -485,6 +485,19 @@ class Plan:
                     bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / (1 if pl.classes is not None else ncls))
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
+    def _march_cands(self, ch: _Choice, Lr: Layer) -> List[P.IgemmPlan]:
+        """The marching-kernel plans (depth -5) of a stride-1 3x3x1 forward launch: those among its candidates when the autotuner listed them, else
+        planner.march_plans' deterministic list (the untuned lowering then takes the first one)."""
+        got = [pl for pl in ch.cands if pl.depth == -5]
+        if got or len(ch.cands) != 1:
+            return got
+        p0 = ch.cands[0]
+        got = P.march_plans(p0.kind, Lr.wshape, p0.cls, p0.q, self.eng.es, p0.kc, p0.nc, p0.kreal, self.n)
+        for pl in got:
+            if pl.pack_map is None:
+                pl.pack_map = P.pack_map(pl, Lr.wshape)
+        return got
+
     @staticmethod
     def _igemm_name(pl: P.IgemmPlan, inp: L.Tensor) -> str:
         """Kernel group of a convolution launch in the profiles: which of the four kernels its plan runs on."""
@@ -553,7 +566,7 @@ class Plan:
         # gradient read x and the attention map and multiply in LDS (csrc/mconv.hip MODE 3, csrc/mwgrad.hip GIN): vsseg_att_apply_fwd is not launched and
         # the gated tensor (2c channels at the level's resolution) is neither written nor read back.  Level 0 of this network (the logits convolution).
         self.gate_onload: Dict[str, AttGate] = {}
-        if eng.gate_onload and eng.es == 2 and self.tune:
+        if eng.gate_onload and eng.es == 2:  # (independent of the autotuner: VSSEG_AUTOTUNE=0 lowers the same graph, with the first marching plan)
             for g in ops:
                 if not isinstance(g, AttGate):
                     continue
@@ -566,7 +579,7 @@ class Plan:
                 Lc, cpc = c.layer, self.cplans[c.layer.prefix]
                 if Lc.transposed or tuple(Lc.stride) != (1, 1, 1) or Lc.kernel != (3, 3, 1) or Lc.cin != 32 or Lc.cout > 8 or c.x is not g.out or len(cpc.fwd) != 1 or cpc.fold_fwd or g.x.c != Lc.cin:
                     continue
-                if not any(pl.depth == -5 for pl in cpc.fwd[0].cands):
+                if not self._march_cands(cpc.fwd[0], Lc):
                     continue
                 if self.train and not P.march_wgrad_tiles(Lc.cin, 8, self.lv[Lc.level], self.n, eng.wgrad_scratch().numel()):
                     continue
@@ -607,7 +620,7 @@ class Plan:
                 gl = self.gate_onload.get(op.x.name)
                 if gl is not None:  # the attention gate in front of this convolution is applied on load: read x and the attention map, marching plans only
                     ch0 = cp.fwd[0]
-                    gch = _Choice([pl for pl in ch0.cands if pl.depth == -5], ch0.woff, ch0.wshape2, ch0.woff2, wshape=ch0.wshape)
+                    gch = _Choice(self._march_cands(ch0, Lr), ch0.woff, ch0.wshape2, ch0.woff2, wshape=ch0.wshape)
                     cp.fwd[0] = gch
                     self._igemm(F, gch, self._desc(gl.x), self._desc(op.out), bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act],
                                 in_gate=self._alloc(gl.att, self.bufs).data_ptr())
@@ -787,6 +800,9 @@ class Plan:
                     cache[key] = list(bestk)
                     _tune_cache.dirty = True
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
+            elif gl is not None:  # untuned lowering of a gated H operand: the marching kernel is the only one that gates on load — its first tile
+                assert mtiles, "gate-on-load was enabled for a layer without a marching weight-gradient tile"
+                d.march, live_tile = 1, L.i3(mtiles[0])
             d.tile = live_tile
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
@@ -941,8 +957,8 @@ class Plan:
                     import warnings
 
                     self._graphs.pop(graph_key, None)
-                    if str(e).startswith("vsseg "):  # a launch the library rejected (L.check) is an error of the step, not of the capture
-                        raise
+                    if isinstance(e, L.VssegError) and not e.during_capture:  # the library rejected a launch (bad arguments, a real launch failure): an error of the step,
+                        raise                                                  # not of the capture — only calls HIP refuses BECAUSE the stream is capturing fall back
                     torch.cuda.synchronize()
                     if torch.cuda.is_current_stream_capturing():
                         raise RuntimeError(f"vs_seg_amd: hipGraph capture of the {graph_key} launch list failed ({e}) and left the stream capturing") from e
@@ -1059,9 +1075,27 @@ class Engine:
             for d, m in zip(key[1], self.min_multiple()):
                 if d % m:
                     raise ValueError(f"spatial size {key[1]} must be a multiple of {self.min_multiple()} (product of the network strides)")
-            pl = Plan(self, *key[:3])
+            pl = self._lower_rank0_first(key) if train else Plan(self, *key[:3])
             self.plans[key] = pl
         return pl
+
+    def _lower_rank0_first(self, key) -> Plan:
+        """Data parallel: rank 0 lowers the training plan (measuring whatever the shipped / cached plans do not cover), broadcasts its measured
+        choices, and the other ranks lower from those — every rank then runs the same kernels with the same memory footprint, and the step stays
+        bit-reproducible across ranks and processes.  Training plans only: every rank creates them at the same step (DataParallelTrainer), which an
+        eval plan (a rank without test cases never lowers one) does not guarantee.  Single process: plain lowering."""
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or self.dry_run or os.environ.get("VSSEG_AUTOTUNE", "1") == "0":
+            return Plan(self, *key[:3])
+        if dist.get_rank() == 0:
+            pl = Plan(self, *key[:3])
+            dist.broadcast_object_list([dict(_tune_cache())], src=0)
+            return pl
+        box = [None]
+        dist.broadcast_object_list(box, src=0)
+        _tune_cache().update(box[0])
+        return Plan(self, *key[:3])
 
     def min_multiple(self):
         m = [1, 1, 1]

@@ -10,7 +10,7 @@ how windows are spread over GPUs (`vs_seg_amd.parallel.sharded_sliding_window_in
 from __future__ import annotations
 
 import math
-from typing import Callable, Dict, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -123,10 +123,16 @@ def _side_stream(device, i: int) -> "torch.cuda.Stream":
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable, overlap: float = 0.25, mode: str = "constant", padding_mode: str = "constant",
-                             cval: float = 0.0, device=None, concurrent_groups: int = 2) -> torch.Tensor:
-    """`concurrent_groups` (not a MONAI argument; 1 = strictly serial): consecutive window groups run their predictor on that many HIP streams, so
-    the latency-bound deep levels of one window's forward overlap the bandwidth-bound outer levels of the next; the blend (`out += map*seg`) stays
-    on the caller's stream in window order, so the result is bit-identical to the serial schedule."""
+                             cval: float = 0.0, device=None, concurrent_groups: Optional[int] = None) -> torch.Tensor:
+    """`concurrent_groups` (not a MONAI argument; 1 = strictly serial, the reference's schedule): consecutive window groups run their predictor on that
+    many HIP streams, so the latency-bound deep levels of one window's forward overlap the bandwidth-bound outer levels of the next; the blend
+    (`out += map*seg`) stays on the caller's stream in window order, so the result is bit-identical to the serial schedule.
+
+    The default is 1 for an arbitrary `predictor` — a callable that reuses buffers between calls, or returns views of them, would race on two
+    streams — and 2 for a predictor that declares itself `stream_safe` (`UNet2d5_spvPA.segmentation_predictor()`: one set of eval activation
+    buffers, packed weights and hipGraph per stream, i.e. twice the eval memory and lowering time of the serial schedule)."""
+    if concurrent_groups is None:
+        concurrent_groups = 2 if getattr(predictor, "stream_safe", False) else 1
     if not inputs.is_cuda:
         raise RuntimeError("vs_seg_amd.sliding_window_inference runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
     if inputs.dim() != 5 or inputs.shape[1] != 1:

@@ -206,6 +206,17 @@ class UNet2d5_spvPA(nn.Module):
             self.att_maps = atts
         return logits, self.att_maps
 
+    def segmentation_predictor(self):
+        """`lambda x: model(x)[0]` (the predictor the reference hands to sliding_window_inference, ref:params/VSparams.py:560) marked `stream_safe`:
+        eval forwards of this model issued on different HIP streams use separate plans (activation buffers, packed weights, hipGraph), so the
+        inferer may keep two window groups in flight (vs_seg_amd.inferers.sliding_window_inference, `concurrent_groups`)."""
+
+        def predictor(*a, **k):
+            return self(*a, **k)[0]
+
+        predictor.stream_safe = True
+        return predictor
+
     MAX_EVAL_SLOTS = 4  # independent sets of eval activation buffers (one per HIP stream that runs eval forwards)
 
     def _eval_slot(self, stream: int) -> int:

@@ -139,6 +139,15 @@ def allreduce_scalar_mean(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def allreduce_max_float(value: float, device="cpu") -> float:
+    """Maximum of one host scalar over the ranks (the max-over-ranks wall time of a timed region); identity in a single process."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t)
+
+
 def allreduce_sum(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (identity in a single process); returns x."""
     if _collectives_on():

@@ -331,7 +331,7 @@ class VSparams:
         model.eval()
         n = len(data_loader)
         dice_dev = torch.zeros(n, dtype=torch.float32, device=self.device)
-        predictor = lambda *a, **k: model(*a, **k)[0]  # noqa: E731
+        predictor = model.segmentation_predictor() if hasattr(model, "segmentation_predictor") else (lambda *a, **k: model(*a, **k)[0])  # model_segmentation, ref:params/VSparams.py:560
         mine = DP.shard_indices(n)  # the unpadded, unshuffled test loader yields exactly these cases, in this order
         with torch.no_grad():
             for i, data in enumerate(data_loader):
