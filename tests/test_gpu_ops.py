@@ -615,8 +615,14 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
     tz, mtw = shape
     mp = [pl for pl in P.march_plans(kind, tuple(w.shape), cls, dims, 2, kc, nreal, kreal, n=2) if (pl.tile[2], pl.mtw) == (tz, mtw)]
     assert mp, "no marching plan for this shape"
-    mp = dataclasses.replace(mp[0], tile=(lx, mp[0].tile[1], tz))
-    mp.pack_map = P.pack_map(mp, tuple(w.shape))
+    mps = []
+    for depth in P.MARCH_DEPTHS:  # -5: packed weights in LDS, -6: in registers (where instantiated)
+        m_ = [pl for pl in mp if pl.depth == depth]
+        if m_:
+            m_ = dataclasses.replace(m_[0], tile=(lx, m_[0].tile[1], tz))
+            m_.pack_map = P.pack_map(m_, tuple(w.shape))
+            mps.append(m_)
+    assert mps and mps[0].depth == -5
     parts = H._split_cl(inp_cl, split) if split else None
     odt = torch.float32 if nout == 2 else H.DT[dt]
     res_t = H.to_cl(_round(torch.randn(2, nout, *dims), dt), H.DT[dt])
@@ -625,7 +631,7 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
     modes = ["plain", "stats", "prelu"] + (["accumulate", "res_add", "relu_mask", "gate"] if nout % 4 == 0 else [])
     for mode in modes:
         outs = []
-        for pl in (gen, mp):
+        for pl in (gen, *mps):
             out = torch.zeros(2, *dims, nout, dtype=odt, device="cuda")
             kw, stats = {}, None
             if mode == "stats":
@@ -647,13 +653,14 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
             L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm D={pl.depth} {mode}")
             torch.cuda.synchronize()
             outs.append((out, stats))
-        (og, sg), (om, sm) = outs
-        assert torch.equal(og, om), f"{mode}: marching kernel differs from the general kernel (max {float((og.float() - om.float()).abs().max())})"
-        if mode == "plain":
-            np.testing.assert_allclose(H.from_cl(om).numpy(), want.float().numpy(), atol=_tol(dt, want))
-        if mode == "stats":
-            a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
-            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+        og, sg = outs[0]
+        for pl, (om, sm) in zip(mps, outs[1:]):
+            assert torch.equal(og, om), f"{mode}: marching kernel (depth {pl.depth}) differs from the general kernel (max {float((og.float() - om.float()).abs().max())})"
+            if mode == "plain":
+                np.testing.assert_allclose(H.from_cl(om).numpy(), want.float().numpy(), atol=_tol(dt, want))
+            if mode == "stats":
+                a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
+                np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("dims,split,shape,lx", [((7, 128, 4), 16, (2, 4), 3), ((6, 64, 8), 16, (4, 4), 6), ((5, 64, 8), 0, (4, 2), 2)])

@@ -242,6 +242,10 @@ def test_bench_gpus_2_starts_two_ranks_and_prints_one_line():
     """SURVEY §8(e) / BASELINE configs 4-5: `python bench.py --gpus N` must run N ranks.  Two ranks share the one GPU of the test box
     (VSSEG_SHARE_DEVICE=1, gloo): what is checked is the launch path and the `world > 1` branches of bench.py (barriers, max-over-ranks timing,
     sharded cases, rank-0-only output), not a measurement."""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()  # the ranks are other processes on the same GPU: hand the memory cached by this session's earlier tests back to the driver
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VSSEG_SHARE_DEVICE="1", VSSEG_DIST_BACKEND="gloo", VSSEG_NO_POISON="1", VSSEG_AUTOTUNE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "VSSEG_FORCE_COLLECTIVES", "VSSEG_TUNE_CACHE"):

@@ -184,13 +184,13 @@ static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
 extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && (d->depth == -2 || d->depth == -4)) return vsseg_sconv_lds_bytes(d);
   if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
-  if (d && d->depth == -5) return vsseg_mconv_lds_bytes(d);
+  if (d && (d->depth == -5 || d->depth == -6)) return vsseg_mconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
 
 extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
-  VSSEG_CHECK(!d || !d->in_gate || d->depth == -5, "vsseg_igemm: the input gate (in_gate) needs a marching-kernel plan (depth -5)");
+  VSSEG_CHECK(!d || !d->in_gate || d->depth == -5 || d->depth == -6, "vsseg_igemm: the input gate (in_gate) needs a marching-kernel plan (depth -5 / -6)");
   if (d && (d->depth == -2 || d->depth == -4)) {  // streaming kernel (sconv.hip; -4: fused output-parity classes): fails loudly when the launch is outside its domain, never falls back
     VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
     const void* z = zero_page();
@@ -203,7 +203,7 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_cconv_launch(d, z, as_stream(stream));
   }
-  if (d && d->depth == -5) {  // marching streaming kernel (mconv.hip): same contract
+  if (d && (d->depth == -5 || d->depth == -6)) {  // marching streaming kernel (mconv.hip; -6: packed weights in registers): same contract
     VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");

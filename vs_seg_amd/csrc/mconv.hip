@@ -50,12 +50,16 @@ struct MconvK {
 // AttentionBlock2's `att.repeat(C) * x + x` (ref:params/networks/blocks/attentionblock.py:43-47) is a per-voxel scalar on the convolution's input.
 // A thread multiplies the pieces IT fetched by (1 + att[voxel]) in LDS (fp32 product rounded to bf16: bit-identical to vsseg_att_apply_fwd) right
 // after its own DMA wait and in front of the step's barrier — no extra barrier, and the gated tensor is never written to HBM or read back.
-template <int CIN, int NT, int TZ, int MT, int MODE>
+// WREG (launch plans with depth -6): the packed weights live in REGISTERS (KSTEPS x NT fragments of 4 VGPRs, loaded once per workgroup) instead of in LDS.
+// With few M-tiles per wave the K loop re-reads every weight fragment from LDS at every x step — on the 64 -> 32 layers (MT = 1, 36 fragments per
+// step and wave against 18 operand fragments) two thirds of the LDS bandwidth the launch is bound by; in registers they cost nothing per step and
+// the 9-36 KB of LDS they occupied go back to the ring.
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr bool STATS = MODE == 1, AUXM = MODE == 2, GIN = MODE == 3;
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
-  constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = KSTEPS * NT * 1024;
+  constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = WREG ? 0 : KSTEPS * NT * 1024;
   constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
@@ -71,7 +75,15 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   const int xs = b % k.nxs; const int n = b / k.nxs;
   const int y0 = yb * TYB, z0 = zb * TZ, xb = xs * k.lx, steps = min(k.lx, X - xb);
 
-  for (int i = tid; i < W_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Wl)[i] = reinterpret_cast<const uint4*>(k.wpack)[i];
+  if constexpr (!WREG)
+    for (int i = tid; i < W_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Wl)[i] = reinterpret_cast<const uint4*>(k.wpack)[i];
+  bf16x8 wreg[WREG ? KSTEPS : 1][WREG ? NT : 1];
+  if constexpr (WREG) {
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wreg[ks][t] = *reinterpret_cast<const bf16x8*>(k.wpack + ((ks * NT + t) * 64 + lane) * 16);
+  }
   for (int i = tid; i < MC_NR * PLANE_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Rl)[i] = make_uint4(0u, 0u, 0u, 0u);  // rows outside the image stay zero: they are never fetched
   for (int i = tid; i < NT * 16; i += 256) {
     const bool ok = i < cout;
@@ -227,7 +239,10 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     for (int ks = 0; ks < KSTEPS; ++ks) {
       bf16x8 w[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (ks * NT + t) * 1024);
+      for (int t = 0; t < NT; ++t) {
+        if constexpr (WREG) w[t] = wreg[ks][t];
+        else w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (ks * NT + t) * 1024);
+      }
       const char* hb = Rl + koff[ks] + (dxk[ks] == 0 ? sm1 : (dxk[ks] == 1 ? s0 : sp1));
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   if constexpr (STATS) {  // per-channel sum / sum of squares of this workgroup's voxels: shuffle tree -> one LDS row per wave, summed in wave order -> the layer's
                           // sharded statistics as fixed-point integer atomics (order-independent: vsseg_fx_add; layout of vsseg_igemm_desc.stats)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][NT*16]: the weights are no longer needed
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][NT*16]: the weights / the ring are no longer needed
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -345,41 +360,44 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-template <int CIN, int NT, int TZ, int MT> static int mc_lds() {
+template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds() {
   constexpr int G = CIN / 8, RS = TZ * G, RPM = 16 / TZ, ROWS = MT * 4 * RPM + 2, KSTEPS = (9 * G + 3) / 4;
-  return KSTEPS * NT * 1024 + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
+  constexpr int red = 4 * 2 * NT * 16 * 4;  // statistics reduction buffer (aliases the weights / the ring)
+  const int lds = (WREG ? 0 : KSTEPS * NT * 1024) + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
+  return lds > red ? lds : red;
 }
-template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_mode(const MconvK& k, int grid, hipStream_t s) {
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG> static int mc_launch_mode(const MconvK& k, int grid, hipStream_t s) {
   static bool init = false;
-  const int lds = mc_lds<CIN, NT, TZ, MT>();
+  const int lds = mc_lds<CIN, NT, TZ, MT, WREG>();
   if (!init) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, WREG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     init = true;
   }
-  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE, WREG>), dim3((unsigned)grid), dim3(256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_igemm (marching)");
   return VSSEG_OK;
 }
-template <int CIN, int NT, int TZ, int MT> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
+template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.in_gate) {
-    if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
+    if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3, WREG>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
     else { vsseg_set_error("vsseg_igemm: no marching-kernel instantiation with the input gate for this shape"); return VSSEG_EINVAL; }
   }
-  if (k.stats) return mc_launch_mode<CIN, NT, TZ, MT, 1>(k, grid, s);
-  if (k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 2>(k, grid, s);
-  return mc_launch_mode<CIN, NT, TZ, MT, 0>(k, grid, s);
+  if (k.stats) return mc_launch_mode<CIN, NT, TZ, MT, 1, WREG>(k, grid, s);
+  if (k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 2, WREG>(k, grid, s);
+  return mc_launch_mode<CIN, NT, TZ, MT, 0, WREG>(k, grid, s);
 }
 
 typedef int (*mc_fn_t)(const MconvK&, int, hipStream_t);
-struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); };
-#define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M>, mc_lds<C, N, Z, M>}
+struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg; int (*lds_wreg)(); };
+#define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, nullptr, nullptr}
+#define MC_W(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, mc_launch<C, N, Z, M, true>, mc_lds<C, N, Z, M, true>}  // + the depth -6 twin (weights in registers)
 // (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
 static const McEntry mc_table[] = {
     MC_E(8, 1, 8, 8), MC_E(8, 2, 8, 8), MC_E(8, 1, 4, 8), MC_E(8, 2, 4, 8), MC_E(8, 1, 4, 4), MC_E(8, 2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
     MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
-    MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_E(16, 2, 4, 2), MC_E(16, 2, 8, 4), MC_E(32, 1, 4, 2), MC_E(32, 2, 4, 2), MC_E(8, 1, 8, 4), MC_E(8, 2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
-    MC_E(32, 1, 2, 4), MC_E(32, 1, 4, 4), MC_E(32, 1, 2, 2), MC_E(32, 2, 4, 4), MC_E(32, 2, 2, 4), MC_E(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_E(32, 4, 2, 2), MC_E(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
-    MC_E(64, 2, 2, 2), MC_E(64, 2, 2, 1), MC_E(64, 1, 2, 2), MC_E(64, 1, 2, 1)};                                                   // 64 -> 32 / 16
+    MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_W(16, 2, 4, 2), MC_W(16, 2, 8, 4), MC_W(32, 1, 4, 2), MC_W(32, 2, 4, 2), MC_E(8, 1, 8, 4), MC_E(8, 2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
+    MC_W(32, 1, 2, 4), MC_W(32, 1, 4, 4), MC_W(32, 1, 2, 2), MC_W(32, 2, 4, 4), MC_W(32, 2, 2, 4), MC_W(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_W(32, 4, 2, 2), MC_W(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
+    MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1)};                                                   // 64 -> 32 / 16
 
 static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
@@ -405,21 +423,21 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
     if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");
   }
   for (const McEntry& e : mc_table)
-    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt) return &e;
+    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
   return no("no instantiation for this (channels, nt, tz, mtw)");
 }
 
 int vsseg_mconv_lds_bytes(const vsseg_igemm_desc* d) {
   const char* why;
   const McEntry* e = mc_find(d, &why);
-  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
-  return e->lds();
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 / -6 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  return d->depth == -6 ? e->lds_wreg() : e->lds();
 }
 
 int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t s) {
   const char* why;
   const McEntry* e = mc_find(d, &why);
-  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  if (!e) { vsseg_set_error("vsseg_igemm: depth -5 / -6 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
   MconvK k;
   k.in0 = reinterpret_cast<const char*>(d->in.ptr);
   k.in1 = d->in.ptr2 ? reinterpret_cast<const char*>(d->in.ptr2) - (int64_t)d->in.csplit * 2 : k.in0;
@@ -459,5 +477,5 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.nxs = (k.X + k.lx - 1) / k.lx; k.nyb = k.Y / d->tile[1]; k.nzb = k.Z / d->tile[2];
   const int64_t grid = (int64_t)d->in.n * k.nxs * k.nyb * k.nzb;
   VSSEG_CHECK(grid > 0 && grid < (1ll << 30), "vsseg_igemm: bad marching grid");
-  return e->fn(k, (int)grid, s);
+  return d->depth == -6 ? e->fn_wreg(k, (int)grid, s) : e->fn(k, (int)grid, s);
 }

@@ -326,7 +326,10 @@ class Plan:
                f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else ""))
         cache = _tune_cache()
         hit = cache.get(key)
-        if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+        # VSSEG_RETUNE_DEPTHS="-6": launches with a candidate plan of one of these depths are measured again although a choice is cached (how the plans of a
+        # NEW kernel variant get into the cache without re-measuring every launch: tools/tune_shapes.py)
+        retune = {int(v) for v in os.environ.get("VSSEG_RETUNE_DEPTHS", "").split(",") if v.strip()}
+        if hit is not None and os.environ.get("VSSEG_AUTOTUNE", "1") != "force" and not any(pl.depth in retune for pl in ch.cands):
             for pl in ch.cands:
                 if [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth] == (hit if len(hit) > 4 else hit + [1]):
                     ch.cached = True
@@ -488,7 +491,7 @@ class Plan:
     def _march_cands(self, ch: _Choice, Lr: Layer) -> List[P.IgemmPlan]:
         """The marching-kernel plans (depth -5) of a stride-1 3x3x1 forward launch: those among its candidates when the autotuner listed them, else
         planner.march_plans' deterministic list (the untuned lowering then takes the first one)."""
-        got = [pl for pl in ch.cands if pl.depth == -5]
+        got = [pl for pl in ch.cands if P.is_march(pl)]
         if got or len(ch.cands) != 1:
             return got
         p0 = ch.cands[0]
@@ -505,7 +508,7 @@ class Plan:
             return f"sconv<bf16,{pl.nt}>"
         if pl.depth == -3:
             return f"cconv<bf16,{pl.nt}>"
-        if pl.depth == -5:
+        if P.is_march(pl):
             return f"mconv<bf16,{pl.nt}>"
         return f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"
 

@@ -196,13 +196,21 @@ def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPl
 MARCH_SHAPES = {(16, 1, 4, 2), (16, 1, 8, 4), (16, 2, 4, 2), (16, 2, 8, 4), (32, 1, 4, 2), (32, 2, 4, 2), (8, 1, 8, 4), (8, 2, 8, 4), (8, 1, 8, 8), (8, 2, 8, 8), (8, 1, 4, 8), (8, 2, 4, 8), (8, 1, 4, 4), (8, 2, 4, 4), (16, 1, 4, 8), (16, 1, 4, 4), (16, 2, 4, 8), (16, 2, 4, 4), (16, 2, 8, 8), (16, 1, 8, 8),
                 (32, 1, 2, 4), (32, 1, 4, 4), (32, 1, 2, 2), (32, 2, 4, 4), (32, 2, 2, 4), (32, 2, 2, 2), (32, 4, 4, 4), (32, 4, 2, 2), (32, 4, 4, 2),
                 (64, 2, 2, 2), (64, 2, 2, 1), (64, 1, 2, 2), (64, 1, 2, 1)}
+# ... of which these also exist with the packed weights in registers instead of LDS (depth -6; csrc/mconv.hip WREG, the MC_W entries)
+MARCH_WREG_SHAPES = {(16, 2, 4, 2), (16, 2, 8, 4), (32, 1, 4, 2), (32, 2, 4, 2), (32, 1, 2, 4), (32, 1, 4, 4), (32, 1, 2, 2), (32, 2, 4, 4), (32, 2, 2, 4), (32, 2, 2, 2), (32, 4, 2, 2), (32, 4, 4, 2),
+                     (64, 2, 2, 2), (64, 2, 2, 1), (64, 1, 2, 2), (64, 1, 2, 1)}
 MARCH_RING = 4
+MARCH_DEPTHS = (-5, -6)
 
 
-def march_lds_bytes(kc, nt, tz, mt):
+def is_march(pl) -> bool:
+    return pl.depth in MARCH_DEPTHS
+
+
+def march_lds_bytes(kc, nt, tz, mt, wreg=False):
     g = kc // 8
     rows = mt * 4 * (16 // tz) + 2
-    return ((9 * g + 3) // 4) * nt * 1024 + MARCH_RING * round_up(rows * tz * g * 16, 256) + 5 * nt * 16 * 4 + 16
+    return max((0 if wreg else ((9 * g + 3) // 4) * nt * 1024) + MARCH_RING * round_up(rows * tz * g * 16, 256) + 5 * nt * 16 * 4 + 16, 4 * 2 * nt * 16 * 4)
 
 
 def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmPlan"]:
@@ -225,6 +233,8 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
             pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (lx, tyb, tz), mt, nt, 1, kc, 1, (9 * (kc // 8) + 3) // 4, march_lds_bytes(kc, nt, tz, mt), -5)
             if not any(o.tile == pl.tile and o.mtw == pl.mtw for o in out):
                 out.append(pl)
+                if (c, t, tz, mt) in MARCH_WREG_SHAPES:  # the same launch with the packed weights in registers (LDS bandwidth back to the operand reads)
+                    out.append(dataclasses.replace(pl, depth=-6, lds=march_lds_bytes(kc, nt, tz, mt, True)))
     return out
 
 
