@@ -124,7 +124,7 @@ def roofline_table(full, peak, traffic):
     return rows
 
 
-CONV_GROUPS = ("igemm", "sconv", "cconv", "mconv", "wgrad", "mwgrad")
+CONV_GROUPS = ("igemm", "sconv", "cconv", "mconv", "wgrad", "mwgrad", "mbwd")
 
 
 def roofline_fractions(events, peak):

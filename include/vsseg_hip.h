@@ -133,6 +133,27 @@ typedef struct {
                             * tensor `att.repeat(C) * x + x` of AttentionBlock2 as the convolution input, never materialised) */
 } vsseg_wgrad_desc;
 
+/* Fused backward of one stride-1 3x3x1 Convolution block, Conv3d -> BatchNorm3d(train) -> Dropout -> PReLU (ref:params/networks/blocks/convolutions.py:114-156,
+ * differentiated by loss.backward() at ref:params/VSparams.py:461): the second BatchNorm-backward pass (what vsseg_bn_act_bwd_apply computes) is applied ON LOAD,
+ * and the data gradient and the weight gradient of the convolution are formed from the same LDS planes in ONE marching launch (csrc/mbwd.hip) — the
+ * gradient of the convolution output is never written to HBM.  Call after vsseg_bn_act_bwd_reduce + vsseg_bn_act_bwd_finalize of the layer.  bf16 only;
+ * outside its instantiated shapes the call fails with VSSEG_EINVAL (no fallback). */
+typedef struct {
+  vsseg_tensor y, dout;    /* convolution output before BatchNorm, gradient of the block output: [N][X][Y][Z][cout] */
+  vsseg_tensor x;          /* convolution input [N][X][Y][Z][cin] */
+  vsseg_tensor dx;         /* OUT: data gradient of x (overwritten) */
+  const float *mean, *invstd, *gamma, *scale, *shift, *alpha; /* as for vsseg_bn_act_bwd_apply */
+  const float *mean_dz, *mean_dzx;
+  float p_drop;
+  const uint8_t* keep;     /* keep-mask bytes written by vsseg_bn_act_fwd (required when p_drop > 0) */
+  const void* wpack;       /* packed weights of the data gradient: [ksteps][nt][64 lanes][8] bf16 of the marching conv_dgrad plan (K = 9 * cout -> N = cin) */
+  float* dw;               /* IN/OUT: weight gradient [cout][cin][3][3][1] fp32, += */
+  int32_t tile[3];         /* (x steps per workgroup, rows per workgroup, z slices per workgroup in {2, 4, 8}); rows * z a multiple of 64 */
+  float* scratch;          /* partial-sum slabs: (cout/16) * 9 * cin * 16 floats per workgroup */
+  int64_t scratch_elems;
+} vsseg_conv_bwd_desc;
+int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
+
 const char* vsseg_last_error(void);
 int vsseg_version(void); /* 2: fixed-point accumulators documented + vsseg_fx_status (1: the buffers below were described as plain doubles) */
 

@@ -663,6 +663,97 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
                 np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+FUSED_BWD_CASES = [
+    # cin, cout, dims, (x steps, rows, tz) of the fused launch
+    (16, 16, (10, 64, 16), (4, 32, 8)),   # level-0 unit: two row blocks, two z blocks, three x segments (4 + 4 + 2)
+    (16, 16, (5, 128, 4), (5, 64, 4)),
+    (16, 16, (6, 32, 8), (3, 32, 4)),
+    (16, 32, (7, 64, 8), (4, 64, 4)),     # level-1 unit0: 32-channel dy ring, 16-channel x
+    (16, 32, (4, 32, 16), (4, 32, 8)),
+    (32, 32, (6, 64, 8), (3, 32, 4)),     # waves split the (tap, tile) units of the weight gradient
+    (32, 32, (5, 64, 4), (5, 64, 2)),
+    (64, 32, (4, 32, 4), (4, 32, 2)),     # level-1 decoder unit: 64-channel x
+]
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("cin,cout,dims,tile", FUSED_BWD_CASES)
+def test_fused_conv_backward_equals_separate_launches(cin, cout, dims, tile, p_drop):
+    """vsseg_conv_bwd_fused (csrc/mbwd.hip): BatchNorm/dropout/PReLU backward applied on load + data gradient + weight gradient of a stride-1 3x3x1
+    Convolution block in one marching launch, against the three launches it replaces on the same operands — vsseg_bn_act_bwd_apply writing dy, the
+    data-gradient launch and the weight-gradient launch reading it.  The data gradient must be IDENTICAL bit for bit (same dy values, same packed
+    weights, K order and MFMA order); the weight gradient sums the same products in another order (operand roles swapped) and must agree to fp32
+    rounding; both are also checked against the fp64 definition."""
+    lib = L.lib()
+    k, n = (3, 3, 1), 2
+    torch.manual_seed(21)
+    S = H.stream()
+    y = _round(torch.randn(n, cout, *dims) * 1.3 + 0.2, "bf16")
+    da = _round(torch.randn(n, cout, *dims), "bf16")
+    x = _round(torch.randn(n, cin, *dims), "bf16")
+    w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, "bf16")
+    ycl, dcl, xcl = H.to_cl(y, torch.bfloat16), H.to_cl(da, torch.bfloat16), H.to_cl(x, torch.bfloat16)
+    nvox = n * int(np.prod(dims))
+    vec = torch.zeros(6, cout, device="cuda")
+    vec[0] = torch.randn(cout) * 0.2 + 0.2      # mean
+    vec[1] = torch.rand(cout) + 0.5             # invstd
+    gam, bet, al = (torch.rand(cout) + 0.5).cuda(), (torch.randn(cout) * 0.1).cuda(), torch.tensor([0.25], device="cuda")
+    vec[2] = gam * vec[1]                       # scale, shift of the folded forward affine
+    vec[3] = bet - vec[0] * vec[2]
+    vec[4] = torch.randn(cout) * 0.05           # mean(dz), mean(dz * xhat)
+    vec[5] = torch.randn(cout) * 0.05
+    keep = None
+    if p_drop > 0:  # the forward's stored keep-mask bytes
+        keep = torch.zeros(nvox * cout // 8, dtype=torch.uint8, device="cuda")
+        scratch_out = torch.zeros_like(ycl)
+        L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x77AA, 5, L.Tensor(), 0, H.tdesc(scratch_out), keep.data_ptr(), S))
+    kptr = keep.data_ptr() if keep is not None else None
+    # ---- the three separate launches
+    dy = torch.zeros_like(ycl)
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(dcl), vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), bet.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x77AA, 5,
+                                       vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), kptr, S))
+    cls = P.lattice_classes("conv_dgrad", k, (1, 1, 1))[0]
+    gen = P.plan_igemm("conv_dgrad", tuple(w.shape), cls, dims, 2, kc_pad=cout, aux_es=0)
+    gen.pack_map = P.pack_map(gen, tuple(w.shape))
+    dx_ref = torch.zeros(n, *dims, cin, dtype=torch.bfloat16, device="cuda")
+    wp_gen = H.pack(gen, w, torch.bfloat16)
+    d = H.igemm_desc(gen, wp_gen, H.tdesc(dy), H.tdesc(dx_ref))
+    L.check(lib.vsseg_igemm(C.byref(d), S), "igemm dgrad")
+    dw_ref = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), dy, xcl, cout, cin)
+    # ---- the fused launch
+    mps = P.march_plans("conv_dgrad", tuple(w.shape), cls, dims, 2, cout, cin, cout, n=n)
+    assert mps, "no marching data-gradient plan (packed-weight layout) for this shape"
+    mp = mps[0]
+    mp.pack_map = P.pack_map(mp, tuple(w.shape))
+    wp = H.pack(mp, w, torch.bfloat16)
+    dx = torch.full((n, *dims, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(cout * cin * 9, dtype=torch.float32, device="cuda")
+    scr = torch.zeros(16 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    fd = L.ConvBwdDesc()
+    fd.y, fd.dout, fd.x, fd.dx = H.tdesc(ycl), H.tdesc(dcl), H.tdesc(xcl), H.tdesc(dx)
+    fd.mean, fd.invstd, fd.gamma, fd.scale, fd.shift, fd.alpha = vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr()
+    fd.mean_dz, fd.mean_dzx, fd.p_drop, fd.keep = vec[4].data_ptr(), vec[5].data_ptr(), p_drop, kptr
+    fd.wpack, fd.dw, fd.tile = wp.data_ptr(), dw.data_ptr(), L.i3(tile)
+    fd.scratch, fd.scratch_elems = scr.data_ptr(), scr.numel()
+    L.check(lib.vsseg_conv_bwd_fused(C.byref(fd), S), "conv_bwd_fused")
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref), f"data gradient differs from the separate launches: max {float((dx.float() - dx_ref.float()).abs().max())}"
+    dwf = dw.cpu().reshape(w.shape)
+    np.testing.assert_allclose(dwf.numpy(), dw_ref.numpy(), rtol=2e-4, atol=2e-4 * float(dw_ref.abs().max()))
+    # ---- fp64 definition on the bf16 dy the separate pass produced
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    F.conv3d(xd, wd, None, padding=P.same_pad(k)).backward(H.from_cl(dy).double())
+    np.testing.assert_allclose(H.from_cl(dx).numpy(), xd.grad.float().numpy(), atol=_tol("bf16", xd.grad))
+    np.testing.assert_allclose(dwf.numpy(), wd.grad.float().numpy(), rtol=1e-3, atol=1e-3 * float(wd.grad.abs().max()))
+    # the second call accumulates into dw (+=), and a shape outside the table is refused loudly
+    L.check(lib.vsseg_conv_bwd_fused(C.byref(fd), S), "conv_bwd_fused")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().reshape(w.shape).numpy(), 2 * dwf.numpy(), rtol=1e-5, atol=1e-6)
+    fd.tile = L.i3((tile[0], tile[1], 3))
+    assert lib.vsseg_conv_bwd_fused(C.byref(fd), S) == L.EINVAL and b"not applicable" in lib.vsseg_last_error()
+
+
 @pytest.mark.parametrize("dims,split,shape,lx", [((7, 128, 4), 16, (2, 4), 3), ((6, 64, 8), 16, (4, 4), 6), ((5, 64, 8), 0, (4, 2), 2)])
 def test_attention_gate_on_load_equals_materialised_gate(dims, split, shape, lx):
     """in_gate / h_gate: the marching convolution and the marching weight gradient multiply the input voxels by (1 + att) in LDS (AttentionBlock2,

@@ -44,12 +44,15 @@ def test_plans_lower_on_cpu(att, dt):
     # the merged residual conv has none and the 1-channel attention map convolutions run on the narrow kernel
     assert n_conv - 2 <= len(igemms) <= n_conv
     assert sum(1 for r in igemms if r[1][0]._obj.class_split == 8) == 3 and sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_igemm and r[1][0]._obj.class_split == 8) == 3
-    assert sum(1 for r in tr.bwd if r[0] in (eng.lib.vsseg_wgrad, eng.lib.vsseg_wgrad_narrow)) == n_conv - len(tr.merged)  # the final 1x1x1 residual conv is merged into the final 3x3x1 conv
+    # (bf16: the stride-1 3x3x1 blocks of the finest levels run BatchNorm-backward apply + data gradient + weight gradient as ONE launch, csrc/mbwd.hip)
+    n_fused = sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_conv_bwd_fused)
+    assert (n_fused >= 1) == (dt == "bf16")
+    assert sum(1 for r in tr.bwd if r[0] in (eng.lib.vsseg_wgrad, eng.lib.vsseg_wgrad_narrow)) + n_fused == n_conv - len(tr.merged)  # the final 1x1x1 residual conv is merged into the final 3x3x1 conv
     assert len(tr.merged) == 1 and sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_merge_residual_grads) == 1
     assert len(ev.bwd) == 0 and len(ev.fwd) < len(tr.fwd)
     # every dropout launch reads the seed through the plan's device scalar (fixed arguments: the lists can be captured as hipGraphs)
     seeded = [r for lst in (tr.fwd, tr.bwd) for r in lst if tr.seed_dev.data_ptr() in [a for a in r[1] if isinstance(a, int)]]
-    assert len(seeded) == 3 * sum(1 for L_ in prog.layers if L_.has_bn) and len(tr.bwd_pre) == 1 and len(tr.ext_slots) == 1
+    assert len(seeded) == 3 * sum(1 for L_ in prog.layers if L_.has_bn) - n_fused and len(tr.bwd_pre) == 1 and len(tr.ext_slots) == 1  # (a fused launch reads the stored keep-mask: no seed)
     # the LDS request the C side computes equals the planner's (mirrored formula)
     for rec in igemms[:10]:
         d = rec[1][0]._obj

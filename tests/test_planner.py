@@ -234,7 +234,9 @@ def test_march_plans_cover_the_benchmark_layers_and_mirror_the_kernel_lds():
             lx, tyb, tz = pl.tile
             assert pl.depth in (-5, -6) and tyb == 64 * pl.mtw // tz and dims[1] % tyb == 0 and dims[2] % tz == 0 and 1 <= lx <= dims[0]
             g = cin // 8
-            assert pl.lds == ((9 * g + 3) // 4) * pl.nt * 1024 + 4 * (tyb + 2) * tz * g * 16 + 5 * pl.nt * 16 * 4 + 16 <= 160 * 1024
+            wbytes = 0 if pl.depth == -6 else ((9 * g + 3) // 4) * pl.nt * 1024  # depth -6: the packed weights live in registers
+            assert pl.lds == wbytes + 4 * (tyb + 2) * tz * g * 16 + 5 * pl.nt * 16 * 4 + 16 <= 160 * 1024
+            assert pl.depth == -5 or (cin, pl.nt, tz, pl.mtw) in P.MARCH_WREG_SHAPES
             assert pl.ksteps == (9 * g + 3) // 4 and pl.nchunks == 1 and pl.ck == cin
     # outside the domain: strided, 3x3x3, fp32
     assert P.march_plans("conv_fwd", (16, 16, 3, 3, 1), P.lattice_classes("conv_fwd", (3, 3, 1), (2, 2, 1))[0], (192, 64, 128), 2, 16, 16, 16) == []

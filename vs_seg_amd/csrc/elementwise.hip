@@ -6,6 +6,7 @@
 #define VSSEG_NT_STORES
 #define VSSEG_NT_LOADS
 #include "common.h"
+#include "bn_bwd.h"
 #include <algorithm>
 #include <type_traits>
 
@@ -482,28 +483,14 @@ __global__ void bn_act_bwd_apply_kernel(const T* __restrict__ y, int yp, const T
   const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
   const int cg = (int)(gt % cgs), c = cg * 8;
   const int64_t vstep = nthreads / cgs;
-  float mean[8], istd[8], sc[8], sh[8], k1[8], mdz[8], mdzx[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    mean[j] = a.mean[c + j]; istd[j] = a.invstd[c + j]; sc[j] = a.scale[c + j]; sh[j] = a.shift[c + j];
-    k1[j] = a.gamma[c + j] * a.invstd[c + j]; mdz[j] = mean_dz[c + j]; mdzx[j] = mean_dzx[c + j];
-  }
   const float alpha = *a.alpha, inv_keep = 1.f / (1.f - a.p_drop);
+  BnBwdC8 k;  // the arithmetic is bn_bwd.h's: the fused data + weight gradient kernel (mbwd.hip) forms the same values on load
+  bn_bwd_consts(k, a.mean, a.invstd, a.gamma, a.scale, a.shift, mean_dz, mean_dzx, c, inv_keep);
   const bool drop = a.p_drop > 0.f;
   if (drop && keep_in == nullptr) dropout_resolve_seed(a.seed, a.salt);
   auto one = [&](const f8& yy, const f8& da, unsigned keep, int64_t v) {
     f8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xhat = (yy.v[j] - mean[j]) * istd[j];
-      const float z = yy.v[j] * sc[j] + sh[j];  // bit-identical to the forward's value: same side of the PReLU kink
-      const bool k = (keep >> j) & 1u;
-      const float d = k ? z * inv_keep : 0.f;
-      const float g = da.v[j];
-      const float dd = d > 0.f ? g : alpha * g;
-      const float dz = k ? dd * inv_keep : 0.f;
-      o.v[j] = k1[j] * (dz - mdz[j] - xhat * mdzx[j]);
-    }
+    bn_bwd_dy8(yy, da, keep, alpha, k, o);
     st8(dy + v * dyp + c, o);
   };
   // mask source decided once, outside the loop (0 no dropout, 1 stored bytes, 2 Philox): see bn_act_bwd_reduce_kernel

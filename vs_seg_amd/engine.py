@@ -831,6 +831,74 @@ class Plan:
                 for ch in cp.dgrad:
                     self._igemm(B, ch, dy_compact if ch.fold else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
+        def fused_backward(op: ConvBnAct, yd: L.Tensor, dA: L.Tensor) -> bool:
+            """The layer's vsseg_bn_act_bwd_apply + data gradient + weight gradient as ONE marching launch (csrc/mbwd.hip), where it is instantiated and this
+            data gradient is the first contribution to d(x) (the launch overwrites): dy is then never written.  Returns False when the layer is not eligible."""
+            Lr, pre = op.layer, op.layer.prefix
+            x = op.x
+            want = eng.fused_bwd
+            if (want == "0" or eng.es != 2 or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or x.parts is not None or x.base is not None or x.kind != "act"
+                    or x.root.name == prog.input.name or x.c != Lr.cin or x.name in self.gate_onload or dA.ptr2 or (p_drop > 0.0 and keep_ptr(Lr) is None)):
+                return False
+            if want != "1" and f"{Lr.cin}x{Lr.cout}" not in want.split(","):
+                return False
+            scr = self.eng.wgrad_scratch()
+            tiles = P.fused_bwd_tiles(Lr.cout, Lr.cin, self.lv[Lr.level], self.n, scr.numel())
+            cls = P.lattice_classes("conv_dgrad", Lr.kernel, Lr.stride)[0]
+            mps = P.march_plans("conv_dgrad", Lr.wshape, cls, self.lv[Lr.level], eng.es, Lr.cout, Lr.cin, Lr.cout, self.n)  # (the packed-weight layout of the data gradient)
+            if not tiles or not mps or written.get(x.root.name):
+                return False
+            assert contribution(x) == 0
+            mp = mps[0]
+            mp.pack_map = P.pack_map(mp, Lr.wshape)
+            ch = _Choice([mp], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape))
+            self._register(ch, mp)
+            d = L.ConvBwdDesc()
+            d.y, d.dout, d.x, d.dx = yd, dA, self._desc(x), gdesc(x)
+            d.mean, d.invstd, d.gamma, d.scale, d.shift, d.alpha = vptr(0, pre), vptr(1, pre), self._pp(pre + ".norm.weight"), vptr(2, pre), vptr(3, pre), self._pp(pre + ".act.weight")
+            d.mean_dz, d.mean_dzx, d.p_drop, d.keep = vptr(4, pre), vptr(5, pre), p_drop, keep_ptr(Lr)
+            d.dw = self._gp(Lr.wkey)
+            d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
+            self._wpack_fixups.append((d, ch.map_off))
+            self.keep.append(d)
+            tile, tuned = tiles[0], ""
+            if self.tune and len(tiles) > 1:
+                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}"
+                cache = _tune_cache()
+                if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+                    tile, tuned = tuple(cache[key]), " tuned[cache]"
+                else:  # measured on the real buffers; the weight gradient accumulates into a scratch copy of the gradient buffer
+                    stream = torch.cuda.current_stream().cuda_stream
+                    if getattr(self, "_tune_gflat", None) is None:
+                        self._tune_gflat = torch.zeros_like(self.eng.gflat)
+                    wp = torch.zeros(mp.pack_map.size, dtype=eng.tdtype, device=eng.device)
+                    d.dw, d.wpack = d.dw + self._tune_gflat.data_ptr() - self.eng.gflat.data_ptr(), wp.data_ptr()
+                    ms = {}
+                    for t in tiles:
+                        d.tile = L.i3(t)
+                        if lib.vsseg_conv_bwd_fused(C.byref(d), stream):
+                            ms[t] = float("inf")
+                            continue
+                        best = float("inf")
+                        for _ in range(self.eng.tune_reps):
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                            lib.vsseg_conv_bwd_fused(C.byref(d), stream)
+                            e1.record()
+                            e1.synchronize()
+                            best = min(best, e0.elapsed_time(e1))
+                        ms[t] = best
+                    d.dw = self._gp(Lr.wkey)
+                    tile = min(ms, key=ms.get)
+                    cache[key] = list(tile)
+                    _tune_cache.dirty = True
+                    tuned = f" tuned[best of {len(ms)}: {ms[tile]:.3f} ms]"
+            d.tile = L.i3(tile)
+            nq = float(self._vox(Lr.level))
+            B.append([lib.vsseg_conv_bwd_fused, [C.byref(d)], dict(tag=f"{pre[-40:]} q={self.lv[Lr.level]} cin={Lr.cin} cout={Lr.cout} tile={tuple(tile)}{tuned}", name=f"mbwd<bf16,{Lr.cout // 16},{Lr.cin // 16}>", kind="mfma",
+                                                                  flops=2.0 * 2.0 * nq * 9 * Lr.cin * Lr.cout, bytes=eng.es * nq * (2 * Lr.cout + 2 * Lr.cin) + nq * Lr.cout / 8)])
+            return True
+
         gate_fuse: Dict[str, tuple] = {}  # relu-conv prefix -> (d(gated) descriptor, attention map pointer) of the gate fused into its data gradient
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
@@ -849,9 +917,11 @@ class Plan:
                     folded_bias.add(producer[op.res.name].layer.prefix)
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
-                dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd, keep_ptr(Lr)],
-                          self._ew_meta("bn_act_bwd_apply", Lr.out_level, 3 * Lr.cout)])
+                fused = (op.res is None or op.res.name.endswith(":res")) and fused_backward(op, yd, dA)  # (an identity residual re-uses dA's buffer below: keep those unfused)
+                if not fused:
+                    dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
+                    B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd, keep_ptr(Lr)],
+                              self._ew_meta("bn_act_bwd_apply", Lr.out_level, 3 * Lr.cout)])
                 if op.res is not None and not op.res.name.endswith(":res"):  # identity residual: d(res) += d(out)
                     r, o = op.res, grad_alias.get(op.out.name, op.out)
                     if (r.parts is None and r.base is None and o.parts is None and o.base is None and r.kind == o.kind == "act" and (r.level, r.c) == (o.level, o.c)
@@ -864,7 +934,8 @@ class Plan:
                         B.append([lib.vsseg_add_inplace, [gdesc(op.res), dA], self._ew_meta("grad_add/copy", Lr.out_level, 3 * Lr.cout)])
                     else:
                         B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)], self._ew_meta("grad_add/copy", Lr.out_level, 2 * Lr.cout)])
-                conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
+                if not fused:
+                    conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
             elif isinstance(op, ConvPlain):
                 Lr = op.layer
                 if Lr.prefix in self.merged:  # gradients of a merged residual conv = centre-tap slice / bias gradient of the absorbing conv
@@ -1042,6 +1113,9 @@ class Engine:
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
+        # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip): "0" = off, "1" = every
+        # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
+        self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched

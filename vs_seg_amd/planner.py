@@ -263,6 +263,31 @@ def march_wgrad_tiles(ch, cp, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tupl
     return out
 
 
+# (channels of y / dA = conv outputs, channels of x = conv inputs, TZ, M-tiles per wave) instantiated by csrc/mbwd.hip (vsseg_conv_bwd_fused)
+FUSED_BWD_SHAPES = {(16, 16, 8, 4), (16, 16, 4, 4), (16, 16, 4, 2), (16, 16, 8, 8), (32, 16, 4, 4), (32, 16, 4, 2), (32, 16, 8, 4), (32, 32, 4, 4), (32, 32, 4, 2), (32, 32, 2, 2),
+                    (32, 64, 4, 2), (32, 64, 2, 2), (32, 64, 2, 1)}
+
+
+def fused_bwd_tiles(cout, cin, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tuple[int, int, int]]:
+    """Candidate tiles (x steps per workgroup, rows, z slices) of the fused BatchNorm-backward + data gradient + weight gradient launch of a stride-1 3x3x1
+    convolution block (csrc/mbwd.hip): about 512 / 1024 / 2048 workgroups, each with its own weight-gradient slab."""
+    out = []
+    per_blk = (cout // 16) * 9 * (cin // 16) * 256
+    for (cy, cx, tz, mt) in sorted(FUSED_BWD_SHAPES):
+        tyb = 64 * mt // tz
+        if cy != cout or cx != cin or q[1] % tyb or q[2] % tz:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024, 2048):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            grid = cols * -(-q[0] // lx)
+            if grid * per_blk > scratch_elems or grid > 4096 or (lx, tyb, tz) in out:
+                continue
+            out.append((lx, tyb, tz))
+    return out
+
+
 # ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
 def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Optional[List["IgemmPlan"]]:
     """The output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient fused into streaming-kernel launches: a
