@@ -149,8 +149,13 @@ typedef struct {
   const void* wpack;       /* packed weights of the data gradient: [ksteps][nt][64 lanes][8] bf16 of the marching conv_dgrad plan (K = 9 * cout -> N = cin) */
   float* dw;               /* IN/OUT: weight gradient [cout][cin][3][3][1] fp32, += */
   int32_t tile[3];         /* (x steps per workgroup, rows per workgroup, z slices per workgroup in {2, 4, 8}); rows * z a multiple of 64 */
-  float* scratch;          /* partial-sum slabs: (cout/16) * 9 * cin * 16 floats per workgroup */
+  float* scratch;          /* partial-sum slabs: (cout/16) * (9, or 10 with a residual convolution) * cin * 16 floats per workgroup */
   int64_t scratch_elems;
+  /* Optional: the ResidualUnit's 1x1x1 residual convolution of the SAME input x (ref:params/networks/blocks/convolutions.py:241-255) rides along: dx also gets
+   * Wr' dres, dw_res[cout][cin] += sum_q dres[q] x[q].  dres.ptr == NULL: no residual convolution.  dres may be the tensor `dout` itself (single-subunit units). */
+  vsseg_tensor dres;       /* gradient of the residual convolution's output [N][X][Y][Z][cout] */
+  const void* wpack_res;   /* packed weights of its data gradient: [ksteps][nt][64][8] bf16 of the conv_dgrad plan of the 1x1x1 convolution (K = cout -> N = cin, one chunk) */
+  float* dw_res;           /* IN/OUT: its weight gradient [cout][cin] fp32, += */
 } vsseg_conv_bwd_desc;
 int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
 

@@ -754,6 +754,68 @@ def test_fused_conv_backward_equals_separate_launches(cin, cout, dims, tile, p_d
     assert lib.vsseg_conv_bwd_fused(C.byref(fd), S) == L.EINVAL and b"not applicable" in lib.vsseg_last_error()
 
 
+@pytest.mark.parametrize("same", [True, False])
+@pytest.mark.parametrize("cin,cout,dims,tile", [(16, 32, (7, 64, 8), (4, 64, 4)), (16, 32, (9, 32, 16), (4, 32, 4)), (64, 32, (6, 32, 8), (3, 32, 4)), (64, 32, (5, 64, 4), (5, 64, 2)), (64, 32, (4, 32, 4), (4, 32, 2))])
+def test_fused_conv_backward_with_residual_convolution(cin, cout, dims, tile, same):
+    """vsseg_conv_bwd_fused with the ResidualUnit's 1x1x1 residual convolution riding along (ref:params/networks/blocks/convolutions.py:241-255): dx = conv3x3'(dy) + conv1x1'(dres)
+    in one store, dw_res = sum dres x.  `same`: dres is the tensor dout itself (single-subunit decoder units) or another tensor (encoder units).  Against the
+    fp64 definition (the separate launches round dx to bf16 between the two terms, the fused one does not) and against the separate weight-gradient launches."""
+    lib = L.lib()
+    k, n, p_drop = (3, 3, 1), 2, 0.1
+    torch.manual_seed(23)
+    S = H.stream()
+    y = _round(torch.randn(n, cout, *dims) * 1.3 + 0.2, "bf16")
+    da = _round(torch.randn(n, cout, *dims), "bf16")
+    dr = da if same else _round(torch.randn(n, cout, *dims), "bf16")
+    x = _round(torch.randn(n, cin, *dims), "bf16")
+    w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, "bf16")
+    wr = _round(torch.randn(cout, cin, 1, 1, 1) / cin ** 0.5, "bf16")
+    ycl, dcl, xcl = H.to_cl(y, torch.bfloat16), H.to_cl(da, torch.bfloat16), H.to_cl(x, torch.bfloat16)
+    rcl = dcl if same else H.to_cl(dr, torch.bfloat16)
+    nvox = n * int(np.prod(dims))
+    vec = torch.zeros(6, cout, device="cuda")
+    vec[0], vec[1] = torch.randn(cout) * 0.2 + 0.2, torch.rand(cout) + 0.5
+    gam, bet, al = (torch.rand(cout) + 0.5).cuda(), (torch.randn(cout) * 0.1).cuda(), torch.tensor([0.25], device="cuda")
+    vec[2] = gam * vec[1]
+    vec[3] = bet - vec[0] * vec[2]
+    vec[4], vec[5] = torch.randn(cout) * 0.05, torch.randn(cout) * 0.05
+    keep = torch.zeros(nvox * cout // 8, dtype=torch.uint8, device="cuda")
+    L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x77AA, 5, L.Tensor(), 0, H.tdesc(torch.zeros_like(ycl)), keep.data_ptr(), S))
+    dy = torch.zeros_like(ycl)
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(dcl), vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), bet.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x77AA, 5,
+                                       vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), keep.data_ptr(), S))
+    dw_ref = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), dy, xcl, cout, cin)
+    dwr_ref = H.run_wgrad(False, tuple(wr.shape), (1, 1, 1), (1, 1, 1), rcl, xcl, cout, cin)
+    cls = P.lattice_classes("conv_dgrad", k, (1, 1, 1))[0]
+    mp = P.march_plans("conv_dgrad", tuple(w.shape), cls, dims, 2, cout, cin, cout, n=n)[0]
+    mp.pack_map = P.pack_map(mp, tuple(w.shape))
+    rp = P.residual_dgrad_pack_plan(tuple(wr.shape), dims)
+    wp, wpr = H.pack(mp, w, torch.bfloat16), H.pack(rp, wr, torch.bfloat16)
+    dx = torch.full((n, *dims, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dw = torch.zeros(cout * cin * 9, dtype=torch.float32, device="cuda")
+    dwr = torch.zeros(cout * cin, dtype=torch.float32, device="cuda")
+    scr = torch.zeros(16 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    fd = L.ConvBwdDesc()
+    fd.y, fd.dout, fd.x, fd.dx, fd.dres = H.tdesc(ycl), H.tdesc(dcl), H.tdesc(xcl), H.tdesc(dx), H.tdesc(rcl)
+    fd.mean, fd.invstd, fd.gamma, fd.scale, fd.shift, fd.alpha = vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr()
+    fd.mean_dz, fd.mean_dzx, fd.p_drop, fd.keep = vec[4].data_ptr(), vec[5].data_ptr(), p_drop, keep.data_ptr()
+    fd.wpack, fd.dw, fd.tile, fd.wpack_res, fd.dw_res = wp.data_ptr(), dw.data_ptr(), L.i3(tile), wpr.data_ptr(), dwr.data_ptr()
+    fd.scratch, fd.scratch_elems = scr.data_ptr(), scr.numel()
+    L.check(lib.vsseg_conv_bwd_fused(C.byref(fd), S), "conv_bwd_fused")
+    torch.cuda.synchronize()
+    xd = x.double().requires_grad_(True)
+    wd, wrd = w.double().requires_grad_(True), wr.double().requires_grad_(True)
+    F.conv3d(xd, wd, None, padding=P.same_pad(k)).backward(H.from_cl(dy).double(), retain_graph=False)
+    g3 = xd.grad.clone()
+    xd.grad = None
+    F.conv3d(xd, wrd, None).backward(H.from_cl(rcl).double())
+    want = g3 + xd.grad
+    np.testing.assert_allclose(H.from_cl(dx).numpy(), want.float().numpy(), atol=_tol("bf16", want))
+    np.testing.assert_allclose(dw.cpu().reshape(w.shape).numpy(), dw_ref.numpy(), rtol=2e-4, atol=2e-4 * float(dw_ref.abs().max()))
+    np.testing.assert_allclose(dwr.cpu().reshape(wr.shape).numpy(), dwr_ref.numpy(), rtol=2e-4, atol=2e-4 * float(dwr_ref.abs().max()))
+    np.testing.assert_allclose(dwr.cpu().reshape(wr.shape).numpy(), wrd.grad.float().numpy(), rtol=1e-3, atol=1e-3 * float(wrd.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dims,split,shape,lx", [((7, 128, 4), 16, (2, 4), 3), ((6, 64, 8), 16, (4, 4), 6), ((5, 64, 8), 0, (4, 2), 2)])
 def test_attention_gate_on_load_equals_materialised_gate(dims, split, shape, lx):
     """in_gate / h_gate: the marching convolution and the marching weight gradient multiply the input voxels by (1 + att) in LDS (AttentionBlock2,

@@ -125,6 +125,9 @@ class ConvBwdDesc(C.Structure):
         ("tile", C.c_int32 * 3),
         ("scratch", C.c_void_p),
         ("scratch_elems", C.c_int64),
+        ("dres", Tensor),
+        ("wpack_res", C.c_void_p),
+        ("dw_res", C.c_void_p),
     ]
 
 

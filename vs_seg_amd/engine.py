@@ -205,6 +205,7 @@ class Plan:
         self._maps2: List[np.ndarray] = []
         self._map_len = 0
         self._wpack_fixups: list = []  # (descriptor, element offset): wpack is allocated after every launch chose its plan
+        self._res_fixups: list = []  # ... the same for the `wpack_res` field of the fused backward launches
         # Autotune (default on a GPU): every launch measures its candidate plans on the real buffers at lowering time and keeps
         # the fastest.  VSSEG_AUTOTUNE=0 keeps the heuristic plan (deterministic; what the CPU dry-run lowering always uses).
         self.tune = (not eng.dry_run) and os.environ.get("VSSEG_AUTOTUNE", "1") != "0"
@@ -300,7 +301,9 @@ class Plan:
         self.wpack = torch.zeros(self._map_len, dtype=eng.tdtype, device=eng.device)
         for d, off in self._wpack_fixups:
             d.wpack = self.wpack.data_ptr() + eng.es * off
-        del self._maps, self._maps2, self._wpack_fixups
+        for d, off in self._res_fixups:
+            d.wpack_res = self.wpack.data_ptr() + eng.es * off
+        del self._maps, self._maps2, self._wpack_fixups, self._res_fixups
         self._tune_gflat = None
         _tune_cache_save()
 
@@ -843,7 +846,18 @@ class Plan:
             if want != "1" and f"{Lr.cin}x{Lr.cout}" not in want.split(","):
                 return False
             scr = self.eng.wgrad_scratch()
-            tiles = P.fused_bwd_tiles(Lr.cout, Lr.cin, self.lv[Lr.level], self.n, scr.numel())
+            # The ResidualUnit's 1x1x1 residual convolution of the same input (ref:params/networks/blocks/convolutions.py:241-255) rides along: its output gradient is
+            # the gradient of the tensor it is added into — this block's own dA (single-subunit decoder units) or the unit's output gradient (encoder units, where
+            # the add sits behind the second convolution; complete long before this launch).  Its own data- and weight-gradient launches are then skipped.
+            rc = next((o for o in ops if isinstance(o, ConvPlain) and o.x is x and o.layer.kernel == (1, 1, 1) and o.layer.prefix.endswith(".residual") and o.layer.cout == Lr.cout
+                       and o.layer.prefix not in self.merged and o.act == "none" and o.res is None), None)
+            sink = next((o for o in ops if rc is not None and isinstance(o, ConvBnAct) and o.res is rc.out), None)
+            dres = None
+            if eng.fused_bwd_res and rc is not None and sink is not None and (Lr.cout == 32 or Lr.cin > Lr.cout) and rc.layer.prefix in folded_bias:
+                dres = dA if sink is op else grad_of_out(sink.out)
+                if dres.ptr2 or dres.dtype != L.BF16 or dres.c != Lr.cout or not P.fused_bwd_tiles(Lr.cout, Lr.cin, self.lv[Lr.level], self.n, scr.numel(), res=True):
+                    dres = None
+            tiles = P.fused_bwd_tiles(Lr.cout, Lr.cin, self.lv[Lr.level], self.n, scr.numel(), res=dres is not None)
             cls = P.lattice_classes("conv_dgrad", Lr.kernel, Lr.stride)[0]
             mps = P.march_plans("conv_dgrad", Lr.wshape, cls, self.lv[Lr.level], eng.es, Lr.cout, Lr.cin, Lr.cout, self.n)  # (the packed-weight layout of the data gradient)
             if not tiles or not mps or written.get(x.root.name):
@@ -861,9 +875,18 @@ class Plan:
             d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
             self._wpack_fixups.append((d, ch.map_off))
             self.keep.append(d)
+            res_tag = ""
+            if dres is not None:
+                rp = P.residual_dgrad_pack_plan(rc.layer.wshape, self.lv[Lr.level])
+                rch = _Choice([rp], eng.layout.param_off[rc.layer.wkey][0], wshape=tuple(rc.layer.wshape))
+                self._register(rch, rp)
+                d.dres, d.dw_res = dres, self._gp(rc.layer.wkey)
+                self._res_fixups.append((d, rch.map_off))
+                absorbed_res.add(rc.layer.prefix)
+                res_tag = f" +res[{'dA' if sink is op else 'unit dA'}]"
             tile, tuned = tiles[0], ""
             if self.tune and len(tiles) > 1:
-                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}"
+                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}" + ("|res" if res_tag else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     tile, tuned = tuple(cache[key]), " tuned[cache]"
@@ -871,8 +894,11 @@ class Plan:
                     stream = torch.cuda.current_stream().cuda_stream
                     if getattr(self, "_tune_gflat", None) is None:
                         self._tune_gflat = torch.zeros_like(self.eng.gflat)
-                    wp = torch.zeros(mp.pack_map.size, dtype=eng.tdtype, device=eng.device)
-                    d.dw, d.wpack = d.dw + self._tune_gflat.data_ptr() - self.eng.gflat.data_ptr(), wp.data_ptr()
+                    wp = torch.zeros(mp.pack_map.size + 8192, dtype=eng.tdtype, device=eng.device)
+                    delta = self._tune_gflat.data_ptr() - self.eng.gflat.data_ptr()
+                    d.dw, d.wpack = d.dw + delta, wp.data_ptr()
+                    if res_tag:
+                        d.dw_res, d.wpack_res = d.dw_res + delta, wp.data_ptr() + eng.es * mp.pack_map.size
                     ms = {}
                     for t in tiles:
                         d.tile = L.i3(t)
@@ -889,16 +915,20 @@ class Plan:
                             best = min(best, e0.elapsed_time(e1))
                         ms[t] = best
                     d.dw = self._gp(Lr.wkey)
+                    if res_tag:
+                        d.dw_res = self._gp(rc.layer.wkey)
                     tile = min(ms, key=ms.get)
                     cache[key] = list(tile)
                     _tune_cache.dirty = True
                     tuned = f" tuned[best of {len(ms)}: {ms[tile]:.3f} ms]"
             d.tile = L.i3(tile)
             nq = float(self._vox(Lr.level))
-            B.append([lib.vsseg_conv_bwd_fused, [C.byref(d)], dict(tag=f"{pre[-40:]} q={self.lv[Lr.level]} cin={Lr.cin} cout={Lr.cout} tile={tuple(tile)}{tuned}", name=f"mbwd<bf16,{Lr.cout // 16},{Lr.cin // 16}>", kind="mfma",
-                                                                  flops=2.0 * 2.0 * nq * 9 * Lr.cin * Lr.cout, bytes=eng.es * nq * (2 * Lr.cout + 2 * Lr.cin) + nq * Lr.cout / 8)])
+            B.append([lib.vsseg_conv_bwd_fused, [C.byref(d)], dict(tag=f"{pre[-40:]} q={self.lv[Lr.level]} cin={Lr.cin} cout={Lr.cout} tile={tuple(tile)}{res_tag}{tuned}", name=f"mbwd<bf16,{Lr.cout // 16},{Lr.cin // 16}>", kind="mfma",
+                                                                  flops=2.0 * 2.0 * nq * (10 if res_tag else 9) * Lr.cin * Lr.cout,
+                                                                  bytes=eng.es * nq * ((3 if res_tag.endswith("[unit dA]") else 2) * Lr.cout + 2 * Lr.cin) + nq * Lr.cout / 8)])
             return True
 
+        absorbed_res = set()  # residual convolutions whose data / weight gradient a fused launch produces
         gate_fuse: Dict[str, tuple] = {}  # relu-conv prefix -> (d(gated) descriptor, attention map pointer) of the gate fused into its data gradient
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
@@ -943,6 +973,8 @@ class Plan:
                     kx, ky, kz = big.kernel
                     centre = ((kx // 2) * ky + ky // 2) * kz + kz // 2
                     B.append([lib.vsseg_merge_residual_grads, [self._gp(big.wkey), self._gp(big.bkey), self._gp(Lr.wkey), self._gp(Lr.bkey), Lr.cout, Lr.cin, kx * ky * kz, centre], dict(name="vsseg_merge_residual_grads", kind="hbm", flops=0.0, bytes=0.0, side=True)])
+                    continue
+                if Lr.prefix in absorbed_res:  # data + weight gradient came out of the fused launch of the unit's 3x3x1 block (csrc/mbwd.hip, RES); bias gradient: folded_bias
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
@@ -1116,6 +1148,7 @@ class Engine:
         # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip): "0" = off, "1" = every
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
+        self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"  # ... with the unit's 1x1x1 residual convolution riding along
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched

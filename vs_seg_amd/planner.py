@@ -268,14 +268,20 @@ FUSED_BWD_SHAPES = {(16, 16, 8, 4), (16, 16, 4, 4), (16, 16, 4, 2), (16, 16, 8, 
                     (32, 64, 4, 2), (32, 64, 2, 2), (32, 64, 2, 1)}
 
 
-def fused_bwd_tiles(cout, cin, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tuple[int, int, int]]:
+def fused_bwd_lds_bytes(cy, cx, tz, mt, res=False) -> int:
+    """csrc/mbwd.hip mb_lds_bytes: dy ring (+ two raw planes of the residual gradient), two x planes, the data gradient's packed weights."""
+    rows = mt * 4 * (16 // tz) + 2
+    return (MARCH_RING + (2 if res else 0)) * round_up(rows * tz * (cy // 8) * 16, 256) + 2 * round_up((rows - 2) * tz * (cx // 8) * 16, 256) + ((9 * (cy // 8) + 3) // 4) * (cx // 16) * 1024
+
+
+def fused_bwd_tiles(cout, cin, q, n, scratch_elems=48 * 1024 * 1024, res=False) -> List[Tuple[int, int, int]]:
     """Candidate tiles (x steps per workgroup, rows, z slices) of the fused BatchNorm-backward + data gradient + weight gradient launch of a stride-1 3x3x1
     convolution block (csrc/mbwd.hip): about 512 / 1024 / 2048 workgroups, each with its own weight-gradient slab."""
     out = []
-    per_blk = (cout // 16) * 9 * (cin // 16) * 256
+    per_blk = (cout // 16) * (10 if res else 9) * (cin // 16) * 256
     for (cy, cx, tz, mt) in sorted(FUSED_BWD_SHAPES):
         tyb = 64 * mt // tz
-        if cy != cout or cx != cin or q[1] % tyb or q[2] % tz:
+        if cy != cout or cx != cin or q[1] % tyb or q[2] % tz or fused_bwd_lds_bytes(cy, cx, tz, mt, res) > 160 * 1024:
             continue
         cols = n * (q[1] // tyb) * (q[2] // tz)
         for target in (512, 1024, 2048):
@@ -286,6 +292,18 @@ def fused_bwd_tiles(cout, cin, q, n, scratch_elems=48 * 1024 * 1024) -> List[Tup
                 continue
             out.append((lx, tyb, tz))
     return out
+
+
+def residual_dgrad_pack_plan(wshape, q) -> "IgemmPlan":
+    """Packed-weight layout [ksteps][nt][64][8] of the data gradient of a 1x1x1 convolution (K = cout in one chunk -> N = cin in one workgroup): what
+    vsseg_conv_bwd_fused reads as `wpack_res` (the residual convolution riding along)."""
+    cls = lattice_classes("conv_dgrad", (1, 1, 1), (1, 1, 1))[0]
+    kreal, nreal = gemm_dims("conv_dgrad", wshape)
+    kc = round_up(kreal, 8)
+    nt = (nreal + 15) // 16
+    pl = IgemmPlan("conv_dgrad", cls, tuple(q), kc, nreal, kreal, (4, 4, 4), 1, nt, 1, kc, 1, (kc // 8 + 3) // 4, 0, 1)
+    pl.pack_map = pack_map(pl, wshape)
+    return pl
 
 
 # ---- fused output-parity classes on the streaming kernel ("pixel shuffle"): depth -4 ----------------------------------------
