@@ -204,6 +204,11 @@ int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream);
 int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c,
                        float* dbias /* sign = -1 only, or NULL: *dbias += sum_v s[v], the bias gradient of the C -> 1 convolution */,
                        float* scratch /* partial-sum slabs: >= k3*k3*C + 1 floats per workgroup */, int64_t scratch_elems, void* stream);
+/* vsseg_wgrad_narrow for the 1 -> C, 3x3x1 convolution of a Convolution block (ref:params/networks/blocks/convolutions.py:114-156) with T = d(conv output) formed ON
+ * LOAD from y (the convolution output), dout (the gradient of the block output) and the forward's keep-mask bytes — the second BatchNorm-backward pass, bit-identical
+ * to vsseg_bn_act_bwd_apply, which is then not launched and d(conv output) is never written (the network input needs no data gradient).  bf16 only. */
+int vsseg_wgrad_narrow_bn(vsseg_tensor y, vsseg_tensor dout, const uint8_t* keep, const float* mean, const float* invstd, const float* gamma, const float* scale, const float* shift, const float* alpha,
+                          const float* mean_dz, const float* mean_dzx, float p_drop, const void* s, float* dw, int64_t stride_c, float* scratch, int64_t scratch_elems, void* stream);
 
 /* dst[i] = map[i] >= 0 ? cast(src[map[i]]) : 0 — (re)packs the fp32 master weights into MFMA fragment order. */
 int vsseg_gather_cast(const float* src, const int32_t* map, const int32_t* map2 /* optional second addend, or NULL */, void* dst, int64_t n, int32_t dst_dtype, void* stream);

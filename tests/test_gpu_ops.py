@@ -204,6 +204,41 @@ def test_wgrad_narrow(k, cin, cout, dims, dt):
         assert abs(float(db) - want) <= 1e-4 * float(gy.abs().sum()) + 1e-4, (float(db), want)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+@pytest.mark.parametrize("cout,dims", [(16, (12, 16, 8)), (32, (5, 8, 12)), (8, (3, 4, 2))])
+def test_wgrad_narrow_with_batchnorm_backward_on_load(cout, dims, p_drop):
+    """vsseg_wgrad_narrow_bn: the first block's weight gradient (1 -> C, 3x3x1, the network input has no data gradient) with d(conv output) formed on load from
+    (y, dA, keep-mask) instead of read from a tensor vsseg_bn_act_bwd_apply wrote: same values, same summation order -> bit-identical to the two launches."""
+    lib = L.lib()
+    torch.manual_seed(31)
+    n, S = 2, H.stream()
+    ycl = H.to_cl(_round(torch.randn(n, cout, *dims) * 1.2 + 0.3, "bf16"), torch.bfloat16)
+    dcl = H.to_cl(_round(torch.randn(n, cout, *dims), "bf16"), torch.bfloat16)
+    x1 = H.to_cl(_round(torch.randn(n, 1, *dims), "bf16"), torch.bfloat16)
+    nvox = n * int(np.prod(dims))
+    vec = torch.zeros(6, cout, device="cuda")
+    vec[0], vec[1] = torch.randn(cout) * 0.2, torch.rand(cout) + 0.5
+    gam, bet, al = (torch.rand(cout) + 0.5).cuda(), (torch.randn(cout) * 0.1).cuda(), torch.tensor([0.25], device="cuda")
+    vec[2] = gam * vec[1]
+    vec[3] = bet - vec[0] * vec[2]
+    vec[4], vec[5] = torch.randn(cout) * 0.05, torch.randn(cout) * 0.05
+    keep = None
+    if p_drop > 0:
+        keep = torch.zeros(nvox * cout // 8, dtype=torch.uint8, device="cuda")
+        L.check(lib.vsseg_bn_act_fwd(H.tdesc(ycl), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x1234, 3, L.Tensor(), 0, H.tdesc(torch.zeros_like(ycl)), keep.data_ptr(), S))
+    kptr = keep.data_ptr() if keep is not None else None
+    dy = torch.zeros_like(ycl)
+    L.check(lib.vsseg_bn_act_bwd_apply(H.tdesc(ycl), H.tdesc(dcl), vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), bet.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, 0x1234, 3,
+                                       vec[4].data_ptr(), vec[5].data_ptr(), H.tdesc(dy), kptr, S))
+    scr = torch.zeros(1 << 20, device="cuda")
+    dw_ref, dw = torch.zeros(cout, 1, 3, 3, 1, device="cuda"), torch.zeros(cout, 1, 3, 3, 1, device="cuda")
+    L.check(lib.vsseg_wgrad_narrow(H.tdesc(dy), x1.data_ptr(), 3, 1, dw_ref.data_ptr(), 9, None, scr.data_ptr(), scr.numel(), S))
+    L.check(lib.vsseg_wgrad_narrow_bn(H.tdesc(ycl), H.tdesc(dcl), kptr, vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(),
+                                      p_drop, x1.data_ptr(), dw.data_ptr(), 9, scr.data_ptr(), scr.numel(), S))
+    torch.cuda.synchronize()
+    assert float(dw_ref.abs().max()) > 0 and torch.equal(dw, dw_ref), float((dw - dw_ref).abs().max())
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("hg,sb", [(1, 1), (2, 0), (2, 1), (4, 0), (4, 1), (3, 1)])
 def test_wgrad_h_chunk_groups(hg, sb, dt):

@@ -45,8 +45,8 @@ def test_plans_lower_on_cpu(att, dt):
     assert n_conv - 2 <= len(igemms) <= n_conv
     assert sum(1 for r in igemms if r[1][0]._obj.class_split == 8) == 3 and sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_igemm and r[1][0]._obj.class_split == 8) == 3
     # (bf16: the stride-1 3x3x1 blocks of the finest levels run BatchNorm-backward apply + data gradient + weight gradient as ONE launch, csrc/mbwd.hip)
-    n_fused = sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_conv_bwd_fused)
-    assert (n_fused >= 1) == (dt == "bf16")
+    n_fused = sum(1 for r in tr.bwd if r[0] in (eng.lib.vsseg_conv_bwd_fused, eng.lib.vsseg_wgrad_narrow_bn))
+    assert (n_fused >= 2) == (dt == "bf16")
     assert sum(1 for r in tr.bwd if r[0] in (eng.lib.vsseg_wgrad, eng.lib.vsseg_wgrad_narrow)) + n_fused == n_conv - len(tr.merged)  # the final 1x1x1 residual conv is merged into the final 3x3x1 conv
     assert len(tr.merged) == 1 and sum(1 for r in tr.bwd if r[0] is eng.lib.vsseg_merge_residual_grads) == 1
     assert len(ev.bwd) == 0 and len(ev.fwd) < len(tr.fwd)
@@ -79,7 +79,7 @@ def test_shipped_tuned_plans_still_name_existing_candidates():
     from vs_seg_amd import planner as P
 
     data = json.load(open(E.TUNED_DEFAULTS))
-    ig = {k: v for k, v in data.items() if not k.startswith(("wgrad", "use_cs"))}  # (use_cs|...: per-class or class-split launch, 0 / 1)
+    ig = {k: v for k, v in data.items() if not k.startswith(("wgrad", "use_cs", "fbwd"))}  # (use_cs|...: per-class or class-split launch, 0 / 1; fbwd|...: tile of a fused backward launch)
     assert len(ig) > 150 and sum(1 for k in data if k.startswith("wgrad")) >= 40
     checked = hits = 0
     for key, choice in list(ig.items())[::5]:

@@ -15,6 +15,7 @@
 // addresses measured 0.72 ms for the whole launch, slower than the MFMA kernel.  T is read exactly once, s nine times out of L1/L2.
 #define VSSEG_NT_LOADS  // the C-channel tensor is read exactly once (ld8): non-temporal; the one-channel field is re-read nine times and stays cached
 #include "common.h"
+#include "bn_bwd.h"
 
 struct WnK {
   const void* t;
@@ -27,13 +28,20 @@ struct WnK {
   int sign;
   int64_t stride_c;
   int64_t items;  // n * X * yq * Z work items per channel group
+  // BN (vsseg_wgrad_narrow_bn): T = d(conv output) is formed ON LOAD from the convolution output `t`, the gradient of the block output `da` and the forward's
+  // keep-mask bytes — the second pass of the BatchNorm -> Dropout -> PReLU backward (bn_bwd.h, bit-identical to vsseg_bn_act_bwd_apply, which is then not launched)
+  const void* da;
+  const unsigned char* keep;
+  const float *mean, *invstd, *gamma, *scale, *shift, *alpha, *mean_dz, *mean_dzx;
+  float inv_keep;
+  int dapitch;
 };
 
 template <typename T> __device__ __forceinline__ float wn_ld(const T* p);
 template <> __device__ __forceinline__ float wn_ld<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float wn_ld<bf16_t>(const bf16_t* p) { return bf2f(*p); }
 
-template <typename T, int K3>  // K3: 3 = 3x3x1 taps, 1 = 1x1x1
+template <typename T, int K3, bool BN = false>  // K3: 3 = 3x3x1 taps, 1 = 1x1x1
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
   constexpr int NT = K3 * K3, ROWS = K3 == 3 ? 6 : 4, R = K3 / 2;
   __shared__ float red[4][NT * 64 + 1];  // one row per wave, summed in wave order (run-to-run bit-identical)
@@ -44,6 +52,13 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
   const int64_t step = nthreads / cgs;
   const T* tp = reinterpret_cast<const T*>(k.t) + cg * 8;
   const T* sp = reinterpret_cast<const T*>(k.s);
+  const T* dap = BN ? reinterpret_cast<const T*>(k.da) + cg * 8 : nullptr;
+  BnBwdC8 bc;
+  float alpha = 0.f;
+  if constexpr (BN) {
+    bn_bwd_consts(bc, k.mean, k.invstd, k.gamma, k.scale, k.shift, k.mean_dz, k.mean_dzx, cg * 8, k.inv_keep);
+    alpha = *k.alpha;
+  }
   const int X = k.X, Y = k.Y, Z = k.Z;
   float acc[NT][8];
 #pragma unroll
@@ -66,6 +81,24 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WnK k) {
     f8 tv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) tv[i] = ld8(t0 + i * trow);
+    if constexpr (BN) {  // y, dA, keep-mask -> dy, rounded to the storage type as the materialised tensor would have been
+      const T* d0 = dap + (int64_t)v0 * k.dapitch;
+      const int64_t darow = (int64_t)Z * k.dapitch;
+      f8 dv[4];
+      unsigned kp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dv[i] = ld8(d0 + i * darow);
+        kp[i] = k.keep ? (unsigned)k.keep[(int64_t)(v0 + i * Z) * cgs + cg] : 0xffu;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f8 o;
+        bn_bwd_dy8(tv[i], dv[i], kp[i], alpha, bc, o);
+        if constexpr (sizeof(T) == 2) tv[i] = bf16x8_to_f8(f8_to_bf16x8(o));
+        else tv[i] = o;
+      }
+    }
 #pragma unroll
     for (int dxi = 0; dxi < K3; ++dxi) {
       const int xs = x + dxi - R;
@@ -127,7 +160,23 @@ __global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_narrow_reduce_kernel
   dw[(int64_t)c * stride_c + widx] += s;
 }
 
+static int wgrad_narrow_impl(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* dbias, float* scratch, int64_t scratch_elems, void* stream, const WnK* bn);
 extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* dbias, float* scratch, int64_t scratch_elems, void* stream) {
+  return wgrad_narrow_impl(t, s, k3, sign, dw, stride_c, dbias, scratch, scratch_elems, stream, nullptr);
+}
+// 1 -> C, 3x3x1, bf16: the same reduction with T = d(conv output) formed on load (see WnK): y = convolution output, dout = gradient of the block output
+extern "C" int vsseg_wgrad_narrow_bn(vsseg_tensor y, vsseg_tensor dout, const uint8_t* keep, const float* mean, const float* invstd, const float* gamma, const float* scale, const float* shift, const float* alpha,
+                                     const float* mean_dz, const float* mean_dzx, float p_drop, const void* s, float* dw, int64_t stride_c, float* scratch, int64_t scratch_elems, void* stream) {
+  VSSEG_CHECK(y.ptr && dout.ptr && !dout.ptr2 && mean && invstd && gamma && scale && shift && alpha && mean_dz && mean_dzx, "vsseg_wgrad_narrow_bn: null pointer");
+  VSSEG_CHECK(y.dtype == VSSEG_BF16 && dout.dtype == VSSEG_BF16 && dout.c == y.c && dout.pitch % 8 == 0 && dout.n == y.n && dout.x == y.x && dout.y == y.y && dout.z == y.z, "vsseg_wgrad_narrow_bn: y / dout must be bf16 tensors of one shape");
+  VSSEG_CHECK(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || keep), "vsseg_wgrad_narrow_bn: dropout needs the keep-mask bytes of the forward");
+  WnK bn;
+  bn.da = dout.ptr; bn.dapitch = dout.pitch; bn.keep = p_drop > 0.f ? keep : nullptr;
+  bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.scale = scale; bn.shift = shift; bn.alpha = alpha; bn.mean_dz = mean_dz; bn.mean_dzx = mean_dzx;
+  bn.inv_keep = 1.f / (1.f - p_drop);
+  return wgrad_narrow_impl(y, s, 3, 1, dw, stride_c, nullptr, scratch, scratch_elems, stream, &bn);
+}
+static int wgrad_narrow_impl(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, float* dw, int64_t stride_c, float* dbias, float* scratch, int64_t scratch_elems, void* stream, const WnK* bn) {
   VSSEG_CHECK(!dbias || sign == -1, "vsseg_wgrad_narrow: the bias gradient (sum of the one-channel dY) belongs to the C -> 1 case (sign = -1)");
   VSSEG_CHECK(t.ptr && s && dw && scratch && !t.ptr2, "vsseg_wgrad_narrow: bad pointers (two-part tensors are not supported)");
   VSSEG_CHECK(k3 == 1 || k3 == 3, "vsseg_wgrad_narrow: 3x3x1 or 1x1x1 kernels only (k3 = %d)", k3);
@@ -149,7 +198,12 @@ extern "C" int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int
   VSSEG_CHECK(cap >= 1, "vsseg_wgrad_narrow: scratch too small");
   if (grid > cap) grid = (int)cap;
   k.slab = scratch;
-  if (t.dtype == VSSEG_F32) {
+  k.da = nullptr; k.keep = nullptr;
+  if (bn) {
+    k.da = bn->da; k.dapitch = bn->dapitch; k.keep = bn->keep; k.inv_keep = bn->inv_keep;
+    k.mean = bn->mean; k.invstd = bn->invstd; k.gamma = bn->gamma; k.scale = bn->scale; k.shift = bn->shift; k.alpha = bn->alpha; k.mean_dz = bn->mean_dz; k.mean_dzx = bn->mean_dzx;
+    hipLaunchKernelGGL((wgrad_narrow_kernel<bf16_t, 3, true>), dim3(grid), dim3(256), 0, as_stream(stream), k);
+  } else if (t.dtype == VSSEG_F32) {
     if (k3 == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<float, 3>), dim3(grid), dim3(256), 0, as_stream(stream), k);
     else hipLaunchKernelGGL((wgrad_narrow_kernel<float, 1>), dim3(grid), dim3(256), 0, as_stream(stream), k);
   } else {

@@ -845,7 +845,7 @@ class Plan:
                 return False
             if want != "1" and f"{Lr.cin}x{Lr.cout}" not in want.split(","):
                 return False
-            scr = self.eng.wgrad_scratch()
+            scr = self.eng.fused_scratch()  # (its own slabs: the launch runs on the main stream, concurrently with the side stream's weight gradients)
             # The ResidualUnit's 1x1x1 residual convolution of the same input (ref:params/networks/blocks/convolutions.py:241-255) rides along: its output gradient is
             # the gradient of the tensor it is added into — this block's own dA (single-subunit decoder units) or the unit's output gradient (encoder units, where
             # the add sits behind the second convolution; complete long before this launch).  Its own data- and weight-gradient launches are then skipped.
@@ -928,6 +928,19 @@ class Plan:
                                                                   bytes=eng.es * nq * ((3 if res_tag.endswith("[unit dA]") else 2) * Lr.cout + 2 * Lr.cin) + nq * Lr.cout / 8)])
             return True
 
+        def fused_narrow(op: ConvBnAct, yd: L.Tensor, dA: L.Tensor) -> bool:
+            """The 1 -> C 3x3x1 block on the network input (no data gradient): vsseg_bn_act_bwd_apply is applied on load by the narrow weight-gradient reduction."""
+            Lr, pre = op.layer, op.layer.prefix
+            if (eng.fused_bwd == "0" or eng.es != 2 or not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cin != 1 or Lr.cout not in (8, 16, 32, 64)
+                    or op.x.root.name != prog.input.name or self.lv[Lr.level][1] % 4 or dA.ptr2 or dA.c != Lr.cout or (p_drop > 0.0 and keep_ptr(Lr) is None)):
+                return False
+            x1 = self._xdesc(op.x, True)  # the compact one-channel copy of the network input
+            scr = self.eng.wgrad_scratch()
+            B.append([lib.vsseg_wgrad_narrow_bn, [yd, dA, keep_ptr(Lr), vptr(0, pre), vptr(1, pre), self._pp(pre + ".norm.weight"), vptr(2, pre), vptr(3, pre), self._pp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre),
+                                                   p_drop, x1.ptr, self._gp(Lr.wkey), 9, scr.data_ptr(), scr.numel()],
+                      dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (2 * Lr.cout + 1) + self._vox(Lr.level) * Lr.cout / 8, tag=f"{pre[-40:]} 1->{Lr.cout} k={Lr.kernel} +bn on load")])
+            return True
+
         absorbed_res = set()  # residual convolutions whose data / weight gradient a fused launch produces
         gate_fuse: Dict[str, tuple] = {}  # relu-conv prefix -> (d(gated) descriptor, attention map pointer) of the gate fused into its data gradient
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
@@ -947,7 +960,7 @@ class Plan:
                     folded_bias.add(producer[op.res.name].layer.prefix)
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
-                fused = (op.res is None or op.res.name.endswith(":res")) and fused_backward(op, yd, dA)  # (an identity residual re-uses dA's buffer below: keep those unfused)
+                fused = (op.res is None or op.res.name.endswith(":res")) and (fused_backward(op, yd, dA) or fused_narrow(op, yd, dA))  # (an identity residual re-uses dA's buffer below: keep those unfused)
                 if not fused:
                     dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
                     B.append([lib.vsseg_bn_act_bwd_apply, [yd, dA, vptr(0, pre), vptr(1, pre), gam, bet, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], vptr(4, pre), vptr(5, pre), dyd, keep_ptr(Lr)],
@@ -1175,6 +1188,11 @@ class Engine:
         if getattr(self, "_wg_scratch", None) is None:
             self._wg_scratch = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device=self.device)  # 192 MB of partial-sum slabs, shared by all layers
         return self._wg_scratch
+
+    def fused_scratch(self) -> torch.Tensor:
+        if getattr(self, "_fb_scratch", None) is None:
+            self._fb_scratch = torch.zeros(48 * 1024 * 1024, dtype=torch.float32, device=self.device)  # partial-sum slabs of the fused backward launches (main stream)
+        return self._fb_scratch
 
     def plan(self, n, dims, train, slot: int = 0) -> Plan:
         """The lowered launch lists + activation buffers for one (batch, size, mode).  `slot` > 0: a further, independent set of buffers for
