@@ -177,7 +177,18 @@ def cpu_baseline(budget_s=25.0):
     shape = (PATCH[0] // 2, PATCH[1], PATCH[2])
     t = step(shape)
     frac = (shape[0] * shape[1] * shape[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
-    return dict(value=frac / t, unit="patches/s", cores=cores, host_cores=ncpu, kind="port",
+    # "all host cores, same box" (north_star) beside it, bounded: the same step on a 64x64x32 patch with every host core and, for the comparison at equal shape,
+    # with the 16 threads of the headline figure (a few seconds in total)
+    small = (64, 64, 32)
+    sfrac = (small[0] * small[1] * small[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
+    t16 = min(step(small), step(small))
+    torch.set_num_threads(ncpu)
+    step(small)
+    tall = min(step(small), step(small))
+    torch.set_num_threads(cores)
+    all_cores = dict(cores=ncpu, value=sfrac / tall, unit="patches/s", same_sample_with_16_threads=sfrac / t16,
+                     sample=f"the same step on a {small[0]}x{small[1]}x{small[2]} patch ({sfrac:.4f} of a benchmark patch): {tall:.2f} s with {ncpu} threads, {t16:.2f} s with {cores}; scaled by voxels")
+    return dict(value=frac / t, unit="patches/s", cores=cores, host_cores=ncpu, kind="port", all_cores=all_cores,
                 sample=f"1 training step (fwd+Dice_spvPA+bwd+Adam, fp32, batch 1) of the oracle on a {shape[0]}x{shape[1]}x{shape[2]} patch = {frac:.3f} of a 384x128x128 patch in {t:.2f} s, scaled by voxels")
 
 

@@ -104,6 +104,14 @@ typedef struct {
   int32_t class_oo[8][3];
   int32_t class_ntaps[8];
   int32_t class_tap[8][8];
+  /* A 1x1x1 convolution of the SAME input riding along (the ResidualUnit's residual convolution, ref:params/networks/blocks/convolutions.py:241-255; marching kernel,
+   * depth -5 / -6, plain or statistics epilogue only): res_tiles more 16-channel output tiles that run only the K-steps of the centre tap; the input is read once
+   * for both convolutions.  res_out.ptr != NULL: their values (+ bias_res) are stored there (bf16) — training, where the add sits behind the BatchNorm pass;
+   * res_out.ptr == NULL: they are added to the main tiles behind their activation — eval: out = act(bn(conv(x))) + residual(x).  0: off. */
+  int32_t res_tiles;
+  const void* wpack_res;   /* [K-steps of the centre tap][res_tiles][64 lanes][8] in the compute dtype (planner.residual_tile_pack_map) */
+  const float* bias_res;   /* [res_out.c] or NULL */
+  vsseg_tensor res_out;
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).

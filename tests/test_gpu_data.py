@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 from vs_seg_amd import _lib as L  # noqa: E402
 from vs_seg_amd.data import nifti  # noqa: E402
 from vs_seg_amd.data import transforms as T  # noqa: E402
+from oracle import data_oracle as DO  # noqa: E402
 
 
 def test_normalize_intensity_matches_host():
@@ -22,7 +23,7 @@ def test_normalize_intensity_matches_host():
         x = torch.from_numpy(v).cuda()
         y, acc = torch.empty_like(x), torch.zeros(2, dtype=torch.float64, device="cuda")
         L.check(lib.vsseg_normalize_intensity(x.data_ptr(), y.data_ptr(), x.numel(), acc.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        np.testing.assert_allclose(y.cpu().numpy(), T.host_normalize_intensity(v), atol=2e-5)
+        np.testing.assert_allclose(y.cpu().numpy(), DO.host_normalize_intensity(v), atol=2e-5)
 
 
 def _case(vol, lab):
@@ -45,8 +46,8 @@ def test_patch_sampler_matches_host_flip_crop_including_padding():
         for b, i in enumerate(idx):
             flip, start = s.last_draws[b]
             seen_flip.add(flip)
-            np.testing.assert_array_equal(img[b, 0].cpu().numpy(), T.host_flip_crop(host[i][0], flip, start, roi))
-            np.testing.assert_array_equal(lab[b, 0].cpu().numpy(), T.host_flip_crop(host[i][1], flip, start, roi))
+            np.testing.assert_array_equal(img[b, 0].cpu().numpy(), DO.host_flip_crop(host[i][0], flip, start, roi))
+            np.testing.assert_array_equal(lab[b, 0].cpu().numpy(), DO.host_flip_crop(host[i][1], flip, start, roi))
     assert seen_flip == {True, False}
     # negative origin / roi larger than the volume = SpatialPadd's zero padding, through the C ABI directly
     lib = L.lib()
@@ -102,7 +103,7 @@ def test_vsparams_train_validate_infer_export_end_to_end(tmp_path):
     c0 = train_loader.cases[0]
     raw, aff, _ = nifti.read_nifti(train_files[0]["image"])
     np.testing.assert_array_equal(c0["image_meta"]["ornt"], [[0, -1], [1, -1], [2, 1]])
-    want = T.host_spatial_pad(T.host_normalize_intensity(raw[::-1, ::-1]), p.pad_crop_shape)
+    want = DO.host_spatial_pad(DO.host_normalize_intensity(raw[::-1, ::-1]), p.pad_crop_shape)
     np.testing.assert_allclose(c0["image"].cpu().numpy(), want, atol=2e-5)
     batches = list(train_loader)
     assert [b["image"].shape[0] for b in batches] == [2, 1] and batches[0]["image"].shape[1:] == (1, 64, 64, 16)

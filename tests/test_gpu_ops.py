@@ -851,6 +851,68 @@ def test_fused_conv_backward_with_residual_convolution(cin, cout, dims, tile, sa
     np.testing.assert_allclose(dwr.cpu().reshape(wr.shape).numpy(), wrd.grad.float().numpy(), rtol=1e-3, atol=1e-3 * float(wrd.grad.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,dims,shape,lx", [(16, 32, (6, 64, 16), (8, 4), 4), (16, 32, (5, 128, 8), (4, 4), 5), (16, 32, (7, 32, 8), (4, 2), 3), (64, 32, (5, 64, 4), (2, 2), 2), (64, 32, (6, 32, 6), (2, 1), 6)])
+def test_marching_kernel_with_residual_tiles(cin, cout, dims, shape, lx):
+    """vsseg_igemm_desc.res_tiles (csrc/mconv.hip NR): the ResidualUnit's 1x1x1 residual convolution of the same input as extra output tiles of the unit's first
+    3x3x1 convolution — centre-tap K-steps only, input read once.  Stored to its own tensor (training: + statistics of the main tiles) it must be BIT-IDENTICAL to
+    the two separate launches; added in the epilogue (eval: out = prelu(bn(conv(x))) + residual(x)) it skips the bf16 rounding of the residual tensor."""
+    lib = L.lib()
+    k, n = (3, 3, 1), 2
+    torch.manual_seed(17)
+    x = _round(torch.randn(n, cin, *dims), "bf16")
+    w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, "bf16")
+    wr = _round(torch.randn(cout, cin, 1, 1, 1) / cin ** 0.5, "bf16")
+    b, br = torch.randn(cout).cuda(), torch.randn(cout).cuda()
+    xcl = H.to_cl(x, torch.bfloat16)
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    tz, mtw = shape
+    for depth in P.MARCH_DEPTHS:
+        mp = [pl for pl in P.march_res_plans(tuple(w.shape), tuple(wr.shape), cls, dims, 2, cin, n=n) if (pl.tile[2], pl.mtw, pl.depth) == (tz, mtw, depth)]
+        if not mp and depth == -6:  # (weights-in-registers twins exist for some shapes only)
+            continue
+        assert mp, (depth, [(p_.tile, p_.mtw, p_.depth) for p_ in P.march_res_plans(tuple(w.shape), tuple(wr.shape), cls, dims, 2, cin, n=n)])
+        mp = dataclasses.replace(mp[0], tile=(lx, mp[0].tile[1], tz))
+        wp = H.pack(mp, w, torch.bfloat16)
+        wpr = torch.zeros(mp.pack_map_res.size, dtype=torch.bfloat16, device="cuda")
+        mr = torch.from_numpy(mp.pack_map_res).cuda()
+        L.check(lib.vsseg_gather_cast(wr.float().reshape(-1).cuda().data_ptr(), mr.data_ptr(), None, wpr.data_ptr(), mr.numel(), L.BF16, H.stream()), "gather_cast")
+        # separate launches (general kernel)
+        gen = P.plan_igemm("conv_fwd", tuple(w.shape), cls, dims, 2, kc_pad=cin, aux_es=0)
+        gen.pack_map = P.pack_map(gen, tuple(w.shape))
+        cls1 = P.lattice_classes("conv_fwd", (1, 1, 1), (1, 1, 1))[0]
+        gen1 = P.plan_igemm("conv_fwd", tuple(wr.shape), cls1, dims, 2, kc_pad=cin, aux_es=0)
+        gen1.pack_map = P.pack_map(gen1, tuple(wr.shape))
+        y_ref = torch.zeros(n, *dims, cout, dtype=torch.bfloat16, device="cuda")
+        r_ref = torch.zeros_like(y_ref)
+        st_ref = torch.zeros(L.STAT_SHARDS * 2 * cout, dtype=torch.float64, device="cuda")
+        wpg, wpg1 = H.pack(gen, w, torch.bfloat16), H.pack(gen1, wr, torch.bfloat16)
+        d = H.igemm_desc(gen, wpg, H.tdesc(xcl), H.tdesc(y_ref), bias=b.data_ptr(), stats=st_ref.data_ptr(), stats_stride=cout)
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm")
+        d = H.igemm_desc(gen1, wpg1, H.tdesc(xcl), H.tdesc(r_ref), bias=br.data_ptr())
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm 1x1x1")
+        # one launch, residual tensor stored
+        y, r = torch.full_like(y_ref, float("nan")), torch.full_like(y_ref, float("nan"))
+        st = torch.zeros_like(st_ref)
+        d = H.igemm_desc(mp, wp, H.tdesc(xcl), H.tdesc(y), bias=b.data_ptr(), stats=st.data_ptr(), stats_stride=cout, res_tiles=mp.res_tiles, wpack_res=wpr.data_ptr(), bias_res=br.data_ptr(), res_out=H.tdesc(r))
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm + residual tiles")
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref) and torch.equal(r, r_ref), (depth, float((y.float() - y_ref.float()).abs().max()), float((r.float() - r_ref.float()).abs().max()))
+        a, bb = H.stat_decode(st_ref).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(st).view(L.STAT_SHARDS, 2, -1).sum(0)
+        np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+        # eval form: folded BatchNorm + PReLU, residual added in the epilogue
+        sc, sh, al = (torch.rand(cout) + 0.5).cuda(), torch.randn(cout).cuda() * 0.1, torch.tensor([0.25], device="cuda")
+        out = torch.full_like(y_ref, float("nan"))
+        d = H.igemm_desc(mp, wp, H.tdesc(xcl), H.tdesc(out), bias=b.data_ptr(), scale=sc.data_ptr(), shift=sh.data_ptr(), alpha=al.data_ptr(), act=L.ACT_PRELU, res_tiles=mp.res_tiles, wpack_res=wpr.data_ptr(), bias_res=br.data_ptr())
+        L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm + residual tiles (eval)")
+        torch.cuda.synchronize()
+        yy = F.conv3d(x.double(), w.double(), b.double().cpu(), padding=P.same_pad(k)) * sc.double().cpu().view(1, -1, 1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1, 1)
+        want = F.prelu(yy, al.double().cpu()) + F.conv3d(x.double(), wr.double(), br.double().cpu())
+        np.testing.assert_allclose(H.from_cl(out).numpy(), want.float().numpy(), atol=_tol("bf16", want))
+    # the general kernel refuses the field loudly
+    d = H.igemm_desc(gen, wpg, H.tdesc(xcl), H.tdesc(y), res_tiles=2, wpack_res=wpr.data_ptr())
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) != 0
+
+
 @pytest.mark.parametrize("dims,split,shape,lx", [((7, 128, 4), 16, (2, 4), 3), ((6, 64, 8), 16, (4, 4), 6), ((5, 64, 8), 0, (4, 2), 2)])
 def test_attention_gate_on_load_equals_materialised_gate(dims, split, shape, lx):
     """in_gate / h_gate: the marching convolution and the marching weight gradient multiply the input voxels by (1 + att) in LDS (AttentionBlock2,

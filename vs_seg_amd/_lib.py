@@ -73,6 +73,10 @@ class IgemmDesc(C.Structure):
         ("class_oo", (C.c_int32 * 3) * 8),
         ("class_ntaps", C.c_int32 * 8),
         ("class_tap", (C.c_int32 * 8) * 8),
+        ("res_tiles", C.c_int32),
+        ("wpack_res", C.c_void_p),
+        ("bias_res", C.c_void_p),
+        ("res_out", Tensor),
     ]
 
 

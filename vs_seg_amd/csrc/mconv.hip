@@ -44,6 +44,12 @@ struct MconvK {
   int out_f32, aux_mode, act, cout, cout_mod, stats_stride;
   int X, Y, Z;
   int lx, nxs, nyb, nzb;  // x steps per workgroup; segments in x, blocks in y and z
+  // NR > 0: NR more 16-channel tiles of a 1x1x1 convolution of the SAME input ride along (the ResidualUnit's residual convolution,
+  // ref:params/networks/blocks/convolutions.py:241-255): only the K-steps of the centre tap, weights in registers, the operand reads shared with the main tiles
+  const char* wpack_r;   // [KHI - KLO][NR][64 lanes][8]
+  const float* bias_r;
+  char* res_out;         // its output tensor (bf16), or nullptr: added to the main tiles behind their activation (eval: out = act(bn(conv(x))) + residual(x))
+  int res_vox_bytes, res_cout;
 };
 
 // MODE: 0 plain, 1 + BatchNorm statistics, 2 + auxiliary operand (bf16), 3 plain + attention gate applied to the input on load (GIN):
@@ -54,9 +60,10 @@ struct MconvK {
 // With few M-tiles per wave the K loop re-reads every weight fragment from LDS at every x step — on the 64 -> 32 layers (MT = 1, 36 fragments per
 // step and wave against 18 operand fragments) two thirds of the LDS bandwidth the launch is bound by; in registers they cost nothing per step and
 // the 9-36 KB of LDS they occupied go back to the ring.
-template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG>
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr bool STATS = MODE == 1, AUXM = MODE == 2, GIN = MODE == 3;
+  constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
   constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = WREG ? 0 : KSTEPS * NT * 1024;
@@ -93,6 +100,21 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[cv] : 0.f;
   }
   const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
+  bf16x8 wres[NR ? KR : 1][NR ? NR : 1];
+  float rb[NR ? NR : 1][4];
+  if constexpr (NR > 0) {
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+      for (int t = 0; t < NR; ++t) wres[ks][t] = *reinterpret_cast<const bf16x8*>(k.wpack_r + ((ks * NR + t) * 64 + (threadIdx.x & 63)) * 16);
+#pragma unroll
+    for (int t = 0; t < NR; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + ((threadIdx.x & 63) >> 4) * 4 + r;
+        rb[t][r] = (k.bias_r && c < k.res_cout) ? k.bias_r[c] : 0.f;
+      }
+  }
 
   // ---- this thread's DMA pieces: LDS slot j = (u*4 + wave)*64 + lane of a plane holds (row j / RS, piece' (j % RS) / TZ, z j % TZ)
   int rel[NINST], grel[GIN ? NINST : 1];
@@ -235,6 +257,13 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 racc[NR ? MT : 1][NR ? NR : 1];
+    if constexpr (NR > 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NR; ++t) racc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       bf16x8 w[NT];
@@ -249,6 +278,12 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
         const bf16x8 av = *reinterpret_cast<const bf16x8*>(hb + m * MT_BYTES);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[t], av, acc[m][t], 0, 0, 0);
+        if constexpr (NR > 0) {
+          if (ks >= KLO && ks < KHI) {
+#pragma unroll
+            for (int t = 0; t < NR; ++t) racc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[ks >= KLO ? ks - KLO : 0][t], av, racc[m][t], 0, 0, 0);
+          }
+        }
       }
     }
 
@@ -290,6 +325,12 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) val[r] = val[r] > 0.f ? val[r] : alpha_eff * val[r];
           }
+          if constexpr (NR > 0) {
+            if (k.res_out == nullptr && t < NR) {  // eval: + residual(x), behind the activation
+#pragma unroll
+              for (int r = 0; r < 4; ++r) val[r] += racc[m][t][r] + rb[t][r];
+            }
+          }
           if constexpr (AUXM) {
             const uint2 a = auxv[m][t];
             const float4 av = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u));
@@ -323,6 +364,17 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     if (ekind == 0) epilogue(std::integral_constant<int, 0>{});
     else if (AUXM && ekind == 1) epilogue(std::integral_constant<int, AUXM ? 1 : 0>{});
     else epilogue(std::integral_constant<int, 2>{});
+    if constexpr (NR > 0) {
+      if (k.res_out != nullptr) {  // the residual convolution's own output tensor (training: added behind the BatchNorm pass)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          char* rp = k.res_out + (ovox0 + (int64_t)m * RPM * Z) * k.res_vox_bytes + g * 8;
+#pragma unroll
+          for (int t = 0; t < NR; ++t)
+            if (t * 16 + g * 4 < k.res_cout) st4(reinterpret_cast<bf16_t*>(rp + t * 32), make_float4(racc[m][t][0] + rb[t][0], racc[m][t][1] + rb[t][1], racc[m][t][2] + rb[t][2], racc[m][t][3] + rb[t][3]));
+        }
+      }
+    }
     if constexpr (AUXM) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -377,6 +429,20 @@ template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG> static int mc_la
   VSSEG_LAUNCH_CHECK("vsseg_igemm (marching)");
   return VSSEG_OK;
 }
+template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_launch_res(const MconvK& k, int grid, hipStream_t s) {  // + NR residual tiles: plain / statistics epilogues
+  if (k.in_gate || k.aux_mode) { vsseg_set_error("vsseg_igemm: residual tiles combine with the plain and the statistics epilogue only"); return VSSEG_EINVAL; }
+  static bool init = false;
+  const int lds = mc_lds<CIN, NT, TZ, MT, WREG>();
+  if (!init) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    init = true;
+  }
+  if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, residual tiles)");
+  return VSSEG_OK;
+}
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.in_gate) {
     if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3, WREG>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
@@ -388,16 +454,18 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const
 }
 
 typedef int (*mc_fn_t)(const MconvK&, int, hipStream_t);
-struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg; int (*lds_wreg)(); };
+struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg; int (*lds_wreg)(); int nr; };
 #define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, nullptr, nullptr}
 #define MC_W(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, mc_launch<C, N, Z, M, true>, mc_lds<C, N, Z, M, true>}  // + the depth -6 twin (weights in registers)
+#define MC_R(C, N, R, Z, M) {C, N, Z, M, mc_launch_res<C, N, Z, M, false, R>, mc_lds<C, N, Z, M, false>, mc_launch_res<C, N, Z, M, true, R>, mc_lds<C, N, Z, M, true>, R}  // + R residual tiles (res_tiles)
 // (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
 static const McEntry mc_table[] = {
     MC_E(8, 1, 8, 8), MC_E(8, 2, 8, 8), MC_E(8, 1, 4, 8), MC_E(8, 2, 4, 8), MC_E(8, 1, 4, 4), MC_E(8, 2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
     MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
     MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_W(16, 2, 4, 2), MC_W(16, 2, 8, 4), MC_W(32, 1, 4, 2), MC_W(32, 2, 4, 2), MC_E(8, 1, 8, 4), MC_E(8, 2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
     MC_W(32, 1, 2, 4), MC_W(32, 1, 4, 4), MC_W(32, 1, 2, 2), MC_W(32, 2, 4, 4), MC_W(32, 2, 2, 4), MC_W(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_W(32, 4, 2, 2), MC_W(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
-    MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1)};                                                   // 64 -> 32 / 16
+    MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1),                                                    // 64 -> 32 / 16
+    MC_R(16, 2, 2, 8, 4), MC_R(16, 2, 2, 8, 8), MC_R(16, 2, 2, 4, 4), MC_R(16, 2, 2, 4, 2), MC_R(64, 2, 2, 2, 1), MC_R(64, 2, 2, 2, 2)};   // ResidualUnit first convolutions of level 1 with their 1x1x1 residual convolution: 16 -> 32 + 32, 64 -> 32 + 32
 
 static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
@@ -422,8 +490,12 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
     const vsseg_tensor& a = d->accumulate ? d->out : d->res;
     if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");
   }
+  if (d->res_tiles && (!d->wpack_res || d->res_tiles < 1 || d->res_tiles > d->nt || d->accumulate || d->res_mode != VSSEG_RES_NONE || d->in_gate || d->out.ptr2 ||
+                       (d->res_out.ptr && (d->res_out.dtype != VSSEG_BF16 || d->res_out.ptr2 || (d->res_out.c & 3) || d->res_out.c > d->res_tiles * 16 || (d->res_out.pitch & 3)))))
+    return no("residual tiles need their packed weights, a plain or statistics epilogue and a one-part bf16 output");
+  if (d->res_tiles && !d->res_out.ptr && (d->out.dtype != VSSEG_BF16 || (d->out.c & 3))) return no("residual tiles added in the epilogue need a bf16 output");
   for (const McEntry& e : mc_table)
-    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
+    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt && e.nr == d->res_tiles) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
   return no("no instantiation for this (channels, nt, tz, mtw)");
 }
 
@@ -475,6 +547,9 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.lx = d->tile[0] > k.X ? k.X : d->tile[0];
   k.nxs = (k.X + k.lx - 1) / k.lx; k.nyb = k.Y / d->tile[1]; k.nzb = k.Z / d->tile[2];
+  k.wpack_r = reinterpret_cast<const char*>(d->wpack_res); k.bias_r = d->bias_res;
+  k.res_out = reinterpret_cast<char*>(d->res_out.ptr); k.res_vox_bytes = d->res_out.pitch * 2;
+  k.res_cout = d->res_tiles ? (d->res_out.ptr ? d->res_out.c : d->out.c) : 0;
   const int64_t grid = (int64_t)d->in.n * k.nxs * k.nyb * k.nzb;
   VSSEG_CHECK(grid > 0 && grid < (1ll << 30), "vsseg_igemm: bad marching grid");
   return d->depth == -6 ? e->fn_wreg(k, (int)grid, s) : e->fn(k, (int)grid, s);

@@ -5,8 +5,8 @@ Deterministic head (cached once per case, like `CacheDataset(cache_rate=1.0)`, r
 Random tail (per sample, per epoch):
     RandFlipd(prob=0.5, spatial_axis=0) → RandSpatialCropd(roi=pad_crop_shape, random_center=True, random_size=False)
 
-`host_*` functions are the numpy restatement of MONAI 0.4.0's arithmetic (parity unpinned — MONAI is not
-installed) and serve as the CPU check of the HIP path (`vsseg_normalize_intensity`, `vsseg_crop_flip`).  `PatchSampler`
+The numpy restatement of MONAI 0.4.0's arithmetic that checks the HIP path (`vsseg_normalize_intensity`, `vsseg_crop_flip`) is test
+infrastructure and lives in `oracle/data_oracle.py` (parity unpinned — MONAI is not installed).  `PatchSampler`
 is the product path: cached volumes live in HBM, one launch crops/flips image and label of a whole batch.
 """
 from __future__ import annotations
@@ -24,15 +24,8 @@ MAX_SEED = np.iinfo(np.uint32).max + 1
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# numpy restatement (checker / CPU-side head of the chain)
+# geometry shared with the checker (the numpy restatement of the MONAI arithmetic lives in oracle/data_oracle.py: test infrastructure)
 # ---------------------------------------------------------------------------------------------------------------
-def host_normalize_intensity(img: np.ndarray) -> np.ndarray:
-    """NormalizeIntensityd(keys=["image"]): (x - mean) / std over the whole image, population std, no division if std == 0."""
-    m, s = float(img.mean(dtype=np.float64)), float(img.std(dtype=np.float64))
-    out = img.astype(np.float32) - np.float32(m)
-    return out / np.float32(s) if s != 0.0 else out
-
-
 def pad_widths(shape: Sequence[int], spatial_size: Sequence[int]) -> List[Tuple[int, int]]:
     """SpatialPadd(method="symmetric"): width w = max(target - size, 0) split as (w // 2, w - w // 2)."""
     out = []
@@ -40,15 +33,6 @@ def pad_widths(shape: Sequence[int], spatial_size: Sequence[int]) -> List[Tuple[
         w = max(int(t) - int(d), 0)
         out.append((w // 2, w - w // 2))
     return out
-
-
-def host_spatial_pad(vol: np.ndarray, spatial_size: Sequence[int]) -> np.ndarray:
-    return np.pad(vol, pad_widths(vol.shape, spatial_size), mode="constant", constant_values=0)
-
-
-def host_flip_crop(vol: np.ndarray, flip: bool, start: Sequence[int], roi: Sequence[int]) -> np.ndarray:
-    v = vol[::-1] if flip else vol
-    return np.ascontiguousarray(v[start[0] : start[0] + roi[0], start[1] : start[1] + roi[1], start[2] : start[2] + roi[2]])
 
 
 class RandomTail:

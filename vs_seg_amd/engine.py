@@ -103,6 +103,8 @@ class _Choice:
     cmod: int = 0  # ... and output channel c is real channel c % cmod for the per-channel vectors
     alt: Optional["_Choice"] = None  # on the first lattice class of a multi-class op: all classes as ONE launch (planner.class_split_plans)
     probe_plan: Optional[P.IgemmPlan] = None  # plan of the last probe lowering (Plan._igemm(probe=True))
+    woff_res: int = 0  # plans with residual tiles (planner.march_res_plans): flat offset of the 1x1x1 residual convolution's weight ...
+    map_off_res: int = -1  # ... and the element offset of its packed weights inside Plan.wpack
 
 
 @dataclass
@@ -281,6 +283,25 @@ class Plan:
                     dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd)
+        # ResidualUnit: the 1x1x1 residual convolution of the SAME input rides along in the unit's first 3x3x1 convolution (vsseg_igemm_desc.res_tiles, csrc/mconv.hip
+        # NR: the input is read once for both, ref:params/networks/blocks/convolutions.py:241-255) where a marching plan with residual tiles is instantiated
+        self.resn: Dict[str, ConvPlain] = {}     # unit convolution prefix -> the residual convolution op riding along
+        self.resn_of: Dict[str, str] = {}        # residual convolution prefix -> unit convolution prefix
+        if eng.resn and eng.es == 2:
+            for op in eng.prog.ops:
+                if not isinstance(op, ConvBnAct) or op.layer.transposed or tuple(op.layer.stride) != (1, 1, 1) or op.layer.kernel != (3, 3, 1) or op.x.parts is not None or op.x.base is not None:
+                    continue
+                Lr = op.layer
+                rc = next((o for o in eng.prog.ops if isinstance(o, ConvPlain) and o.x is op.x and o.layer.kernel == (1, 1, 1) and o.layer.prefix.endswith(".residual") and o.layer.cout == Lr.cout
+                           and o.layer.prefix not in self.merged and o.act == "none" and o.res is None and o.out.kind == "act"), None)
+                if rc is None or len(self.cplans[Lr.prefix].fwd) != 1 or self.cplans[Lr.prefix].fold_fwd:
+                    continue
+                cls = P.lattice_classes("conv_fwd", Lr.kernel, Lr.stride)[0]
+                plans = P.march_res_plans(Lr.wshape, rc.layer.wshape, cls, self.lv[Lr.level], eng.es, op.x.c, self.n)
+                if not plans:
+                    continue
+                self.cplans[Lr.prefix].fwd = [_Choice(plans if self.tune else plans[:1], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape), woff_res=eng.layout.param_off[rc.layer.wkey][0])]
+                self.resn[Lr.prefix], self.resn_of[rc.layer.prefix] = rc, Lr.prefix
 
     def _register(self, ch: _Choice, pl: P.IgemmPlan):
         """Append the chosen plan's weight gather map(s) to the step's pack list."""
@@ -292,6 +313,11 @@ class Plan:
         else:
             self._maps2.append(np.full(pl.pack_map.size, -1, np.int32))
         self._map_len += pl.pack_map.size
+        if pl.res_tiles:  # the residual convolution's tiles: their own gather map behind the main one
+            ch.map_off_res = self._map_len
+            self._maps.append(np.where(pl.pack_map_res >= 0, pl.pack_map_res + ch.woff_res, -1).astype(np.int32))
+            self._maps2.append(np.full(pl.pack_map_res.size, -1, np.int32))
+            self._map_len += pl.pack_map_res.size
 
     def _finish_pack(self):
         eng = self.eng
@@ -315,6 +341,7 @@ class Plan:
             d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
+        d.res_tiles = pl.res_tiles
         d.class_split = len(pl.classes) if pl.classes is not None else 0
         for s_, c_ in enumerate(pl.classes or ()):  # workgroup row s_ = lattice class s_: its output offset and its taps (indices into the union tap table above)
             d.class_oo[s_][0], d.class_oo[s_][1], d.class_oo[s_][2] = c_.oo
@@ -326,7 +353,8 @@ class Plan:
         """Tuned-plan cache lookup (same launch signature measured before, in this process or in a cache file), else measure."""
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
-               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else ""))
+               f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else "")
+               + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else ""))
         cache = _tune_cache()
         hit = cache.get(key)
         # VSSEG_RETUNE_DEPTHS="-6": launches with a candidate plan of one of these depths are measured again although a choice is cached (how the plans of a
@@ -353,6 +381,11 @@ class Plan:
             L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), m.data_ptr(), None, wp.data_ptr(), m.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
             self._fill_desc(d, pl)
             d.wpack = wp.data_ptr()
+            if pl.res_tiles:
+                mr = torch.from_numpy(np.where(pl.pack_map_res >= 0, pl.pack_map_res + ch.woff_res, -1).astype(np.int32)).to(eng.device)
+                wpr = torch.empty(mr.numel(), dtype=eng.tdtype, device=eng.device)
+                L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), mr.data_ptr(), None, wpr.data_ptr(), mr.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
+                d.wpack_res = wpr.data_ptr()
             if lib.vsseg_igemm(C.byref(d), stream):  # a candidate the kernel rejects is simply not chosen
                 times.append(float("inf"))
                 continue
@@ -444,7 +477,7 @@ class Plan:
         return use
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False, res_out: Optional[L.Tensor] = None, bias_res=0):
         """probe: build the launch (plan chosen / measured as usual) WITHOUT making it part of the step — no packed-weight registration, the descriptor
         is only referenced by `lst` (Plan._use_class_split times two alternative lowerings of an op this way; ch.probe_plan = the plan it used)."""
         nb = self.n if nb is None else nb
@@ -460,6 +493,9 @@ class Plan:
         if res is not None:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
+        d.bias_res = bias_res or None
+        if res_out is not None:
+            d.res_out = res_out
         if ch.chosen is not None:  # a further launch of the same lattice class (another sample): same plan, same packed weights
             pl = ch.chosen
         else:
@@ -473,6 +509,8 @@ class Plan:
             d.cout_mod = pl.nc
         if not probe:
             self._wpack_fixups.append((d, ch.map_off))
+            if pl.res_tiles:
+                self._res_fixups.append((d, ch.map_off_res))
             self.keep.append(d)
         nvalid = nb  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
@@ -485,10 +523,13 @@ class Plan:
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
         tuned = " tuned[cache]" if ch.cached else ("" if ch.tuned_ms is None else f" tuned[{ch.cands.index(pl)}/{len(ch.cands)} {ch.tuned_ms[0]:.3f}->{min(ch.tuned_ms):.3f}ms]")
         fold_tag = f" zfold{ch.fold}" if ch.fold else ""
-        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma", flops=2.0 * nvalid * taps_eff * pl.kreal * pl.nc / max(ch.fold, 1),
+        rn = pl.res_tiles * 16 if pl.res_tiles else 0  # output channels of the 1x1x1 residual convolution riding along
+        meta = dict(tag=f"{pl.kind}{fold_tag} q={pl.q} K={pl.kreal}x{pl.ntaps} N={pl.nc}{'+res' + str(rn) if rn else ''} tile={pl.tile} ck={pl.ck} ns={pl.nsplit} D={pl.depth} lds={pl.lds}{tuned}", name=self._igemm_name(pl, inp), kind="mfma",
+                    flops=2.0 * nvalid * (taps_eff * pl.kreal * pl.nc + pl.kreal * rn) / max(ch.fold, 1),
                     # algorithmic bytes: input once + output once (+ the residual / mask / gated operand or the previous gradient an
                     # accumulating launch has to read: one more output-sized tensor)
-                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / (1 if pl.classes is not None else ncls))
+                    bytes=float(nvalid) * pl.nc * es_out * (2 if (accumulate or res is not None) else 1) + float(nb) * inp.x * inp.y * inp.z * pl.kreal * es_in / (1 if pl.classes is not None else ncls)
+                    + (float(nvalid) * rn * es_out if res_out is not None else 0.0))
         lst.append([self.eng.lib.vsseg_igemm, [C.byref(d)], meta])
 
     def _march_cands(self, ch: _Choice, Lr: Layer) -> List[P.IgemmPlan]:
@@ -602,9 +643,13 @@ class Plan:
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
+                rcv = self.resn.get(pre)  # the unit's 1x1x1 residual convolution rides along (same input): stored to its own tensor, or (eval, single-subunit units) added in the epilogue
+                rkw = dict(bias_res=self._pp(rcv.layer.bkey)) if rcv is not None else {}
+                if rcv is not None and (self.train or op.res is not rcv.out):
+                    rkw["res_out"] = self._desc(rcv.out)
                 if self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                    self._igemm_classes(F, cp.fwd, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd))
+                    self._igemm_classes(F, cp.fwd, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd), **rkw)
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
                     if fused_res is not None:
@@ -616,11 +661,13 @@ class Plan:
                                   self._ew_meta("bn_act_fwd", Lr.out_level, (3 if res is not None else 2) * Lr.cout)])
                 else:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
+                    if rcv is not None and op.res is rcv.out:  # out = act(bn(conv(x))) + residual(x) entirely inside the launch: the residual tensor does not exist
+                        res = None
                     self._igemm_classes(F, cp.fwd, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
-                                        res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd))
+                                        res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd), **rkw)
             elif isinstance(op, ConvPlain):
                 Lr, cp = op.layer, self.cplans[op.layer.prefix]
-                if Lr.prefix in self.merged or Lr.prefix in res1_fused:  # computed inside the convolution / elementwise kernel it is added to
+                if Lr.prefix in self.merged or Lr.prefix in res1_fused or Lr.prefix in self.resn_of:  # computed inside the convolution / elementwise kernel it is added to
                     continue
                 absorbed = self.absorbs.get(Lr.prefix)
                 gl = self.gate_onload.get(op.x.name)
@@ -1161,7 +1208,8 @@ class Engine:
         # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip): "0" = off, "1" = every
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
-        self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"  # ... with the unit's 1x1x1 residual convolution riding along
+        self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
+        self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched

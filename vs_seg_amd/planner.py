@@ -113,6 +113,8 @@ class IgemmPlan:
     lds: int
     depth: int = 1
     pack_map: np.ndarray = field(repr=False, default=None)  # int32, -1 = zero
+    res_tiles: int = 0  # marching plans: 16-channel tiles of a 1x1x1 convolution of the same input riding along (march_res_plans) ...
+    pack_map_res: np.ndarray = field(repr=False, default=None)  # ... and their gather map
     classes: Optional[List[LatticeClass]] = field(repr=False, default=None)  # class-split plan: workgroup row s computes lattice class s (cls = their union, oo = 0)
 
     def class_taps(self, s: int) -> List[int]:
@@ -236,6 +238,43 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
                 if (c, t, tz, mt) in MARCH_WREG_SHAPES:  # the same launch with the packed weights in registers (LDS bandwidth back to the operand reads)
                     out.append(dataclasses.replace(pl, depth=-6, lds=march_lds_bytes(kc, nt, tz, mt, True)))
     return out
+
+
+# (input channels, main tiles, residual tiles, TZ, M-tiles per wave): marching launches with the ResidualUnit's 1x1x1 residual convolution riding along (csrc/mconv.hip MC_R)
+MARCH_RES_SHAPES = {(16, 2, 2, 8, 4), (16, 2, 2, 8, 8), (16, 2, 2, 4, 4), (16, 2, 2, 4, 2), (64, 2, 2, 2, 1), (64, 2, 2, 2, 2)}
+
+
+def march_res_plans(wshape, wshape_res, cls, q, es, kc, n=1) -> List["IgemmPlan"]:
+    """Marching plans of a stride-1 3x3x1 forward convolution with `res_tiles` more output tiles of the 1x1x1 convolution `wshape_res` of the same input
+    (vsseg_igemm_desc.res_tiles): the instantiated subset of `march_plans`, each with the residual convolution's packed weights in `pack_map_res`."""
+    kreal, nreal = gemm_dims("conv_fwd", wshape)
+    kr, nr_ch = gemm_dims("conv_fwd", wshape_res)
+    if kr != kreal or tuple(wshape_res[2:]) != (1, 1, 1):
+        return []
+    nr = (nr_ch + 15) // 16
+    out = []
+    for pl in march_plans("conv_fwd", wshape, cls, q, es, kc, nreal, kreal, n):
+        if (kc, pl.nt, nr, pl.tile[2], pl.mtw) in MARCH_RES_SHAPES:
+            r = dataclasses.replace(pl, res_tiles=nr)
+            r.pack_map = pack_map(r, wshape)
+            r.pack_map_res = residual_tile_pack_map(kc, nr, wshape_res)
+            out.append(r)
+    return out
+
+
+def residual_tile_pack_map(kc, nr, wshape_res) -> np.ndarray:
+    """int32 gather map [K-steps of the centre tap][nr][64][8] -> flat index into the 1x1x1 weight (or -1): the K order is the 3x3x1 launch's (tap, 8-channel group),
+    restricted to the K-steps [G, ceil(5G / 4)) that hold the centre tap's groups [4G, 5G) (csrc/mconv.hip KLO / KHI)."""
+    g_ = kc // 8
+    klo, khi = g_, (5 * g_ + 3) // 4
+    kreal, nreal = gemm_dims("conv_fwd", wshape_res)
+    ks, t, lane, j = np.meshgrid(np.arange(klo, khi), np.arange(nr), np.arange(64), np.arange(8), indexing="ij")
+    p = ks * 4 + (lane >> 4)
+    c = (p - 4 * g_) * 8 + j
+    nn = t * 16 + (lane & 15)
+    valid = (p >= 4 * g_) & (p < 5 * g_) & (c < kreal) & (nn < nreal)
+    flat = weight_flat_index("conv_fwd", wshape_res, np.where(valid, c, 0), np.where(valid, nn, 0), 0)
+    return np.where(valid, flat, -1).astype(np.int32).reshape(-1)
 
 
 # (H channels, P channels as stored, TZ, M-tiles per wave) instantiated by csrc/mwgrad.hip; rows per workgroup = 64 * mt / tz
