@@ -164,6 +164,8 @@ typedef struct {
   vsseg_tensor dres;       /* gradient of the residual convolution's output [N][X][Y][Z][cout] */
   const void* wpack_res;   /* packed weights of its data gradient: [ksteps][nt][64][8] bf16 of the conv_dgrad plan of the 1x1x1 convolution (K = cout -> N = cin, one chunk) */
   float* dw_res;           /* IN/OUT: its weight gradient [cout][cin] fp32, += */
+  const float* x_gate;     /* optional fp32 attention map [N][X][Y][Z] of x: x[v] is multiplied by (1 + x_gate[v]) on load (AttentionBlock2 in front of the unit, never
+                            * materialised; x may then be the two-part concat); dx is the gradient of the GATED tensor.  64 input channels with dres == dout only. */
 } vsseg_conv_bwd_desc;
 int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
 

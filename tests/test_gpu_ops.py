@@ -849,6 +849,21 @@ def test_fused_conv_backward_with_residual_convolution(cin, cout, dims, tile, sa
     np.testing.assert_allclose(dw.cpu().reshape(w.shape).numpy(), dw_ref.numpy(), rtol=2e-4, atol=2e-4 * float(dw_ref.abs().max()))
     np.testing.assert_allclose(dwr.cpu().reshape(wr.shape).numpy(), dwr_ref.numpy(), rtol=2e-4, atol=2e-4 * float(dwr_ref.abs().max()))
     np.testing.assert_allclose(dwr.cpu().reshape(wr.shape).numpy(), wrd.grad.float().numpy(), rtol=1e-3, atol=1e-3 * float(wrd.grad.abs().max()))
+    if cin == 64 and same:  # x gated on load from the two-part concat (AttentionBlock2 in front of the unit): bit-identical to the launch on the materialised gated tensor
+        att = torch.rand(n, *dims, device="cuda")
+        gated = torch.empty_like(xcl)
+        L.check(lib.vsseg_att_apply_fwd(H.tdesc(xcl), att.data_ptr(), H.tdesc(gated), S), "att_apply_fwd")
+        parts = H._split_cl(xcl, 32)
+        outs = []
+        for xin, gate in ((H.tdesc(gated), None), (H.two_part(*parts), att.data_ptr())):
+            dxg = torch.full((n, *dims, cin), float("nan"), dtype=torch.bfloat16, device="cuda")
+            dwg, dwrg = torch.zeros_like(dw), torch.zeros_like(dwr)
+            fd.x, fd.dx, fd.dw, fd.dw_res, fd.x_gate = xin, H.tdesc(dxg), dwg.data_ptr(), dwrg.data_ptr(), gate
+            L.check(lib.vsseg_conv_bwd_fused(C.byref(fd), S), "conv_bwd_fused (gated x)")
+            torch.cuda.synchronize()
+            outs.append((dxg, dwg, dwrg))
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs[0], outs[1])) and float(outs[1][1].abs().max()) > 0
+        assert not torch.equal(outs[1][1], dw)  # (the gate does change the weight gradient)
 
 
 @pytest.mark.parametrize("cin,cout,dims,shape,lx", [(16, 32, (6, 64, 16), (8, 4), 4), (16, 32, (5, 128, 8), (4, 4), 5), (16, 32, (7, 32, 8), (4, 2), 3), (64, 32, (5, 64, 4), (2, 2), 2), (64, 32, (6, 32, 6), (2, 1), 6)])
@@ -908,6 +923,23 @@ def test_marching_kernel_with_residual_tiles(cin, cout, dims, shape, lx):
         yy = F.conv3d(x.double(), w.double(), b.double().cpu(), padding=P.same_pad(k)) * sc.double().cpu().view(1, -1, 1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1, 1)
         want = F.prelu(yy, al.double().cpu()) + F.conv3d(x.double(), wr.double(), br.double().cpu())
         np.testing.assert_allclose(H.from_cl(out).numpy(), want.float().numpy(), atol=_tol("bf16", want))
+        if cin == 64:  # + the attention gate applied on load to the two-part concat (the level-1 decoder unit): bit-identical to the launch on the materialised gated tensor
+            att = torch.rand(n, *dims, device="cuda")
+            gated = torch.empty_like(xcl)
+            L.check(lib.vsseg_att_apply_fwd(H.tdesc(xcl), att.data_ptr(), H.tdesc(gated), H.stream()), "att_apply_fwd")
+            parts = H._split_cl(xcl, 32)
+            res = []
+            for inp, kw in ((H.tdesc(gated), {}), (H.two_part(*parts), dict(in_gate=att.data_ptr()))):
+                yg, rg, stg = torch.full_like(y_ref, float("nan")), torch.full_like(y_ref, float("nan")), torch.zeros_like(st_ref)
+                d = H.igemm_desc(mp, wp, inp, H.tdesc(yg), bias=b.data_ptr(), stats=stg.data_ptr(), stats_stride=cout, res_tiles=mp.res_tiles, wpack_res=wpr.data_ptr(), bias_res=br.data_ptr(), res_out=H.tdesc(rg), **kw)
+                L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm + residual tiles + gate")
+                og = torch.full_like(y_ref, float("nan"))
+                d = H.igemm_desc(mp, wp, inp, H.tdesc(og), bias=b.data_ptr(), scale=sc.data_ptr(), shift=sh.data_ptr(), alpha=al.data_ptr(), act=L.ACT_PRELU, res_tiles=mp.res_tiles, wpack_res=wpr.data_ptr(), bias_res=br.data_ptr(), **kw)
+                L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "igemm + residual tiles + gate (eval)")
+                torch.cuda.synchronize()
+                res.append((yg, rg, H.stat_decode(stg).view(L.STAT_SHARDS, 2, -1).sum(0), og))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][3], res[1][3]) and not torch.isnan(res[1][3].float()).any()
+            np.testing.assert_allclose(res[1][2].cpu().numpy(), res[0][2].cpu().numpy(), rtol=1e-6, atol=1e-4)
     # the general kernel refuses the field loudly
     d = H.igemm_desc(gen, wpg, H.tdesc(xcl), H.tdesc(y), res_tiles=2, wpack_res=wpr.data_ptr())
     assert lib.vsseg_igemm(C.byref(d), H.stream()) != 0

@@ -132,6 +132,7 @@ class ConvBwdDesc(C.Structure):
         ("dres", Tensor),
         ("wpack_res", C.c_void_p),
         ("dw_res", C.c_void_p),
+        ("x_gate", C.c_void_p),
     ]
 
 

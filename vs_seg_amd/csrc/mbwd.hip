@@ -29,7 +29,11 @@ constexpr int MB_NR = 4;  // ring slots of dy: planes x-1, x, x+1 + the one bein
 struct MbwdK {
   const char* y; const char* da;       // conv output (before BatchNorm), gradient of the block's output: CY channels each
   const unsigned char* keep;           // keep-mask bytes [voxel][CY / 8] of the forward, or nullptr (no dropout)
-  const char* x;                       // conv input, CX channels
+  const char* x;                       // conv input, CX channels: channels [0, csplit) ...
+  const char* x1;                      // ... and [csplit, CX), biased by -csplit channels (== x for a one-part tensor)
+  int x_csplit_pc;                     // first 16-byte piece of a voxel row that lives in part 1
+  const float* x_gate;                 // XG: fp32 attention map of x: voxel v of x is multiplied by (1 + x_gate[v]) on load (AttentionBlock2 in front of the unit,
+                                       //     ref:params/networks/blocks/attentionblock.py:43-47: the gated tensor is never materialised)
   const float *mean, *invstd, *gamma, *scale, *shift, *alpha, *mean_dz, *mean_dzx;
   float inv_keep;
   const char* wpack;                   // packed weights of the data gradient (K = 9 * CY -> N = CX)
@@ -58,7 +62,7 @@ constexpr int mb_lds_bytes(int CY, int CX, int TZ, int MT, int RES) {
 }
 
 // (one workgroup per CU where the LDS footprint allows no second one anyway: the register budget is then 512 per lane instead of 256)
-template <int CY, int CX, int TZ, int MT, bool UNITSPLIT, int RES>
+template <int CY, int CX, int TZ, int MT, bool UNITSPLIT, int RES, bool XG = false>
 __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 ? 1 : 2) void mbwd_kernel(const MbwdK k) {
   constexpr int GH = CY / 8, GP = CX / 8, RSH = TZ * GH, RSP = TZ * GP, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int NTH = CY / 16, NTP = CX / 16;
@@ -117,8 +121,8 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
     vrel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) hok |= 1u << u;
   }
-  int prel[PINST];
-  unsigned pok = 0;
+  int prel[PINST], pgrel[XG ? PINST : 1];
+  unsigned pok = 0, p1m = 0;
 #pragma unroll
   for (int u = 0; u < PINST; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
@@ -126,7 +130,9 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
     const int pcx = (pp - 2 * (r * RSP / 16)) & (GP - 1);
     const bool ok = j < PSLOTS;
     prel[u] = ok ? (r * Z + z) * k.x_vox_bytes + pcx * 16 : 0;
+    if constexpr (XG) pgrel[u] = ok ? r * Z + z : 0;
     if (ok) pok |= 1u << u;
+    if (ok && pcx >= k.x_csplit_pc) p1m |= 1u << u;
   }
   const float alpha = *k.alpha;
   BnBwdC8 bc;
@@ -139,6 +145,9 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
   const unsigned char* kcol = k.keep ? k.keep + col0 * GH + pc : nullptr;
   const char* rcol = RES == 2 ? k.dr + col0 * k.dr_vox_bytes + pc * 16 : nullptr;
   const char* porg = k.x + col0 * k.x_vox_bytes;
+  const char* porg1 = k.x1 + col0 * k.x_vox_bytes;
+  const float* pgcol = XG ? k.x_gate + col0 : nullptr;
+  float pg[XG ? PINST : 1];
 
   // raw pieces of one dy plane in flight (registers): y, dA (16 bytes each) and the keep-mask byte
   uint4 ry[HINST], rd[HINST], rr2[RES == 2 ? HINST : 1];
@@ -185,12 +194,36 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
       }
     }
   };
-  auto issue_p = [&](int i) {  // plane i of x (always inside the image) into buffer i & 1, by LDS-DMA
-    const char* q = porg + (int64_t)(xb - 1 + i) * plane_vox * k.x_vox_bytes;
+  auto issue_p = [&](int i) {  // plane i of x (always inside the image) into buffer i & 1, by LDS-DMA (XG: its gate values by ordinary loads, issued in front)
+    const int64_t pv = (int64_t)(xb - 1 + i) * plane_vox;
+    if constexpr (XG) {
+#pragma unroll
+      for (int u = 0; u < PINST; ++u) pg[u] = pgcol[pv + pgrel[u]];
+    }
+    const char* q = porg + pv * k.x_vox_bytes;
+    const char* q1 = porg1 + pv * k.x_vox_bytes;
     char* dst = Pl + (i & 1) * PPLANE;
 #pragma unroll
     for (int u = 0; u < PINST; ++u)
-      if ((pok >> u) & 1u) vsseg_dma16(q + prel[u], dst + (u * 4 + wave) * 1024);
+      if ((pok >> u) & 1u) vsseg_dma16(((p1m >> u) & 1u ? q1 : q) + prel[u], dst + (u * 4 + wave) * 1024);
+  };
+  auto gate_p = [&](int i) {  // XG: every thread gates the pieces of x plane i IT fetched, in LDS, in front of the step's barrier (fp32 product rounded to bf16:
+    if constexpr (XG) {          // bit-identical to vsseg_att_apply_fwd)
+      char* dst = Pl + (i & 1) * PPLANE + lane * 16;
+#pragma unroll
+      for (int u = 0; u < PINST; ++u) {
+        if (!((pok >> u) & 1u)) continue;
+        uint4* p = reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024);
+        const uint4 qv = *p;
+        const float gg = 1.f + pg[u];
+        uint4 o;
+        o.x = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.x << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.x & 0xffff0000u), gg));
+        o.y = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.y << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.y & 0xffff0000u), gg));
+        o.z = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.z << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.z & 0xffff0000u), gg));
+        o.w = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.w << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.w & 0xffff0000u), gg));
+        *p = o;
+      }
+    }
   };
 
   // ---- weight gradient: transpose-read addressing (mwgrad.hip).  Lane (g, i = l15): voxel r4 = i >> 2 of a 4-voxel block, 4-channel chunk q = i & 3.
@@ -253,6 +286,7 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
   for (int i = 1; i <= steps; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the raw pieces of plane i+1 and this wave's DMA pieces of x plane i have landed (and the previous step's stores have left)
     store_h(i + 1);                                    // slot (i+1) & 3 held plane i-3: every wave finished reading it before the barrier of step i-1
+    gate_p(i);                                         // (XG) this thread's pieces of x plane i, gate values loaded with the plane's DMAs
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // dy plane i+1 and x plane i are complete for every wave; every wave has finished step i-1
     if (i + 1 <= steps) store_a(i + 1);                // (before the registers are reloaded)
@@ -385,7 +419,26 @@ template <int CY, int CX, int TZ, int MT, bool US, int RES> static int mb_launch
   VSSEG_LAUNCH_CHECK("vsseg_conv_bwd_fused");
   return VSSEG_OK;
 }
+template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch_xg(const MbwdK& k, int grid, hipStream_t s) {  // x gated on load: the level-1 decoder unit (64 -> 32 + residual)
+  static bool init = false;
+  const int lds = mb_lds<CY, CX, TZ, MT, 1>();
+  if (lds > 160 * 1024) { vsseg_set_error("vsseg_conv_bwd_fused: %d bytes of LDS", lds); return VSSEG_EINVAL; }
+  if (!init) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mbwd_kernel<CY, CX, TZ, MT, US, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    init = true;
+  }
+  hipLaunchKernelGGL((mbwd_kernel<CY, CX, TZ, MT, US, 1, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_conv_bwd_fused");
+  return VSSEG_OK;
+}
 template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch(const MbwdK& k, int grid, hipStream_t s) {
+  if (k.x_gate) {
+    if constexpr (CX == 64) {
+      if (k.dr == k.da && k.dr_vox_bytes == k.da_vox_bytes) return mb_launch_xg<CY, CX, TZ, MT, US>(k, grid, s);
+    }
+    vsseg_set_error("vsseg_conv_bwd_fused: the gated input (x_gate) is instantiated for 64 input channels with the residual convolution on dout only");
+    return VSSEG_EINVAL;
+  }
   if (!k.dr) return mb_launch_r<CY, CX, TZ, MT, US, 0>(k, grid, s);
   if constexpr (CX > CY || CY == 32) {  // the units with a 1x1x1 residual convolution: 16 -> 32 (encoder, level 1) and 64 -> 32 (decoder, level 1)
     if (k.dr == k.da && k.dr_vox_bytes == k.da_vox_bytes) return mb_launch_r<CY, CX, TZ, MT, US, 1>(k, grid, s);
@@ -412,7 +465,8 @@ static const MbEntry* mb_find(const vsseg_conv_bwd_desc* d, const char** why) {
   const vsseg_tensor* ts[] = {&d->y, &d->dout, &d->x, &d->dx, &d->dres};
   for (const vsseg_tensor* t : ts) {
     if (t == &d->dres && !t->ptr) continue;
-    if (!t->ptr || t->dtype != VSSEG_BF16 || t->ptr2) return no("tensors must be one-part bf16");
+    if (!t->ptr || t->dtype != VSSEG_BF16 || (t->ptr2 && t != &d->x)) return no("tensors must be one-part bf16 (x may be a two-part tensor)");
+    if (t->ptr2 && (t->csplit <= 0 || t->csplit >= t->c || t->csplit % 16 || ((uintptr_t)t->ptr2 & 15))) return no("bad two-part x");
     if (t->pitch % 8 || ((uintptr_t)t->ptr & 15)) return no("tensor rows must be 16-byte aligned");
     if (t->n != d->y.n || t->x != d->y.x || t->y != d->y.y || t->z != d->y.z) return no("tensor extents differ");
   }
@@ -450,6 +504,9 @@ extern "C" int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream) 
   MbwdK k;
   k.y = reinterpret_cast<const char*>(d->y.ptr); k.da = reinterpret_cast<const char*>(d->dout.ptr); k.keep = d->p_drop > 0.f ? d->keep : nullptr;
   k.x = reinterpret_cast<const char*>(d->x.ptr); k.dx = reinterpret_cast<char*>(d->dx.ptr);
+  k.x1 = d->x.ptr2 ? reinterpret_cast<const char*>(d->x.ptr2) - (int64_t)d->x.csplit * 2 : k.x;
+  k.x_csplit_pc = d->x.ptr2 ? d->x.csplit / 8 : 1 << 20;
+  k.x_gate = d->x_gate;
   k.mean = d->mean; k.invstd = d->invstd; k.gamma = d->gamma; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha; k.mean_dz = d->mean_dz; k.mean_dzx = d->mean_dzx;
   k.inv_keep = 1.f / (1.f - d->p_drop);
   k.wpack = reinterpret_cast<const char*>(d->wpack);

@@ -62,7 +62,7 @@ struct MconvK {
 // the 9-36 KB of LDS they occupied go back to the ring.
 template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
-  constexpr bool STATS = MODE == 1, AUXM = MODE == 2, GIN = MODE == 3;
+  constexpr bool STATS = MODE == 1 || MODE == 4, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
@@ -430,15 +430,27 @@ template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG> static int mc_la
   return VSSEG_OK;
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_launch_res(const MconvK& k, int grid, hipStream_t s) {  // + NR residual tiles: plain / statistics epilogues
-  if (k.in_gate || k.aux_mode) { vsseg_set_error("vsseg_igemm: residual tiles combine with the plain and the statistics epilogue only"); return VSSEG_EINVAL; }
+  if (k.aux_mode) { vsseg_set_error("vsseg_igemm: residual tiles combine with the plain and the statistics epilogue only"); return VSSEG_EINVAL; }
   static bool init = false;
   const int lds = mc_lds<CIN, NT, TZ, MT, WREG>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (CIN == 64) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 3, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 4, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     init = true;
   }
-  if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  if (k.in_gate) {  // the attention gate in front of the unit applied on load (the level-1 decoder unit: 64 input channels)
+    if constexpr (CIN == 64) {
+      if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 4, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
+      else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 3, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    } else {
+      vsseg_set_error("vsseg_igemm: no marching-kernel instantiation with residual tiles and the input gate for this shape");
+      return VSSEG_EINVAL;
+    }
+  } else if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
   else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, NR>), dim3((unsigned)grid), dim3(256), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, residual tiles)");
   return VSSEG_OK;
@@ -490,7 +502,7 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
     const vsseg_tensor& a = d->accumulate ? d->out : d->res;
     if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");
   }
-  if (d->res_tiles && (!d->wpack_res || d->res_tiles < 1 || d->res_tiles > d->nt || d->accumulate || d->res_mode != VSSEG_RES_NONE || d->in_gate || d->out.ptr2 ||
+  if (d->res_tiles && (!d->wpack_res || d->res_tiles < 1 || d->res_tiles > d->nt || d->accumulate || d->res_mode != VSSEG_RES_NONE || d->out.ptr2 ||
                        (d->res_out.ptr && (d->res_out.dtype != VSSEG_BF16 || d->res_out.ptr2 || (d->res_out.c & 3) || d->res_out.c > d->res_tiles * 16 || (d->res_out.pitch & 3)))))
     return no("residual tiles need their packed weights, a plain or statistics epilogue and a one-part bf16 output");
   if (d->res_tiles && !d->res_out.ptr && (d->out.dtype != VSSEG_BF16 || (d->out.c & 3))) return no("residual tiles added in the epilogue need a bf16 output");
@@ -537,7 +549,8 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   VSSEG_CHECK(k.aux_mode != 4 || d->gate, "vsseg_igemm: RES_GATE needs the gate map");
   k.gate = d->gate;
   k.in_gate = d->in_gate;
-  VSSEG_CHECK(!d->in_gate || (!d->stats && !k.aux_mode), "vsseg_igemm: the input gate combines with a plain epilogue only");
+  VSSEG_CHECK(!d->in_gate || !k.aux_mode, "vsseg_igemm: the input gate does not combine with an auxiliary operand");
+  VSSEG_CHECK(!d->in_gate || !d->stats || d->res_tiles, "vsseg_igemm: the input gate combines with statistics only in the residual-tile instantiations");
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;

@@ -619,6 +619,14 @@ class Plan:
                     continue
                 readers = [o for o in ops if isinstance(o, (ConvBnAct, ConvPlain)) and (o.x is g.out or (o.x.parts is not None and g.out in o.x.parts) or o.res is g.out)]
                 readers += [o for o in ops if isinstance(o, AttGate) and (o.x is g.out or (o.x.parts is not None and g.out in o.x.parts))]
+                # (b) a ResidualUnit whose first 3x3x1 convolution carries the unit's 1x1x1 residual convolution as residual tiles (self.resn) and whose backward is the
+                #     fused launch (csrc/mbwd.hip, x gated on load): the level-1 decoder unit.  Both readers of the gated tensor are then one forward launch.
+                unit = [o for o in readers if isinstance(o, ConvBnAct) and o.layer.prefix in self.resn]
+                if (eng.gate_onload_units and len(unit) == 1 and len(readers) == 2 and self.resn[unit[0].layer.prefix] in readers and unit[0].x is g.out and (unit[0].layer.cin, unit[0].layer.cout) == (64, 32)
+                        and g.x.c == 64 and (not self.train or (eng.fused_bwd == "1" and eng.fused_bwd_res and (p_drop == 0.0 or eng.keepmask)
+                                                                and P.fused_bwd_tiles(32, 64, self.lv[unit[0].layer.level], self.n, 48 * 1024 * 1024, res=True)))):
+                    self.gate_onload[g.out.name] = g
+                    continue
                 main = [o for o in readers if isinstance(o, ConvPlain) and o.layer.prefix not in self.merged]
                 if len(main) != 1 or any(o is not main[0] and not (isinstance(o, ConvPlain) and self.merged.get(o.layer.prefix) is main[0]) for o in readers):
                     continue
@@ -638,13 +646,17 @@ class Plan:
         for op in ops:
             if isinstance(op, ConvBnAct):
                 Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
-                xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
+                glu = self.gate_onload.get(op.x.name)  # the attention gate in front of the unit is applied on load: read x (the concat) and the attention map
+                xin, out = (self._desc(glu.x) if glu is not None else self._xdesc(op.x, cp.fold_fwd)), self._desc(op.out)
                 fused_res = plain_by_out[op.res.name] if (op.res is not None and op.res.name in plain_by_out and plain_by_out[op.res.name].layer.prefix in res1_fused) else None
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
                 rm, rv = self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var")
                 rcv = self.resn.get(pre)  # the unit's 1x1x1 residual convolution rides along (same input): stored to its own tensor, or (eval, single-subunit units) added in the epilogue
                 rkw = dict(bias_res=self._pp(rcv.layer.bkey)) if rcv is not None else {}
+                if glu is not None:
+                    assert rcv is not None
+                    rkw["in_gate"] = self._alloc(glu.att, self.bufs).data_ptr()
                 if rcv is not None and (self.train or op.res is not rcv.out):
                     rkw["res_out"] = self._desc(rcv.out)
                 if self.train:
@@ -888,8 +900,10 @@ class Plan:
             x = op.x
             want = eng.fused_bwd
             if (want == "0" or eng.es != 2 or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or x.parts is not None or x.base is not None or x.kind != "act"
-                    or x.root.name == prog.input.name or x.c != Lr.cin or x.name in self.gate_onload or dA.ptr2 or (p_drop > 0.0 and keep_ptr(Lr) is None)):
+                    or x.root.name == prog.input.name or x.c != Lr.cin or dA.ptr2 or (p_drop > 0.0 and keep_ptr(Lr) is None)):
+                assert x.name not in self.gate_onload, "a unit behind an attention gate applied on load must run the fused backward"
                 return False
+            glx = self.gate_onload.get(x.name)  # x is an attention-gated tensor that was never materialised: the launch reads the concat and the attention map
             if want != "1" and f"{Lr.cin}x{Lr.cout}" not in want.split(","):
                 return False
             scr = self.eng.fused_scratch()  # (its own slabs: the launch runs on the main stream, concurrently with the side stream's weight gradients)
@@ -907,7 +921,8 @@ class Plan:
             tiles = P.fused_bwd_tiles(Lr.cout, Lr.cin, self.lv[Lr.level], self.n, scr.numel(), res=dres is not None)
             cls = P.lattice_classes("conv_dgrad", Lr.kernel, Lr.stride)[0]
             mps = P.march_plans("conv_dgrad", Lr.wshape, cls, self.lv[Lr.level], eng.es, Lr.cout, Lr.cin, Lr.cout, self.n)  # (the packed-weight layout of the data gradient)
-            if not tiles or not mps or written.get(x.root.name):
+            if not tiles or not mps or written.get(x.root.name) or (glx is not None and dres is None):
+                assert glx is None, "a unit behind an attention gate applied on load must run the fused backward with its residual convolution"
                 return False
             assert contribution(x) == 0
             mp = mps[0]
@@ -915,7 +930,9 @@ class Plan:
             ch = _Choice([mp], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape))
             self._register(ch, mp)
             d = L.ConvBwdDesc()
-            d.y, d.dout, d.x, d.dx = yd, dA, self._desc(x), gdesc(x)
+            d.y, d.dout, d.x, d.dx = yd, dA, self._desc(glx.x if glx is not None else x), gdesc(x)
+            if glx is not None:
+                d.x_gate = self._alloc(glx.att, self.bufs).data_ptr()
             d.mean, d.invstd, d.gamma, d.scale, d.shift, d.alpha = vptr(0, pre), vptr(1, pre), self._pp(pre + ".norm.weight"), vptr(2, pre), vptr(3, pre), self._pp(pre + ".act.weight")
             d.mean_dz, d.mean_dzx, d.p_drop, d.keep = vptr(4, pre), vptr(5, pre), p_drop, keep_ptr(Lr)
             d.dw = self._gp(Lr.wkey)
@@ -933,7 +950,7 @@ class Plan:
                 res_tag = f" +res[{'dA' if sink is op else 'unit dA'}]"
             tile, tuned = tiles[0], ""
             if self.tune and len(tiles) > 1:
-                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}" + ("|res" if res_tag else "")
+                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}" + ("|res" if res_tag else "") + ("|xg" if glx is not None else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     tile, tuned = tuple(cache[key]), " tuned[cache]"
@@ -1210,6 +1227,7 @@ class Engine:
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
+        self.gate_onload_units = os.environ.get("VSSEG_GATE_ONLOAD_UNITS", "1") != "0"  # ... also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched
