@@ -36,6 +36,9 @@ extern "C" {
 #define VSSEG_RES_GATE 3     /* out = acc + res * (1 + gate[voxel])     (backward of AttentionBlock2 `att*x + x`, ref:.../attentionblock.py:43-47, fused
                               *  into the data gradient of the attention branch's first convolution: both flow into d(x))                          */
 
+#define VSSEG_RES_IN1 5      /* out = f(acc) + in1[voxel] * in1_w[c] + in1_b[c]: a 1x1x1 convolution of a ONE-channel tensor added behind the activation (the first
+                              *  ResidualUnit's residual convolution of the network input, ref:.../convolutions.py:241-255 with in_channels = 1): marching kernel only */
+
 #define VSSEG_SEED_INDIRECT 0x80000000u /* OR-ed into a dropout `salt`: the `seed` argument is then the DEVICE ADDRESS of the 64-bit seed */
 
 #define VSSEG_MAX_TAPS 27
@@ -112,6 +115,9 @@ typedef struct {
   const void* wpack_res;   /* [K-steps of the centre tap][res_tiles][64 lanes][8] in the compute dtype (planner.residual_tile_pack_map) */
   const float* bias_res;   /* [res_out.c] or NULL */
   vsseg_tensor res_out;
+  const void* in1;         /* VSSEG_RES_IN1: one-channel tensor [N][X][Y][Z] in the compute dtype (bf16) */
+  const float* in1_w;      /* [cout] weights and */
+  const float* in1_b;      /* [cout] bias of the 1 -> cout convolution */
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).

@@ -122,7 +122,8 @@ def golden_net_eval(only=None):
 def golden_net_train(only=None):
     """One training-mode fwd + loss + bwd with dropout p=0 (torch's dropout stream cannot be reproduced elsewhere)."""
     for name, att, hard, seed, shape in [("b2_32x32x8", True, True, 21, (2, 1, 32, 32, 8)), ("b2_32x32x8_noatt_nohard", False, False, 22, (2, 1, 32, 32, 8)), ("b1_64x64x16", True, True, 23, (1, 1, 64, 64, 16)),
-                                         ("b1_384x128x128", True, True, 24, (1, 1, 384, 128, 128))]:  # the benchmark patch: sub-samples + checksums only
+                                         ("b1_384x128x128", True, True, 24, (1, 1, 384, 128, 128)),  # the benchmark patch: sub-samples + checksums only
+                                         ("b1_384x384x64", True, True, 25, (1, 1, 384, 384, 64))]:  # the reference's own default patch (ref:params/VSparams.py:76, train_batch_size 1)
         if only and name not in only:
             continue
         big = int(np.prod(shape)) > 1_000_000

@@ -12,7 +12,7 @@ SO_PATH = os.environ.get("VSSEG_LIB_PATH") or os.path.join(_HERE, "libvsseg_hip.
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_PRELU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
-RES_NONE, RES_ADD, RES_RELUMASK, RES_GATE = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_RELUMASK, RES_GATE, RES_IN1 = 0, 1, 2, 3, 5
 MAX_TAPS = 27
 STAT_SHARDS = 256
 SEED_INDIRECT = 0x80000000
@@ -77,6 +77,9 @@ class IgemmDesc(C.Structure):
         ("wpack_res", C.c_void_p),
         ("bias_res", C.c_void_p),
         ("res_out", Tensor),
+        ("in1", C.c_void_p),
+        ("in1_w", C.c_void_p),
+        ("in1_b", C.c_void_p),
     ]
 
 

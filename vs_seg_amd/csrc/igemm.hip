@@ -191,6 +191,7 @@ extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
 
 extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
   VSSEG_CHECK(!d || !d->in_gate || d->depth == -5 || d->depth == -6, "vsseg_igemm: the input gate (in_gate) needs a marching-kernel plan (depth -5 / -6)");
+  VSSEG_CHECK(!d || d->res_mode != VSSEG_RES_IN1 || d->depth == -5 || d->depth == -6, "vsseg_igemm: VSSEG_RES_IN1 needs a marching-kernel plan (depth -5 / -6)");
   VSSEG_CHECK(!d || !d->res_tiles || d->depth == -5 || d->depth == -6, "vsseg_igemm: residual tiles (res_tiles) need a marching-kernel plan (depth -5 / -6)");
   if (d && (d->depth == -2 || d->depth == -4)) {  // streaming kernel (sconv.hip; -4: fused output-parity classes): fails loudly when the launch is outside its domain, never falls back
     VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");

@@ -33,6 +33,8 @@ struct MconvK {
   const char* aux0; const char* aux1;
   const float* gate;
   const float* in_gate;  // GIN: fp32 attention map of the INPUT tensor: voxel v is multiplied by (1 + in_gate[v]) on load
+  const bf16_t* x1c;     // aux_mode 5: one-channel tensor [N][X][Y][Z]; out += x1c[voxel] * in1_w[c] + in1_b[c] behind the activation (the first ResidualUnit's 1x1x1
+  const float *in1_w, *in1_b;  // residual convolution of the ONE-channel network input, ref:params/networks/blocks/convolutions.py:241-255 with in_channels = 1)
   const char* wpack;
   const float *bias, *bias2, *scale, *shift, *alpha;
   double* stats;
@@ -98,6 +100,8 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     epi[i] = ((ok && k.bias) ? k.bias[cv] : 0.f) + ((ok && k.bias2) ? k.bias2[cv] : 0.f);
     epi[NT * 16 + i] = (ok && k.scale) ? k.scale[cv] : 1.f;
     epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[cv] : 0.f;
+    epi[3 * NT * 16 + i] = (ok && k.in1_w) ? k.in1_w[cv] : 0.f;
+    epi[4 * NT * 16 + i] = (ok && k.in1_b) ? k.in1_b[cv] : 0.f;
   }
   const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
   bf16x8 wres[NR ? KR : 1][NR ? NR : 1];
@@ -213,12 +217,12 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int64_t vox = vox0 + (int64_t)m * RPM * Z;
-        gv[m] = k.aux_mode == 4 ? k.gate[vox] : 0.f;
+        gv[m] = k.aux_mode == 4 ? k.gate[vox] : (k.aux_mode == 5 ? bf2f(k.x1c[vox]) : 0.f);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int c = t * 16 + g * 4;
           const char* ap = (t * 16 >= k.aux_csplit ? k.aux1 : k.aux0) + vox * k.aux_vox_bytes + c * 2;
-          av[m][t] = c < cout ? *reinterpret_cast<const uint2*>(ap) : make_uint2(0u, 0u);
+          av[m][t] = (c < cout && k.aux_mode != 5) ? *reinterpret_cast<const uint2*>(ap) : make_uint2(0u, 0u);
         }
       }
     }
@@ -336,6 +340,10 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
             const float4 av = make_float4(__uint_as_float(a.x << 16), __uint_as_float(a.x & 0xffff0000u), __uint_as_float(a.y << 16), __uint_as_float(a.y & 0xffff0000u));
             if (KIND == 1 || (KIND == 2 && k.aux_mode == 3)) {
               val[0] = av.x > 0.f ? val[0] : 0.f; val[1] = av.y > 0.f ? val[1] : 0.f; val[2] = av.z > 0.f ? val[2] : 0.f; val[3] = av.w > 0.f ? val[3] : 0.f;
+            } else if (KIND == 2 && k.aux_mode == 5) {  // + x1 * w[c] + b[c]: the 1 -> C residual convolution, never materialised
+              const float4 w1 = *reinterpret_cast<const float4*>(epi + 3 * NT * 16 + c), b1 = *reinterpret_cast<const float4*>(epi + 4 * NT * 16 + c);
+              const float x1 = gatev[m];
+              val[0] += x1 * w1.x + b1.x; val[1] += x1 * w1.y + b1.y; val[2] += x1 * w1.z + b1.z; val[3] += x1 * w1.w + b1.w;
             } else if (KIND == 2 && k.aux_mode != 4) {
               val[0] += av.x; val[1] += av.y; val[2] += av.z; val[3] += av.w;
             } else {
@@ -498,7 +506,9 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
   if (d->stats && (d->accumulate || d->res_mode != VSSEG_RES_NONE)) return no("statistics combined with a residual");
   if (d->accumulate && d->res_mode != VSSEG_RES_NONE) return no("accumulate combined with a residual");
-  if (d->accumulate || d->res_mode != VSSEG_RES_NONE) {
+  if (d->res_mode == VSSEG_RES_IN1) {
+    if (!d->in1 || !d->in1_w || !d->in1_b || (d->out.c & 3) || d->out.dtype != VSSEG_BF16 || d->accumulate || d->stats) return no("RES_IN1 needs in1 / in1_w / in1_b and a bf16 output");
+  } else if (d->accumulate || d->res_mode != VSSEG_RES_NONE) {
     const vsseg_tensor& a = d->accumulate ? d->out : d->res;
     if ((d->out.c & 3) || (a.pitch & 3) || a.c < d->out.c || a.dtype != VSSEG_BF16) return no("auxiliary tensor layout / dtype");
   }
@@ -539,7 +549,9 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   else if (d->res_mode == VSSEG_RES_ADD) k.aux_mode = 2;
   else if (d->res_mode == VSSEG_RES_RELUMASK) k.aux_mode = 3;
   else if (d->res_mode == VSSEG_RES_GATE) k.aux_mode = 4;
-  if (k.aux_mode) {
+  else if (d->res_mode == VSSEG_RES_IN1) k.aux_mode = 5;
+  k.x1c = reinterpret_cast<const bf16_t*>(d->in1); k.in1_w = d->in1_w; k.in1_b = d->in1_b;
+  if (k.aux_mode && k.aux_mode != 5) {
     const vsseg_tensor& a = d->accumulate ? d->out : d->res;
     k.aux0 = reinterpret_cast<const char*>(a.ptr);
     k.aux1 = a.ptr2 ? reinterpret_cast<const char*>(a.ptr2) - (int64_t)a.csplit * 2 : k.aux0;

@@ -477,7 +477,8 @@ class Plan:
         return use
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
-               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False, res_out: Optional[L.Tensor] = None, bias_res=0):
+               res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False, res_out: Optional[L.Tensor] = None, bias_res=0,
+               in1=None):
         """probe: build the launch (plan chosen / measured as usual) WITHOUT making it part of the step — no packed-weight registration, the descriptor
         is only referenced by `lst` (Plan._use_class_split times two alternative lowerings of an op this way; ch.probe_plan = the plan it used)."""
         nb = self.n if nb is None else nb
@@ -494,6 +495,8 @@ class Plan:
             d.res = res
         d.stats, d.stats_stride = stats or None, stats_stride
         d.bias_res = bias_res or None
+        if in1 is not None:  # VSSEG_RES_IN1: (one-channel tensor, weights, bias) of a 1 -> C 1x1x1 convolution added behind the activation
+            d.in1, d.in1_w, d.in1_b = in1
         if res_out is not None:
             d.res_out = res_out
         if ch.chosen is not None:  # a further launch of the same lattice class (another sample): same plan, same packed weights
@@ -608,6 +611,18 @@ class Plan:
                     if pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None:
                         res1_fused[pr.layer.prefix] = pr
 
+        # ... and in eval inside the epilogue of the convolution it is added to (VSSEG_RES_IN1), where that convolution has a marching plan
+        self.eval_in1: Dict[str, ConvPlain] = {}  # prefix of the convolution whose epilogue adds the residual -> the residual convolution op
+        if not self.train and eng.res1_fuse and eng.es == 2 and not eng.dry_run:
+            for op in ops:
+                if isinstance(op, ConvBnAct) and op.res is not None and op.res.name in plain_by_out and op.x.parts is None and op.x.base is None:
+                    pr = plain_by_out[op.res.name]
+                    cpo = self.cplans[op.layer.prefix]
+                    if (pr.layer.cin == 1 and pr.layer.kernel == (1, 1, 1) and pr.x.root.name == prog.input.name and pr.act == "none" and pr.res is None and op.layer.kernel == (3, 3, 1)
+                            and tuple(op.layer.stride) == (1, 1, 1) and not op.layer.transposed and len(cpo.fwd) == 1 and not cpo.fold_fwd and op.layer.prefix not in self.resn and self._march_cands(cpo.fwd[0], op.layer)):
+                        self.eval_in1[op.layer.prefix] = pr
+                        res1_fused[pr.layer.prefix] = pr  # (its own launch is skipped)
+
         # Attention gates applied ON LOAD (ref:params/networks/blocks/attentionblock.py:43-47: out = att.repeat(C) * x + x): where the gated tensor's only
         # reader is ONE stride-1 3x3x1 convolution (with its merged 1x1x1 residual) that runs on the marching kernel, that convolution and its weight
         # gradient read x and the attention map and multiply in LDS (csrc/mconv.hip MODE 3, csrc/mwgrad.hip GIN): vsseg_att_apply_fwd is not launched and
@@ -675,6 +690,14 @@ class Plan:
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [gam, bet, rm, rv, BN_EPS, vptr(2, pre), vptr(3, pre), Lr.cout]])  # depends on parameters only
                     if rcv is not None and op.res is rcv.out:  # out = act(bn(conv(x))) + residual(x) entirely inside the launch: the residual tensor does not exist
                         res = None
+                    pr1 = self.eval_in1.get(pre)
+                    if pr1 is not None:  # the first ResidualUnit: its 1 -> C residual convolution of the network input is x1 * w + b in this launch's epilogue (marching plans only)
+                        ch0 = cp.fwd[0]
+                        cp.fwd[0] = _Choice(self._march_cands(ch0, Lr), ch0.woff, wshape=ch0.wshape)
+                        x1 = self._xdesc(pr1.x, True)
+                        self._igemm(F, cp.fwd[0], xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res_mode=L.RES_IN1,
+                                    in1=(x1.ptr, self._pp(pr1.layer.wkey), self._pp(pr1.layer.bkey)))
+                        continue
                     self._igemm_classes(F, cp.fwd, xin, out, bias=self._pp(Lr.bkey), scale=vptr(2, pre), shift=vptr(3, pre), alpha=alp, act=L.ACT_PRELU, res=res,
                                         res_mode=L.RES_ADD if res is not None else L.RES_NONE, ncls=len(cp.fwd), **rkw)
             elif isinstance(op, ConvPlain):
