@@ -8,7 +8,9 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -- python $R/bench.py --steps 2 --warmu
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/write.log 2>&1
 (cd $R && python tools/rocprof_summary.py pmc $OUT/fetch/*/*.db $OUT/write/*/*.db $OUT/roofline_traffic.json > $OUT/pmc_hbm.txt && cp $OUT/roofline_traffic.json profiles/roofline_traffic.json)
 python $R/bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --steps 5 --warmup 2 $TRAIN > $OUT/kt.log 2>&1
+# kernel trace of the training steps with ONE stream and eager launches (VSSEG_OVERLAP=0 VSSEG_GRAPHS=0): no kernel shares the GPU with a concurrent weight gradient,
+# so the per-kernel durations of kernel_stats.txt are clean (the product's default schedule — two streams, hipGraph replay — is what bench.json times)
+VSSEG_OVERLAP=0 VSSEG_GRAPHS=0 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $R/bench.py --steps 5 --warmup 2 $TRAIN > $OUT/kt.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/kts -- python $R/tools/profile_eval.py 8 > $OUT/kts.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/sfetch -- python $R/tools/profile_eval.py 2 > $OUT/sfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/swrite -- python $R/tools/profile_eval.py 2 > $OUT/swrite.log 2>&1

@@ -26,9 +26,12 @@ def bench_name(short_name):
     m = re.match(r"sconv_kernel<(\d+), (\d+), (\d+), \d+>", short_name)  # streaming kernel: the MODE / tap / input-channel variants of one NT share a bench name
     if m:
         return f"sconv<bf16,{m.group(2)}>"
-    m = re.match(r"mconv_kernel<(\d+), (\d+), (\d+), (\d+), \d+>", short_name)  # marching kernel: (CIN, NT, TZ, MT, MODE) variants of one NT share a bench name
+    m = re.match(r"mconv_kernel<(\d+), (\d+), (\d+), (\d+), \d+(, \w+)*>", short_name)  # marching kernel: (CIN, NT, TZ, MT, MODE, WREG, NR) variants of one NT share a bench name
     if m:
         return f"mconv<bf16,{m.group(2)}>"
+    m = re.match(r"mbwd_kernel<(\d+), (\d+), ", short_name)  # fused backward (BatchNorm backward on load + data gradient + weight gradient): (tiles of the outputs, tiles of the inputs)
+    if m:
+        return f"mbwd<bf16,{int(m.group(1)) // 16},{int(m.group(2)) // 16}>"
     m = re.match(r"mwgrad_kernel<(\d+), (\d+), ", short_name)  # marching weight gradient: bench name by the P tiles (ntp = max(1, CP / 16))
     if m:
         return f"mwgrad<bf16,{max(1, int(m.group(2)) // 16)}>"
