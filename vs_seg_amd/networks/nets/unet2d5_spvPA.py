@@ -211,8 +211,19 @@ class UNet2d5_spvPA(nn.Module):
         eval forwards of this model issued on different HIP streams use separate plans (activation buffers, packed weights, hipGraph), so the
         inferer may keep two window groups in flight (vs_seg_amd.inferers.sliding_window_inference, `concurrent_groups`)."""
 
-        def predictor(*a, **k):
-            return self(*a, **k)[0]
+        def predictor(x):
+            # logits only, as a VIEW of the stream's own plan buffer (no copy of the logits, no copies of the six attention maps the inferer never looks at):
+            # valid until the next call on the same HIP stream — the inferer blends a group's segmentation before it lets that stream run its next group
+            if self.training or torch.is_grad_enabled():
+                return self(x)[0]
+            if not x.is_cuda:
+                raise RuntimeError("vs_seg_amd.UNet2d5_spvPA runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
+            self._ensure_flat()
+            keep, self.reuse_output_buffers = self.reuse_output_buffers, True
+            try:
+                return self._run_forward(x, False)[1][0]
+            finally:
+                self.reuse_output_buffers = keep
 
         predictor.stream_safe = True
         return predictor
