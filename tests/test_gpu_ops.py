@@ -620,6 +620,7 @@ MARCH_CASES = [
     ("conv_fwd", 64, 32, (5, 64, 4), 32, (2, 2), 2),
     ("conv_fwd", 1, 16, (6, 64, 8), 0, (8, 8), 3),        # the network input, zero-extended to one 8-channel group
     ("conv_dgrad", 32, 2, (5, 128, 4), 0, (4, 8), 5),     # data gradient of the logits convolution: K = 2 (-> 8), N = 32
+    ("conv_dgrad", 16, 1, (6, 64, 8), 0, (8, 4), 3),      # data gradient of an attention sigmoid convolution: K = 1 (-> 8), N = 16; also from the COMPACT one-channel gradient
 ]
 
 
@@ -696,6 +697,27 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
             if mode == "stats":
                 a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
                 np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+        if kreal == 1 and mode in ("plain", "stats", "relu_mask", "accumulate"):
+            # one real input channel: the marching kernel also reads the COMPACT one-channel tensor (2 bytes per voxel instead of the zero-extended 16): bit-identical
+            compact = inp_cl[..., :1].contiguous()
+            out = res_t.clone() if mode == "accumulate" else torch.full((2, *dims, nout), float("nan"), dtype=odt, device="cuda")
+            kw, stats = {}, None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "accumulate":
+                kw = dict(accumulate=1)
+            elif mode == "relu_mask":
+                kw = dict(res=H.tdesc(res_t), res_mode=L.RES_RELUMASK)
+            if bias is not None:
+                kw["bias"] = bias.data_ptr()
+            wp = H.pack(mps[0], w, inp_cl.dtype)
+            d = H.igemm_desc(mps[0], wp, H.tdesc(compact), H.tdesc(out), **kw)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm compact input {mode}")
+            torch.cuda.synchronize()
+            assert torch.equal(out, og), f"{mode}: compact one-channel input differs (max {float((out.float() - og.float()).abs().max())})"
+            if mode == "stats":
+                np.testing.assert_allclose(H.stat_decode(stats).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
 FUSED_BWD_CASES = [

@@ -590,7 +590,7 @@ __global__ void att_apply_bwd_kernel(const T* __restrict__ x0, const T* __restri
     if (live && sub == 0) {
       if (datt_ext) dot += datt_ext[v];
       const float r = dot * a * (1.f - a);
-      st8(dpre + v * dprep, f8{{r, 0, 0, 0, 0, 0, 0, 0}});
+      if (dpre) st8(dpre + v * dprep, f8{{r, 0, 0, 0, 0, 0, 0, 0}});  // (nullptr: every consumer reads the compact copy)
       if (dpre1) Elem<T>::st(dpre1 + v, r);  // compact 1-channel copy for the z-folded data gradient of the sigmoid convolution
       bsum += r;
     }
@@ -620,8 +620,8 @@ template <typename T, bool ACC> static void att_bwd_launch(int G, dim3 g, dim3 b
 #undef VSSEG_ATT_BWD
 }
 extern "C" int vsseg_att_apply_bwd(vsseg_tensor x, const float* att, vsseg_tensor dout, const float* datt_ext, vsseg_tensor dx, int32_t accumulate_dx, vsseg_tensor dpre, float* dbias, void* dpre1, void* stream) {
-  VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && dpre.ptr && x.dtype == dout.dtype && x.dtype == dx.dtype && x.dtype == dpre.dtype && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 && dpre.c == 8 &&
-                  x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && dpre.pitch % 8 == 0 && x.c <= 256,
+  VSSEG_CHECK(x.ptr && att && dout.ptr && dx.ptr && (dpre.ptr || dpre1) && x.dtype == dout.dtype && x.dtype == dx.dtype && (!dpre.ptr || (x.dtype == dpre.dtype && dpre.c == 8 && dpre.pitch % 8 == 0)) && x.c == dout.c && x.c == dx.c && x.c % 8 == 0 &&
+                  x.pitch % 8 == 0 && dout.pitch % 8 == 0 && dx.pitch % 8 == 0 && x.c <= 256,
               "vsseg_att_apply_bwd: bad arguments");
   int cgs = x.c / 8;
   int G = 1;

@@ -62,8 +62,12 @@ struct MconvK {
 // With few M-tiles per wave the K loop re-reads every weight fragment from LDS at every x step — on the 64 -> 32 layers (MT = 1, 36 fragments per
 // step and wave against 18 operand fragments) two thirds of the LDS bandwidth the launch is bound by; in registers they cost nothing per step and
 // the 9-36 KB of LDS they occupied go back to the ring.
-template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0>
+// C1 (CIN 8 only): the input is a COMPACT one-channel tensor [N][X][Y][Z] (2 bytes per voxel: the network input, the pre-sigmoid gradient of an attention map) instead
+// of its zero-extension to one 8-channel group (16 bytes per voxel, 7/8 of them zeros read from HBM): the thread that owns a plane slot loads the voxel's value one step
+// ahead (ordinary load into a register) and writes the zero-extended 16-byte piece into the ring itself.
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, bool C1 = false>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
+  static_assert(!C1 || CIN == 8, "compact one-channel inputs are one zero-extended channel group");
   constexpr bool STATS = MODE == 1 || MODE == 4, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     const int pc = (pp - 2 * (r * RS / 16)) & (G - 1);
     const int gy = y0 + r - 1;
     const bool ok = j < PLANE_SLOTS && (unsigned)gy < (unsigned)Y;
-    rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + pc * 16 : 0;
+    rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + (C1 ? 0 : pc * 16) : 0;
     if constexpr (GIN) grel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) okmask |= 1u << u;
     if (ok && pc >= k.in_csplit_pc) p1mask |= 1u << u;
@@ -148,6 +152,28 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
     for (int u = 0; u < NINST; ++u)
       if ((okmask >> u) & 1u) vsseg_dma16(inside ? (const void*)(((p1mask >> u) & 1u ? p1 : p0) + rel[u]) : k.zeros, dst + (u * 4 + wave) * 1024);
+  };
+
+  // C1: the one-channel values of this thread's slots of plane i -> registers; -> zero-extended 16-byte pieces in ring slot i & 3 (planes / rows outside the image: zero)
+  auto loadc = [&](int i, unsigned (&cv)[C1 ? NINST : 1]) {
+    if constexpr (C1) {
+      const int x = xb - 1 + i;
+      const bool inside = (unsigned)x < (unsigned)X;
+      const char* p0 = org0 + (int64_t)(inside ? x : 0) * plane_stride;
+#pragma unroll
+      for (int u = 0; u < NINST; ++u) {  // unconditional loads from valid addresses, the zero padding is a select on the loaded value
+        const unsigned v = *reinterpret_cast<const unsigned short*>(p0 + rel[u]);
+        cv[u] = (inside && ((okmask >> u) & 1u)) ? v : 0u;
+      }
+    }
+  };
+  auto storec = [&](int i, const unsigned (&cv)[C1 ? NINST : 1]) {
+    if constexpr (C1) {
+      char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES + lane * 16;
+#pragma unroll
+      for (int u = 0; u < NINST; ++u)
+        if ((u * 4 + wave) * 64 + lane < PLANE_SLOTS) *reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024) = make_uint4(cv[u], 0u, 0u, 0u);
+    }
   };
 
   // GIN: the gate values of this thread's pieces of plane i (ordinary loads, issued in FRONT of the plane's DMAs), and the in-place product
@@ -235,9 +261,19 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   load_gate(0, gin0);
   load_gate(1, gin1);
   load_gate(2, gin);
-  issue(0);
-  issue(1);
-  issue(2);
+  unsigned cv0[C1 ? NINST : 1], cv1[C1 ? NINST : 1], cvn[C1 ? NINST : 1];
+  if constexpr (C1) {
+    loadc(0, cv0);
+    loadc(1, cv1);
+    loadc(2, cvn);
+    storec(0, cv0);
+    storec(1, cv1);
+    storec(2, cvn);
+  } else {
+    issue(0);
+    issue(1);
+    issue(2);
+  }
   if constexpr (GIN) {  // the three prologue planes are gated once they have landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     apply_gate(0, gin0);
@@ -251,9 +287,16 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
       if (i > 1) apply_gate(i + 1, gin);                 // ... and are gated by the thread that fetched them
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if constexpr (C1) {
+      if (i > 1) storec(i + 1, cvn);                     // ... (C1) or are written as zero-extended pieces by the thread that loaded the values
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                        // ... everybody's; and every wave has finished reading plane i-2
     if (i < steps) load_aux(i + 1, auxn, gaten);         // next step's auxiliary operand, in front of the DMAs
-    if (i + 2 <= steps + 1) { load_gate(i + 2, gin); issue(i + 2); }
+    if (i + 2 <= steps + 1) {
+      if constexpr (C1) loadc(i + 2, cvn);
+      else { load_gate(i + 2, gin); issue(i + 2); }
+    }
     const int sm1 = ((i - 1) & (MC_NR - 1)) * PLANE_BYTES, s0 = (i & (MC_NR - 1)) * PLANE_BYTES, sp1 = ((i + 1) & (MC_NR - 1)) * PLANE_BYTES;
 
     f32x4 acc[MT][NT];
@@ -463,6 +506,23 @@ template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_laun
   VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, residual tiles)");
   return VSSEG_OK;
 }
+template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_c1_mode(const MconvK& k, int grid, hipStream_t s) {
+  static bool init = false;
+  const int lds = mc_lds<CIN, NT, TZ, MT, false>();
+  if (!init) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    init = true;
+  }
+  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, compact one-channel input)");
+  return VSSEG_OK;
+}
+template <int CIN, int NT, int TZ, int MT> static int mc_launch_c1(const MconvK& k, int grid, hipStream_t s) {  // compact one-channel input (CIN 8 entries)
+  if (k.in_gate) { vsseg_set_error("vsseg_igemm: the input gate does not combine with a compact one-channel input"); return VSSEG_EINVAL; }
+  if (k.stats) return mc_launch_c1_mode<CIN, NT, TZ, MT, 1>(k, grid, s);
+  if (k.aux_mode) return mc_launch_c1_mode<CIN, NT, TZ, MT, 2>(k, grid, s);
+  return mc_launch_c1_mode<CIN, NT, TZ, MT, 0>(k, grid, s);
+}
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.in_gate) {
     if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3, WREG>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
@@ -474,15 +534,16 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const
 }
 
 typedef int (*mc_fn_t)(const MconvK&, int, hipStream_t);
-struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg; int (*lds_wreg)(); int nr; };
+struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg; int (*lds_wreg)(); int nr; mc_fn_t fn_c1; };
 #define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, nullptr, nullptr}
+#define MC_1(N, Z, M) {8, N, Z, M, mc_launch<8, N, Z, M, false>, mc_lds<8, N, Z, M, false>, nullptr, nullptr, 0, mc_launch_c1<8, N, Z, M>}  // one zero-extended channel group, also from a COMPACT one-channel tensor
 #define MC_W(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, mc_launch<C, N, Z, M, true>, mc_lds<C, N, Z, M, true>}  // + the depth -6 twin (weights in registers)
 #define MC_R(C, N, R, Z, M) {C, N, Z, M, mc_launch_res<C, N, Z, M, false, R>, mc_lds<C, N, Z, M, false>, mc_launch_res<C, N, Z, M, true, R>, mc_lds<C, N, Z, M, true>, R}  // + R residual tiles (res_tiles)
 // (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
 static const McEntry mc_table[] = {
-    MC_E(8, 1, 8, 8), MC_E(8, 2, 8, 8), MC_E(8, 1, 4, 8), MC_E(8, 2, 4, 8), MC_E(8, 1, 4, 4), MC_E(8, 2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
+    MC_1(1, 8, 8), MC_1(2, 8, 8), MC_1(1, 4, 8), MC_1(2, 4, 8), MC_1(1, 4, 4), MC_1(2, 4, 4),  // 1 / 2 real channels zero-extended to one 8-channel group -> 16 / 32
     MC_E(16, 1, 4, 8), MC_E(16, 1, 4, 4), MC_E(16, 2, 4, 8), MC_E(16, 2, 4, 4), MC_E(16, 2, 8, 8), MC_E(16, 1, 8, 8),  // 16 -> 16 / 32 (levels 0, 1)
-    MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_W(16, 2, 4, 2), MC_W(16, 2, 8, 4), MC_W(32, 1, 4, 2), MC_W(32, 2, 4, 2), MC_E(8, 1, 8, 4), MC_E(8, 2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
+    MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_W(16, 2, 4, 2), MC_W(16, 2, 8, 4), MC_W(32, 1, 4, 2), MC_W(32, 2, 4, 2), MC_1(1, 8, 4), MC_1(2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
     MC_W(32, 1, 2, 4), MC_W(32, 1, 4, 4), MC_W(32, 1, 2, 2), MC_W(32, 2, 4, 4), MC_W(32, 2, 2, 4), MC_W(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_W(32, 4, 2, 2), MC_W(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
     MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1),                                                    // 64 -> 32 / 16
     MC_R(16, 2, 2, 8, 4), MC_R(16, 2, 2, 8, 8), MC_R(16, 2, 2, 4, 4), MC_R(16, 2, 2, 4, 2), MC_R(64, 2, 2, 2, 1), MC_R(64, 2, 2, 2, 2)};   // ResidualUnit first convolutions of level 1 with their 1x1x1 residual convolution: 16 -> 32 + 32, 64 -> 32 + 32
@@ -500,7 +561,9 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
   if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
   if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
-  if (d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15)) return no("input must be one channel chunk of 16-byte aligned voxel rows");
+  const bool c1 = d->in.c == 1 && d->in.pitch == 1 && d->ck == 8 && !d->in.ptr2;  // a compact one-channel tensor standing for one zero-extended channel group
+  if (!c1 && (d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15))) return no("input must be one channel chunk of 16-byte aligned voxel rows (or a compact one-channel tensor with ck = 8)");
+  if (c1 && (d->depth != -5 || d->in_gate || d->res_tiles || ((uintptr_t)d->in.ptr & 1))) return no("a compact one-channel input needs a depth -5 plan without input gate / residual tiles");
   if (d->ksteps != (9 * (d->ck / 8) + 3) / 4) return no("ksteps");
   if (d->out.c > d->nt * 16 || (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32)) return no("output channels / dtype");
   if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
@@ -517,7 +580,10 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
     return no("residual tiles need their packed weights, a plain or statistics epilogue and a one-part bf16 output");
   if (d->res_tiles && !d->res_out.ptr && (d->out.dtype != VSSEG_BF16 || (d->out.c & 3))) return no("residual tiles added in the epilogue need a bf16 output");
   for (const McEntry& e : mc_table)
-    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt && e.nr == d->res_tiles) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
+    if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt && e.nr == d->res_tiles) {
+      if (c1 && !e.fn_c1) return no("no compact-input instantiation for this shape");
+      return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
+    }
   return no("no instantiation for this (channels, nt, tz, mtw)");
 }
 
@@ -577,5 +643,6 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.res_cout = d->res_tiles ? (d->res_out.ptr ? d->res_out.c : d->out.c) : 0;
   const int64_t grid = (int64_t)d->in.n * k.nxs * k.nyb * k.nzb;
   VSSEG_CHECK(grid > 0 && grid < (1ll << 30), "vsseg_igemm: bad marching grid");
+  if (d->in.c == 1 && d->ck == 8) return e->fn_c1(k, (int)grid, s);
   return d->depth == -6 ? e->fn_wreg(k, (int)grid, s) : e->fn(k, (int)grid, s);
 }

@@ -354,7 +354,7 @@ class Plan:
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
                f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else "")
-               + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else ""))
+               + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else "") + ("|c1" if (d.inp.c == 1 and p0.kc == 8) else ""))
         cache = _tune_cache()
         hit = cache.get(key)
         # VSSEG_RETUNE_DEPTHS="-6": launches with a candidate plan of one of these depths are measured again although a choice is cached (how the plans of a
@@ -548,6 +548,20 @@ class Plan:
                 pl.pack_map = P.pack_map(pl, Lr.wshape)
         return got
 
+    def _compact_choice(self, ch: _Choice, Lr: Layer) -> Optional[_Choice]:
+        """A convolution launch whose input has ONE real channel (the network input, the pre-sigmoid gradient of an attention map), on the marching kernel reading the
+        COMPACT one-channel tensor (csrc/mconv.hip C1: 2 bytes per voxel from HBM instead of the 16 of the zero-extended channel group): the marching plans (weights in
+        LDS) of the launch as their own choice, or None where there is none / the switch is off."""
+        if not self.eng.compact_c1 or self.eng.es != 2 or ch.fold or not ch.cands or ch.cands[0].kc != 8 or ch.cands[0].kreal != 1:
+            return None
+        got = getattr(ch, "_compact", None)
+        if got is None:
+            cands = [pl for pl in self._march_cands(ch, Lr) if pl.depth == -5]
+            got = ch._compact = _Choice(cands, ch.woff, wshape=ch.wshape) if cands else False
+            if got:
+                got._is_compact, got._compact = True, got  # (asked again with the new choice: itself)
+        return got or None
+
     @staticmethod
     def _igemm_name(pl: P.IgemmPlan, inp: L.Tensor) -> str:
         """Kernel group of a convolution launch in the profiles: which of the four kernels its plan runs on."""
@@ -662,7 +676,10 @@ class Plan:
             if isinstance(op, ConvBnAct):
                 Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
                 glu = self.gate_onload.get(op.x.name)  # the attention gate in front of the unit is applied on load: read x (the concat) and the attention map
-                xin, out = (self._desc(glu.x) if glu is not None else self._xdesc(op.x, cp.fold_fwd)), self._desc(op.out)
+                cc1 = self._compact_choice(cp.fwd[0], Lr) if (len(cp.fwd) == 1 and op.x.root.name == prog.input.name and pre not in self.resn) else None
+                if cc1 is not None:  # the network input as a compact one-channel tensor (marching plans only)
+                    cp.fwd[0] = cc1
+                xin, out = (self._desc(glu.x) if glu is not None else self._xdesc(op.x, cp.fold_fwd or cc1 is not None)), self._desc(op.out)
                 fused_res = plain_by_out[op.res.name] if (op.res is not None and op.res.name in plain_by_out and plain_by_out[op.res.name].layer.prefix in res1_fused) else None
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
@@ -725,7 +742,8 @@ class Plan:
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
         if any((not self.cplans[op.layer.prefix].fold_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
-               and op.x.root.name == prog.input.name for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
+               and op.x.root.name == prog.input.name and not (self.cplans[op.layer.prefix].fwd and getattr(self.cplans[op.layer.prefix].fwd[0], "_is_compact", False))
+               for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
             self.needs_padded_input = True
         self.out_logits = self._alloc(prog.logits, self.bufs)
         self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
@@ -913,8 +931,11 @@ class Plan:
                 if len(cp.dgrad) > 1 and not any(ch.fold for ch in cp.dgrad):
                     self._igemm_classes(B, cp.dgrad, dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
                     return
-                for ch in cp.dgrad:
-                    self._igemm(B, ch, dy_compact if ch.fold else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
+                for ci, ch in enumerate(cp.dgrad):
+                    cc1 = self._compact_choice(ch, Lr) if (dy_compact is not None and len(cp.dgrad) == 1) else None
+                    if cc1 is not None:  # the one-channel gradient read compact by the marching kernel (its 8-channel zero-extension is then never written)
+                        cp.dgrad[ci] = ch = cc1
+                    self._igemm(B, ch, dy_compact if (ch.fold or cc1 is not None) else dy, gx, accumulate=acc, res=self._desc(relumask) if relumask is not None else None, res_mode=L.RES_RELUMASK if relumask is not None else L.RES_NONE, ncls=len(cp.dgrad))
 
         def fused_backward(op: ConvBnAct, yd: L.Tensor, dA: L.Tensor) -> bool:
             """The layer's vsseg_bn_act_bwd_apply + data gradient + weight gradient as ONE marching launch (csrc/mbwd.hip), where it is instantiated and this
@@ -1077,8 +1098,8 @@ class Plan:
                 if Lr.prefix in absorbed_res:  # data + weight gradient came out of the fused launch of the unit's 3x3x1 block (csrc/mbwd.hip, RES); bias gradient: folded_bias
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
-                dy = self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if op.act == "sigmoid" else grad_of_out(op.out)
                 dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and ("dpre1:" + op.out.name) in self.bufs) else None
+                dy = (self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if ("dpre:" + op.out.name) in self.bufs else dyc) if op.act == "sigmoid" else grad_of_out(op.out)
                 conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc, gate=gate_fuse.get(Lr.prefix))
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
@@ -1093,13 +1114,19 @@ class Plan:
                     acc = 2  # att_apply_bwd: do not write d(x)
                 else:
                     acc = contribution(op.x)
-                dpre = self._raw("dpre:" + op.att.name, op.att.level, 8)
-                sig = producer[op.att.name].layer  # the sigmoid convolution (its bias gradient sum(dpre) is reduced by its weight-gradient launch, in a fixed order)
+                sigop = producer[op.att.name]
+                sig = sigop.layer  # the sigmoid convolution (its bias gradient sum(dpre) is reduced by its weight-gradient launch, in a fixed order)
                 want_c1 = (eng.narrow_wgrad and sig.kernel in ((3, 3, 1), (1, 1, 1)) and sig.cin in (8, 16, 32, 64) and self.lv[sig.level][1] % 4 == 0)
                 dpre1 = self._raw("dpre1:" + op.att.name, op.att.level, 1).data_ptr() if want_c1 else None  # compact copy of d(pre-sigmoid): z-folded data gradient / narrow weight gradient
+                # the 8-channel zero-extension of d(pre-sigmoid) (16 bytes per voxel for 2 real ones) is written only if a launch reads it: not when the sigmoid convolution's
+                # weight gradient is the narrow reduction and its data gradient reads the compact copy (marching kernel, csrc/mconv.hip C1)
+                cps = self.cplans[sig.prefix]
+                all_compact = (want_c1 and not sig.transposed and tuple(sig.stride) == (1, 1, 1) and sigop.x.parts is None and sigop.x.base is None and len(cps.dgrad) == 1
+                               and self._compact_choice(cps.dgrad[0], sig) is not None)
+                dpre = None if all_compact else self._raw("dpre:" + op.att.name, op.att.level, 8)
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level), None, dpre1],
-                          self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + 8 + 4)])
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level) if dpre is not None else L.Tensor(), None, dpre1],
+                          self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + (8 if dpre is not None else 1) + 4)])
         self._finish_pack()
 
     def _index_slots(self):
@@ -1249,6 +1276,7 @@ class Engine:
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
+        self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
         self.gate_onload_units = os.environ.get("VSSEG_GATE_ONLOAD_UNITS", "1") != "0"  # ... also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
