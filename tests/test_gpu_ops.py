@@ -173,6 +173,13 @@ def test_marching_weight_gradient(cin, cout, dims, split, tile):
     if db is not None:
         want = gy.double().sum((0, 2, 3, 4)).float()
         np.testing.assert_allclose(db.cpu().numpy(), want.numpy(), atol=1e-4 * float(want.abs().max()) + 1e-3)
+    if cout == 2 and cin == 32:  # the logits convolution: P also read as the COMPACT two-channel tensor (4 bytes per voxel instead of the zero-extended 16): bit-identical
+        dwc = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl[..., :2].contiguous(), h, cout, cin, march_tile=tile)
+        assert torch.equal(dwc, dw)
+        gate = torch.rand(2, *dims, device="cuda")
+        a = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin, march_tile=tile, h_gate=gate)
+        b = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl[..., :2].contiguous(), h, cout, cin, march_tile=tile, h_gate=gate)
+        assert torch.equal(a, b) and not torch.equal(a, dw)
 
 
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
@@ -620,6 +627,9 @@ MARCH_CASES = [
     ("conv_fwd", 64, 32, (5, 64, 4), 32, (2, 2), 2),
     ("conv_fwd", 1, 16, (6, 64, 8), 0, (8, 8), 3),        # the network input, zero-extended to one 8-channel group
     ("conv_dgrad", 32, 2, (5, 128, 4), 0, (4, 8), 5),     # data gradient of the logits convolution: K = 2 (-> 8), N = 32
+    ("conv_dgrad", 32, 2, (6, 64, 16), 0, (4, 4), 3),     # ... several z blocks and x segments; also from the COMPACT two-channel gradient
+    ("conv_dgrad", 32, 2, (6, 64, 16), 0, (8, 4), 4),
+    ("conv_dgrad", 32, 2, (5, 64, 16), 0, (8, 8), 2),
     ("conv_dgrad", 16, 1, (6, 64, 8), 0, (8, 4), 3),      # data gradient of an attention sigmoid convolution: K = 1 (-> 8), N = 16; also from the COMPACT one-channel gradient
 ]
 
@@ -697,9 +707,9 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
             if mode == "stats":
                 a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
                 np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
-        if kreal == 1 and mode in ("plain", "stats", "relu_mask", "accumulate"):
-            # one real input channel: the marching kernel also reads the COMPACT one-channel tensor (2 bytes per voxel instead of the zero-extended 16): bit-identical
-            compact = inp_cl[..., :1].contiguous()
+        if (kreal == 1 and mode in ("plain", "stats", "relu_mask", "accumulate")) or (kreal == 2 and mode == "plain"):
+            # one / two real input channels: the marching kernel also reads the COMPACT tensor (2 / 4 bytes per voxel instead of the zero-extended 16): bit-identical
+            compact = inp_cl[..., :kreal].contiguous()
             out = res_t.clone() if mode == "accumulate" else torch.full((2, *dims, nout), float("nan"), dtype=odt, device="cuda")
             kw, stats = {}, None
             if mode == "stats":
@@ -715,7 +725,7 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
             d = H.igemm_desc(mps[0], wp, H.tdesc(compact), H.tdesc(out), **kw)
             L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm compact input {mode}")
             torch.cuda.synchronize()
-            assert torch.equal(out, og), f"{mode}: compact one-channel input differs (max {float((out.float() - og.float()).abs().max())})"
+            assert torch.equal(out, og), f"{mode}: compact input differs (max {float((out.float() - og.float()).abs().max())})"
             if mode == "stats":
                 np.testing.assert_allclose(H.stat_decode(stats).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 

@@ -62,12 +62,13 @@ struct MconvK {
 // With few M-tiles per wave the K loop re-reads every weight fragment from LDS at every x step — on the 64 -> 32 layers (MT = 1, 36 fragments per
 // step and wave against 18 operand fragments) two thirds of the LDS bandwidth the launch is bound by; in registers they cost nothing per step and
 // the 9-36 KB of LDS they occupied go back to the ring.
-// C1 (CIN 8 only): the input is a COMPACT one-channel tensor [N][X][Y][Z] (2 bytes per voxel: the network input, the pre-sigmoid gradient of an attention map) instead
-// of its zero-extension to one 8-channel group (16 bytes per voxel, 7/8 of them zeros read from HBM): the thread that owns a plane slot loads the voxel's value one step
-// ahead (ordinary load into a register) and writes the zero-extended 16-byte piece into the ring itself.
-template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, bool C1 = false>
+// CC = 1 / 2 (CIN 8 only): the input is a COMPACT one- / two-channel tensor [N][X][Y][Z][CC] (2 / 4 bytes per voxel: the network input, the pre-sigmoid gradient of an
+// attention map; the gradient of the two logits) instead of its zero-extension to one 8-channel group (16 bytes per voxel, most of them zeros read from HBM): the thread
+// that owns a plane slot loads the voxel's value(s) one step ahead (ordinary load into a register) and writes the zero-extended 16-byte piece into the ring itself.
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int CC = 0>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
-  static_assert(!C1 || CIN == 8, "compact one-channel inputs are one zero-extended channel group");
+  static_assert(CC == 0 || CIN == 8, "compact inputs are one zero-extended channel group");
+  constexpr bool C1 = CC != 0;
   constexpr bool STATS = MODE == 1 || MODE == 4, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
       const char* p0 = org0 + (int64_t)(inside ? x : 0) * plane_stride;
 #pragma unroll
       for (int u = 0; u < NINST; ++u) {  // unconditional loads from valid addresses, the zero padding is a select on the loaded value
-        const unsigned v = *reinterpret_cast<const unsigned short*>(p0 + rel[u]);
+        unsigned v;
+        if constexpr (CC == 2) v = *reinterpret_cast<const unsigned*>(p0 + rel[u]);
+        else v = *reinterpret_cast<const unsigned short*>(p0 + rel[u]);
         cv[u] = (inside && ((okmask >> u) & 1u)) ? v : 0u;
       }
     }
@@ -506,22 +509,26 @@ template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_laun
   VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, residual tiles)");
   return VSSEG_OK;
 }
-template <int CIN, int NT, int TZ, int MT, int MODE> static int mc_launch_c1_mode(const MconvK& k, int grid, hipStream_t s) {
+template <int CIN, int NT, int TZ, int MT, int MODE, int CC> static int mc_launch_c1_mode(const MconvK& k, int grid, hipStream_t s) {
   static bool init = false;
   const int lds = mc_lds<CIN, NT, TZ, MT, false>();
   if (!init) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     init = true;
   }
-  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
-  VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, compact one-channel input)");
+  hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, CC>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, compact input)");
   return VSSEG_OK;
 }
-template <int CIN, int NT, int TZ, int MT> static int mc_launch_c1(const MconvK& k, int grid, hipStream_t s) {  // compact one-channel input (CIN 8 entries)
-  if (k.in_gate) { vsseg_set_error("vsseg_igemm: the input gate does not combine with a compact one-channel input"); return VSSEG_EINVAL; }
-  if (k.stats) return mc_launch_c1_mode<CIN, NT, TZ, MT, 1>(k, grid, s);
-  if (k.aux_mode) return mc_launch_c1_mode<CIN, NT, TZ, MT, 2>(k, grid, s);
-  return mc_launch_c1_mode<CIN, NT, TZ, MT, 0>(k, grid, s);
+template <int CIN, int NT, int TZ, int MT> static int mc_launch_c1(const MconvK& k, int grid, hipStream_t s) {  // compact one- / two-channel input (CIN 8 entries)
+  if (k.in_gate) { vsseg_set_error("vsseg_igemm: the input gate does not combine with a compact input"); return VSSEG_EINVAL; }
+  if (k.in_vox_bytes == 4) {  // two channels: the logits gradient (plain epilogue only)
+    if (k.stats || k.aux_mode) { vsseg_set_error("vsseg_igemm: a compact two-channel input combines with the plain epilogue only"); return VSSEG_EINVAL; }
+    return mc_launch_c1_mode<CIN, NT, TZ, MT, 0, 2>(k, grid, s);
+  }
+  if (k.stats) return mc_launch_c1_mode<CIN, NT, TZ, MT, 1, 1>(k, grid, s);
+  if (k.aux_mode) return mc_launch_c1_mode<CIN, NT, TZ, MT, 2, 1>(k, grid, s);
+  return mc_launch_c1_mode<CIN, NT, TZ, MT, 0, 1>(k, grid, s);
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.in_gate) {
@@ -561,9 +568,9 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
   if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
   if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
-  const bool c1 = d->in.c == 1 && d->in.pitch == 1 && d->ck == 8 && !d->in.ptr2;  // a compact one-channel tensor standing for one zero-extended channel group
+  const bool c1 = (d->in.c == 1 || d->in.c == 2) && d->in.pitch == d->in.c && d->ck == 8 && !d->in.ptr2;  // a compact one- / two-channel tensor standing for one zero-extended channel group
   if (!c1 && (d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15) || ((uintptr_t)d->in.ptr2 & 15))) return no("input must be one channel chunk of 16-byte aligned voxel rows (or a compact one-channel tensor with ck = 8)");
-  if (c1 && (d->depth != -5 || d->in_gate || d->res_tiles || ((uintptr_t)d->in.ptr & 1))) return no("a compact one-channel input needs a depth -5 plan without input gate / residual tiles");
+  if (c1 && (d->depth != -5 || d->in_gate || d->res_tiles || ((uintptr_t)d->in.ptr & (2 * d->in.c - 1)))) return no("a compact input needs a depth -5 plan without input gate / residual tiles");
   if (d->ksteps != (9 * (d->ck / 8) + 3) / 4) return no("ksteps");
   if (d->out.c > d->nt * 16 || (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32)) return no("output channels / dtype");
   if ((d->out.c & 3) == 0 && (d->out.pitch & 3)) return no("output pitch");
@@ -643,6 +650,6 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.res_cout = d->res_tiles ? (d->res_out.ptr ? d->res_out.c : d->out.c) : 0;
   const int64_t grid = (int64_t)d->in.n * k.nxs * k.nyb * k.nzb;
   VSSEG_CHECK(grid > 0 && grid < (1ll << 30), "vsseg_igemm: bad marching grid");
-  if (d->in.c == 1 && d->ck == 8) return e->fn_c1(k, (int)grid, s);
+  if (d->in.c <= 2 && d->ck == 8) return e->fn_c1(k, (int)grid, s);
   return d->depth == -6 ? e->fn_wreg(k, (int)grid, s) : e->fn(k, (int)grid, s);
 }

@@ -42,8 +42,11 @@ __device__ __forceinline__ bf16x8 mw_tr(const char* lo, const char* hi) {
 
 // CH: channels of H (16, 32, 64); CP: channels of P as stored (8, 16, 32: 8 = a 1/2-channel gradient zero-extended to one channel group);
 // UNITSPLIT: waves split the (tap, cH tile) units instead of the K-steps
-template <int CH, int CP, int TZ, int MT, bool UNITSPLIT, bool GIN>
+// PC2 (CP 8 only): P is a COMPACT two-channel tensor [N][X][Y][Z][2] (4 bytes per voxel: the gradient of the two logits) instead of its zero-extension to one
+// 8-channel group: the thread that owns a plane slot loads the voxel's pair one step ahead and writes the zero-extended 16-byte piece into the P buffer itself.
+template <int CH, int CP, int TZ, int MT, bool UNITSPLIT, bool GIN, bool PC2 = false>
 __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
+  static_assert(!PC2 || CP == 8, "a compact P operand is one zero-extended channel group");
   constexpr int GH = CH / 8, GP = CP / 8, RSH = TZ * GH, RSP = TZ * GP, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int NTH = CH / 16, NTP = CP >= 16 ? CP / 16 : 1;
   constexpr int HSLOTS = ROWS * RSH, PSLOTS = TYB * RSP;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
     const int r = j / RSP, within = j % RSP, pp = within / TZ, z = within % TZ;
     const int pc = (pp - 2 * (r * RSP / 16)) & (GP - 1);
     const bool ok = j < PSLOTS;
-    prel[u] = ok ? (r * Z + z) * k.p_vox_bytes + pc * 16 : 0;
+    prel[u] = ok ? (r * Z + z) * k.p_vox_bytes + (PC2 ? 0 : pc * 16) : 0;
     if (ok) pok |= 1u << u;
   }
   const int64_t col0 = (((int64_t)n * X) * Y + y0) * Z + z0;
@@ -134,12 +137,23 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
       }
     }
   };
-  auto issue_p = [&](int i) {  // plane i of P (always inside the image) into buffer i & 1
+  unsigned pcv[PC2 ? PINST : 1];
+  auto issue_p = [&](int i) {  // plane i of P (always inside the image) into buffer i & 1 (PC2: its values into registers; written by store_p in front of the next barrier)
     const char* q = porg + (int64_t)(xb - 1 + i) * pstride;
     char* dst = Pl + (i & 1) * PPLANE;
 #pragma unroll
-    for (int u = 0; u < PINST; ++u)
-      if ((pok >> u) & 1u) vsseg_dma16(q + prel[u], dst + (u * 4 + wave) * 1024);
+    for (int u = 0; u < PINST; ++u) {
+      if constexpr (PC2) pcv[u] = ((pok >> u) & 1u) ? *reinterpret_cast<const unsigned*>(q + prel[u]) : 0u;
+      else if ((pok >> u) & 1u) vsseg_dma16(q + prel[u], dst + (u * 4 + wave) * 1024);
+    }
+  };
+  auto store_p = [&](int i) {  // PC2: buffer i & 1 held plane i-2, read last in step i-2 by waves that have all passed the barrier of step i-1
+    if constexpr (PC2) {
+      char* dst = Pl + (i & 1) * PPLANE + lane * 16;
+#pragma unroll
+      for (int u = 0; u < PINST; ++u)
+        if ((pok >> u) & 1u) *reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024) = make_uint4(pcv[u], 0u, 0u, 0u);
+    }
   };
 
   // ---- transpose-read addressing.  Lane (g, i = l15): voxel r4 = i >> 2 of a 4-voxel block, 4-channel chunk q = i & 3 of a 16-channel tile.
@@ -194,6 +208,10 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (GIN) {
       if (i > 1) apply_gate(i + 1, gin);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if constexpr (PC2) {
+      store_p(i);  // the values of P plane i, loaded one step ago
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // H plane i+1 and P plane i have landed for every wave; every wave has finished step i-1
@@ -313,7 +331,24 @@ template <int CH, int CP, int TZ, int MT, bool US, bool GIN> static int mw_launc
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (marching)");
   return VSSEG_OK;
 }
+template <int CH, int CP, int TZ, int MT, bool US> static int mw_launch_pc2(const MwgradK& k, int grid, hipStream_t s) {  // gated H + compact two-channel P: the logits convolution
+  static bool init = false;
+  const int lds = mw_lds<CH, CP, TZ, MT>();
+  if (!init) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    init = true;
+  }
+  if (k.h_gate) hipLaunchKernelGGL((mwgrad_kernel<CH, CP, TZ, MT, US, true, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  else hipLaunchKernelGGL((mwgrad_kernel<CH, CP, TZ, MT, US, false, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+  VSSEG_LAUNCH_CHECK("vsseg_wgrad (marching, compact P)");
+  return VSSEG_OK;
+}
 template <int CH, int CP, int TZ, int MT, bool US> static int mw_launch(const MwgradK& k, int grid, hipStream_t s) {
+  if (k.p_vox_bytes == 4) {
+    if constexpr (CH == 32 && CP == 8) return mw_launch_pc2<CH, CP, TZ, MT, US>(k, grid, s);
+    else { vsseg_set_error("vsseg_wgrad: no marching-kernel instantiation with a compact two-channel P for this shape"); return VSSEG_EINVAL; }
+  }
   if (k.h_gate) {
     if constexpr (CH == 32 && CP == 8) return mw_launch_g<CH, CP, TZ, MT, US, true>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
     else { vsseg_set_error("vsseg_wgrad: no marching-kernel instantiation with the gated H operand for this shape"); return VSSEG_EINVAL; }
@@ -350,10 +385,11 @@ static const MwEntry* mw_find(const vsseg_wgrad_desc* d, const char** why) {
   if ((tz != 2 && tz != 4 && tz != 8) || tyb < 1 || (tyb * tz) % 64 || d->tile[0] < 1) return no("tile must be (x steps per workgroup, rows, tz in {2, 4, 8}) with rows * tz a multiple of 64");
   const int mt = tyb * tz / 64;
   if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
-  if (d->h.c % 16 || d->h.pitch % 8 || ((uintptr_t)d->h.ptr & 15) || ((uintptr_t)d->h.ptr2 & 15) || ((uintptr_t)d->p.ptr & 15) || d->p.pitch % 8) return no("operand alignment");
+  const bool pc2 = d->p.c == 2 && d->p.pitch == 2;  // P = a compact two-channel tensor standing for one zero-extended channel group
+  if (d->h.c % 16 || d->h.pitch % 8 || ((uintptr_t)d->h.ptr & 15) || ((uintptr_t)d->h.ptr2 & 15) || ((uintptr_t)d->p.ptr & (pc2 ? 3 : 15)) || (!pc2 && d->p.pitch % 8)) return no("operand alignment");
   if (d->ch_valid != d->h.c || d->cp_valid > d->p.c || d->ntp != (d->p.c >= 16 ? d->p.c / 16 : 1)) return no("channel counts");
   for (const MwEntry& e : mw_table)
-    if (e.ch == d->h.c && e.cp == d->p.c && e.tz == tz && e.mt == mt) return &e;
+    if (e.ch == d->h.c && e.cp == (pc2 ? 8 : d->p.c) && e.tz == tz && e.mt == mt) return &e;
   return no("no instantiation for this (H channels, P channels, tz, rows)");
 }
 

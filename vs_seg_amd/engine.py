@@ -552,15 +552,24 @@ class Plan:
         """A convolution launch whose input has ONE real channel (the network input, the pre-sigmoid gradient of an attention map), on the marching kernel reading the
         COMPACT one-channel tensor (csrc/mconv.hip C1: 2 bytes per voxel from HBM instead of the 16 of the zero-extended channel group): the marching plans (weights in
         LDS) of the launch as their own choice, or None where there is none / the switch is off."""
-        if not self.eng.compact_c1 or self.eng.es != 2 or ch.fold or not ch.cands or ch.cands[0].kc != 8 or ch.cands[0].kreal != 1:
-            return None
+        if not self.eng.compact_c1 or self.eng.es != 2 or ch.fold or not ch.cands or ch.cands[0].kc != 8 or ch.cands[0].kreal not in (1, 2):
+            return None  # (two real channels: the gradient of the logits, csrc/mconv.hip CC = 2)
         got = getattr(ch, "_compact", None)
         if got is None:
             cands = [pl for pl in self._march_cands(ch, Lr) if pl.depth == -5]
-            got = ch._compact = _Choice(cands, ch.woff, wshape=ch.wshape) if cands else False
+            got = ch._compact = _Choice(cands, ch.woff, wshape=ch.wshape, wshape2=ch.wshape2, woff2=ch.woff2) if cands else False  # (a merged residual convolution stays merged)
             if got:
                 got._is_compact, got._compact = True, got  # (asked again with the new choice: itself)
         return got or None
+
+    def _logits_compact(self, Lr: Layer, x: TensorSpec) -> bool:
+        """Whether BOTH backward launches of the logits convolution can read the gradient of the two logits compact: a marching data-gradient plan (csrc/mconv.hip CC = 2)
+        and a marching weight-gradient tile with the compact P operand (csrc/mwgrad.hip PC2, instantiated for 32 input channels)."""
+        cp = self.cplans[Lr.prefix]
+        if (not self.eng.compact_c1 or self.eng.es != 2 or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cout != 2 or Lr.cin != 32
+                or len(cp.dgrad) != 1 or x.parts is not None or x.base is not None or self._compact_choice(cp.dgrad[0], Lr) is None):
+            return False
+        return bool(P.march_wgrad_tiles(Lr.cin, 8, cp.wgrad.q, self.n, self.eng.wgrad_scratch().numel()))
 
     @staticmethod
     def _igemm_name(pl: P.IgemmPlan, inp: L.Tensor) -> str:
@@ -754,9 +763,23 @@ class Plan:
         # ---- backward
         B = self.bwd
         written: Dict[str, bool] = {}
-        dlog8 = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
         x0, y0, z0 = self.lv[0]
-        self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(dlog8.data_ptr(), _tdtype(dlog8), prog.logits.c, 8, self.n, x0, y0, z0, None, 0, L.ZERO_PADDED)]])
+        staged: Dict[str, L.Tensor] = {}
+
+        def logits_grad(compact: bool) -> L.Tensor:
+            """The loss' fp32 gradient of the logits staged in the compute dtype by the eager prelude: zero-extended to one 8-channel group, or (the marching kernels'
+            compact operands, csrc/mconv.hip CC = 2 / csrc/mwgrad.hip PC2) as it is, two channels per voxel."""
+            assert not staged or ("c" in staged) == compact, "the gradient of the logits is staged in one layout"
+            if not staged:
+                if compact:
+                    buf = self._raw("g:logits2", 0, prog.logits.c)
+                    staged["c"] = self._tdesc(buf, 0)
+                    self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), staged["c"]]])
+                else:
+                    buf = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
+                    staged["p"] = self._tdesc(buf, 0)
+                    self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(buf.data_ptr(), _tdtype(buf), prog.logits.c, 8, self.n, x0, y0, z0, None, 0, L.ZERO_PADDED)]])
+            return staged["c" if compact else "p"]
 
         def gdesc(spec: TensorSpec) -> L.Tensor:
             return self._desc(spec, self.grads)
@@ -781,7 +804,7 @@ class Plan:
             t = grad_alias.get(t.name, t)
             if t.kind == "f32":  # logits: the loss' fp32 gradient staged in an 8-channel compute-dtype buffer
                 assert t.name == prog.logits.name
-                return self._tdesc(dlog8, 0)
+                return logits_grad(False)
             assert written.get(t.root.name), f"gradient of {t.name} is consumed before it is produced"
             return gdesc(t)
 
@@ -816,10 +839,11 @@ class Plan:
             d = L.WgradDesc()
             if gl is not None:
                 d.h_gate = self._alloc(gl.att, self.bufs).data_ptr()
+            pc2 = dy_compact is not None and dy_compact.c == 2  # P = the compact two-channel gradient of the logits (marching kernel only, csrc/mwgrad.hip PC2)
             if Lr.transposed:
                 d.p, d.h, d.cp_valid, d.ch_valid = xin, dy, Lr.cin, Lr.cout
             else:
-                d.p, d.h, d.cp_valid, d.ch_valid = dy, xin, Lr.cout, Lr.cin
+                d.p, d.h, d.cp_valid, d.ch_valid = (dy_compact if pc2 else dy), xin, Lr.cout, Lr.cin
             d.q, d.hs, d.ntaps = L.i3(wg.q), L.i3(wg.hs), len(wg.taps)
             for t, (off, widx) in enumerate(wg.taps):
                 d.tap_off[t][0], d.tap_off[t][1], d.tap_off[t][2] = off
@@ -850,11 +874,12 @@ class Plan:
             wpc = 4
             # the marching kernel (csrc/mwgrad.hip: both operands fetched once) where it is instantiated: stride-1 3x3x1 bf16, 16/32/64 input channels
             mtiles = []
-            if eng.es == 2 and not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1) and d.h.c == Lr.cin and d.p.c in (8, 16, 32) and not d.p.ptr2:
-                mtiles = P.march_wgrad_tiles(Lr.cin, d.p.c, wg.q, self.n, scr.numel())
+            if eng.es == 2 and not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1) and d.h.c == Lr.cin and (d.p.c in (8, 16, 32) or pc2) and not d.p.ptr2:
+                mtiles = P.march_wgrad_tiles(Lr.cin, 8 if pc2 else d.p.c, wg.q, self.n, scr.numel())
+            assert mtiles or not pc2
             live_tile = L.i3(wg.tile)
             if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU, and the marching kernel's tiles
-                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}" + ("|gin" if gl is not None else "")
+                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}" + ("|gin" if gl is not None else "") + ("|c2" if pc2 else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     hit = cache[key]
@@ -887,7 +912,7 @@ class Plan:
                         return best
 
                     ms = {}
-                    for hg in (hgs if gl is None else []):  # (a gated H operand: marching kernel only)
+                    for hg in (hgs if (gl is None and not pc2) else []):  # (a gated H operand / a compact P operand: marching kernel only)
                         for sb in (0, 1):
                             for w in (2, 3, 4):
                                 d.march, d.single_buffer, d.hgroup = 0, sb, hg
@@ -906,8 +931,8 @@ class Plan:
                     cache[key] = list(bestk)
                     _tune_cache.dirty = True
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
-            elif gl is not None:  # untuned lowering of a gated H operand: the marching kernel is the only one that gates on load — its first tile
-                assert mtiles, "gate-on-load was enabled for a layer without a marching weight-gradient tile"
+            elif gl is not None or pc2:  # untuned lowering of a gated H operand / a compact P: the marching kernel is the only one that reads them — its first tile
+                assert mtiles, "gate-on-load / a compact P was enabled for a layer without a marching weight-gradient tile"
                 d.march, live_tile = 1, L.i3(mtiles[0])
             d.tile = live_tile
             set_blocks(wpc)
@@ -1099,7 +1124,9 @@ class Plan:
                     continue
                 assert op.res is None or op.res.name.endswith(":res"), "identity residual on a plain convolution is not part of this network"
                 dyc = self._tdesc(self.bufs["dpre1:" + op.out.name], Lr.level) if (op.act == "sigmoid" and ("dpre1:" + op.out.name) in self.bufs) else None
-                dy = (self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if ("dpre:" + op.out.name) in self.bufs else dyc) if op.act == "sigmoid" else grad_of_out(op.out)
+                if op.act != "sigmoid" and op.out.name == prog.logits.name and self._logits_compact(Lr, op.x):
+                    dyc = logits_grad(True)  # both launches of the logits convolution read the two-channel gradient compact (4 bytes per voxel instead of 16)
+                dy = (self._tdesc(self.bufs["dpre:" + op.out.name], Lr.level) if ("dpre:" + op.out.name) in self.bufs else dyc) if op.act == "sigmoid" else (dyc if dyc is not None else grad_of_out(op.out))
                 conv_backward(Lr, op.x, dy, bias_grad=Lr.prefix not in folded_bias, relumask=relu_out.get(op.x.name), dy_compact=dyc, gate=gate_fuse.get(Lr.prefix))
             elif isinstance(op, AttGate):
                 gout = grad_of_out(op.out)
