@@ -379,7 +379,7 @@ def main():
     if args.swi_volumes > 0:
         model.eval()
         vol = torch.from_numpy(np.random.default_rng(7 + rank).standard_normal((1, 1, 512, 512, 120), dtype=np.float32)).to(dev)
-        pred = lambda w: model(w)[0]  # noqa: E731
+        pred = model.segmentation_predictor()  # the predictor the product's inference script builds (vs_seg_amd/params.py): `lambda w: model(w)[0]` without the per-window copies of the logits and attention maps
         def time_swi(swb, lanes=2):
             with torch.no_grad():
                 for _ in range(3):  # every (lane, group size) plan has had its eager runs and its hipGraph capture (third run) before the timed region

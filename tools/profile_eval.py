@@ -31,11 +31,12 @@ nvol = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 if nvol:
     import vs_seg_amd as V
     vol = torch.from_numpy(np.random.default_rng(7).standard_normal((1, 1, 512, 512, 120), dtype=np.float32)).cuda()
+    pred = m.segmentation_predictor()  # what vs_seg_amd/params.py and bench.py run
     with torch.no_grad():
-        V.sliding_window_inference(vol, bench.PATCH, 1, lambda w: m(w)[0], overlap=0.5, mode="gaussian")
+        V.sliding_window_inference(vol, bench.PATCH, 1, pred, overlap=0.5, mode="gaussian")
         torch.cuda.synchronize()
         t = time.perf_counter()
         for _ in range(nvol):
-            V.sliding_window_inference(vol, bench.PATCH, 1, lambda w: m(w)[0], overlap=0.5, mode="gaussian")
+            V.sliding_window_inference(vol, bench.PATCH, 1, pred, overlap=0.5, mode="gaussian")
         torch.cuda.synchronize()
     print(f"sliding window: {(time.perf_counter() - t) / nvol * 1e3:.2f} ms per volume ({nvol} volumes, 14 windows each)")
