@@ -28,6 +28,17 @@ __device__ __forceinline__ void bn_bwd_consts(BnBwdC8& c, const float* __restric
   }
 }
 
+// The forward of the same block on 8 channels, shared by vsseg_bn_act_fwd (elementwise.hip) and by the kernels that apply it ON LOAD to a convolution input that
+// was never materialised (mconv.hip BIN, mbwd.hip XBN): bit-identical activations.   z = y*scale + shift;  d = keep ? z/(1-p) : 0;  a = d > 0 ? d : alpha*d
+__device__ __forceinline__ void bn_fwd_act8(const f8& y, unsigned keep, float alpha, float inv_keep, const float (&sc)[8], const float (&sh)[8], f8& o) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float z = y.v[j] * sc[j] + sh[j];
+    z = ((keep >> j) & 1u) ? z * inv_keep : 0.f;  // p_drop == 0: keep == 0xff and inv_keep == 1
+    o.v[j] = z > 0.f ? z : alpha * z;
+  }
+}
+
 // 8 channels: y (conv output), g (gradient of the block output), keep bits -> dy
 __device__ __forceinline__ void bn_bwd_dy8(const f8& y, const f8& g, unsigned keep, float alpha, const BnBwdC8& c, f8& o) {
 #pragma unroll

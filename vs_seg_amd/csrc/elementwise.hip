@@ -231,12 +231,10 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.v[j] = x1 * w1[j] + b1[j];
     }
+    bn_fwd_act8(x, keep, alpha, inv_keep, sc, sh, x);  // (bn_bwd.h: shared with the kernels that apply the block on load)
+    if constexpr (RES != 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float z = x.v[j] * sc[j] + sh[j];
-      z = ((keep >> j) & 1u) ? z * inv_keep : 0.f;  // p_drop == 0: keep == 0xff and inv_keep == 1
-      z = z > 0.f ? z : alpha * z;
-      x.v[j] = RES ? z + r.v[j] : z;
+      for (int j = 0; j < 8; ++j) x.v[j] += r.v[j];
     }
     st8(out + v * op + c, x);
   }
