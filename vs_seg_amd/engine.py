@@ -129,7 +129,7 @@ class Plan:
         self.eng, self.n, self.dims, self.train = eng, n, tuple(dims), train
         self.lv = level_dims(dims, eng.hp)
         self.compact_input: Optional[torch.Tensor] = None  # [N,X,Y,Z,1] copy of the network input for the z-folded first-layer launches
-        self.needs_padded_input = train  # the 8-channel zero-extended input is only read by launches that are not z-folded (weight gradients)
+        self.needs_padded_input = False  # set by the first launch descriptor that reads the 8-channel zero-extended copy of the network input (_desc): staged per step only then
         self.fwd: List[list] = []
         self.fwd_pre: List[list] = []  # eval only: launches that depend on parameters / buffers alone (BatchNorm folding); re-run with the weight packing when those change
         self.params_key = None  # parameter version the packed weights + folded BatchNorm constants of an eval plan belong to
@@ -165,6 +165,8 @@ class Plan:
         if spec.parts is not None:  # skip-connection concat: the pair of its dense operands
             return L.Tensor.two_part(self._desc(spec.parts[0], store), self._desc(spec.parts[1], store))
         buf = self._alloc(spec, self.bufs if store is None else store)
+        if store is None and spec.root.name == self.eng.prog.input.name:
+            self.needs_padded_input = True  # (every reader of the padded copy gets its descriptor here; the compact copy goes through _xdesc)
         x, y, z = self.lv[spec.level]
         return L.Tensor(buf.data_ptr() + spec.c0 * buf.element_size(), _tdtype(buf), spec.c, spec.root.c, self.n, x, y, z)
 
@@ -802,10 +804,6 @@ class Plan:
                 F.append([lib.vsseg_att_apply_fwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), self._desc(op.out)], self._ew_meta("att_apply_fwd", op.x.level, 2 * op.x.c + 2)])
             if isinstance(op, (ConvBnAct, ConvPlain)) and op.res is not None and op.res.name.endswith(":res"):
                 grad_alias[op.res.name] = op.out
-        if any((not self.cplans[op.layer.prefix].fold_fwd) and op.layer.prefix not in self.merged and op.layer.prefix not in res1_fused
-               and op.x.root.name == prog.input.name and not (self.cplans[op.layer.prefix].fwd and getattr(self.cplans[op.layer.prefix].fwd[0], "_is_compact", False))
-               for op in ops if isinstance(op, (ConvBnAct, ConvPlain))):
-            self.needs_padded_input = True
         self.out_logits = self._alloc(prog.logits, self.bufs)
         self.out_atts = [self._alloc(a, self.bufs) for a in prog.att_maps]
         if not self.train:
