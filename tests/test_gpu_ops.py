@@ -543,6 +543,10 @@ STREAM_CASES = [
     ("conv_fwd", (1, 1, 1), 32, 16, (8, 16, 4), 0),
     ("conv_fwd", (3, 3, 1), 64, 32, (12, 16, 8), 32),  # level-1 concat: 64 input channels, 4x8x4 tile
     ("conv_fwd", (1, 1, 1), 64, 32, (16, 8, 8), 32),
+    ("conv_fwd", (1, 1, 1), 96, 48, (8, 16, 8), 48),   # level-2 decoder unit's residual convolution on the concat (12 channel groups, 3 output tiles)
+    ("conv_dgrad", (1, 1, 1), 96, 48, (16, 8, 4), 0),  # ... its data gradient: K = 48, N = 96 (6 output tiles)
+    ("conv_fwd", (1, 1, 1), 32, 48, (8, 8, 8), 0),     # level-2 encoder unit's residual convolution
+    ("conv_dgrad", (1, 1, 1), 32, 48, (8, 16, 4), 0),  # K = 48, N = 32
 ]
 
 

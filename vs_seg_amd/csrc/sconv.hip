@@ -342,6 +342,7 @@ struct ScEntry { int cin, nt, taps; sc_fn_t fn; int (*lds)(); };
 #define SC_E(C, N, T) {C, N, T, sc_launch<C, N, T>, sc_lds<C, N, T>}
 static const ScEntry sc_table[] = {SC_E(8, 1, 9),  SC_E(8, 2, 9),  SC_E(16, 1, 9), SC_E(16, 2, 9), SC_E(16, 4, 9), SC_E(32, 1, 9), SC_E(32, 2, 9), SC_E(32, 4, 9),
                                    SC_E(16, 1, 1), SC_E(16, 2, 1), SC_E(32, 1, 1), SC_E(32, 2, 1), SC_E(32, 4, 1), SC_E(64, 2, 1), SC_E(64, 4, 1), SC_E(64, 2, 9),
+                                   SC_E(32, 3, 1), SC_E(48, 2, 1), SC_E(48, 3, 1), SC_E(48, 6, 1), SC_E(96, 3, 1), SC_E(96, 6, 1),  // the 1x1x1 residual convolutions of the level-2 units (32 -> 48, 96 -> 48) and their data gradients
                                    SC_E(16, 4, 4), SC_E(32, 4, 4), SC_E(48, 4, 4)};  // taps 4: fused output-parity classes (pixel shuffle): 4 classes x 16 channels, or 2 classes x 32 channels per launch
 
 static const ScEntry* sc_find(const vsseg_igemm_desc* d, const char** why) {

@@ -159,7 +159,8 @@ def stream_tile(kc, ntaps):
 
 
 STREAM_SHAPES = {(8, 1, 9), (8, 2, 9), (16, 1, 9), (16, 2, 9), (16, 4, 9), (32, 1, 9), (32, 2, 9), (32, 4, 9),
-                 (16, 1, 1), (16, 2, 1), (32, 1, 1), (32, 2, 1), (32, 4, 1), (64, 2, 1), (64, 4, 1), (64, 2, 9)}  # (input channels, 16-channel output tiles, taps) instantiated by sconv.hip
+                 (16, 1, 1), (16, 2, 1), (32, 1, 1), (32, 2, 1), (32, 4, 1), (64, 2, 1), (64, 4, 1), (64, 2, 9),
+                 (32, 3, 1), (48, 2, 1), (48, 3, 1), (48, 6, 1), (96, 3, 1), (96, 6, 1)}  # (input channels, 16-channel output tiles, taps) instantiated by sconv.hip
 _TAPS_3x3x1 = [(t // 3 - 1, t % 3 - 1, 0) for t in range(9)]
 
 
