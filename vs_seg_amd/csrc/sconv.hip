@@ -1,6 +1,6 @@
 // Streaming convolution: the HBM-bound launches of vsseg_igemm — stride-1 3x3x1 / 1x1x1 bf16 convolutions and data gradients with at most 64
 // input and output channels on the two finest levels of the 2.5D U-Net (ref:params/networks/blocks/convolutions.py:114-146; the 16/32-channel
-// layers at 384x128x128 and 192x64x128) — as a kernel whose geometry is a compile-time constant.
+// layers at 384x128x128 and 192x64x128; also the 1x1x1 residual convolutions of the level-2 units, 32 -> 48 and 96 -> 48) — as a kernel whose geometry is a compile-time constant.
 //
 // vsseg_igemm's general kernel (igemm_kernel.h) serves every lattice class, tile shape, channel chunking and prefetch depth from run-time
 // tables; on these layers it issued ~1150 instructions per tile and wave around 20-72 MFMAs and ran at 2.1-3.5 TB/s with 55-65 % of its

@@ -186,7 +186,8 @@ def stream_lds_bytes(kc, nt, ntaps):
 
 def stream_plan(kind, wshape, cls, q, es, kc, nreal, kreal) -> Optional["IgemmPlan"]:
     """The depth -2 candidate: the compile-time-geometry streaming kernel on the launches it covers (stride-1 3x3x1 / 1x1x1 bf16,
-    at most 64 channels either side, extents divisible by the 8x8x4 tile)."""
+    the instantiated (input channels, output tiles, taps) of STREAM_SHAPES — up to 64 channels either side, up to 96 for the 1x1x1 launches of level 2 —, extents
+    divisible by the 8x8x4 tile)."""
     if not stream_eligible(cls, q, kc, nreal, es):
         return None
     nt = (nreal + 15) // 16
