@@ -47,6 +47,7 @@ struct MconvK {
   int out_f32, aux_mode, act, cout, cout_mod, stats_stride;
   int X, Y, Z;
   int lx, nxs, nyb, nzb;  // x steps per workgroup; segments in x, blocks in y and z
+  int ps;                 // host side only: a pixel-shuffle launch (template PS)
   // NR > 0: NR more 16-channel tiles of a 1x1x1 convolution of the SAME input ride along (the ResidualUnit's residual convolution,
   // ref:params/networks/blocks/convolutions.py:241-255): only the K-steps of the centre tap, weights in registers, the operand reads shared with the main tiles
   // BIN (MODE 5): the input is the raw OUTPUT y of the preceding convolution of the same ResidualUnit; its BatchNorm -> Dropout -> PReLU block
@@ -78,9 +79,14 @@ struct MconvK {
 // CC = 1 / 2 (CIN 8 only): the input is a COMPACT one- / two-channel tensor [N][X][Y][Z][CC] (2 / 4 bytes per voxel: the network input, the pre-sigmoid gradient of an
 // attention map; the gradient of the two logits) instead of its zero-extension to one 8-channel group (16 bytes per voxel, most of them zeros read from HBM): the thread
 // that owns a plane slot loads the voxel's value(s) one step ahead (ordinary load into a register) and writes the zero-extended 16-byte piece into the ring itself.
-template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int CC = 0>
+// PS (CIN 32, NT 4): the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution as ONE marching launch on the COARSE lattice ("pixel shuffle",
+// as sconv.hip's TAPS 4): output channel tile t is class (px, py) = (t >> 1, t & 1), stored at fine voxel (2x + px, 2y + py, z); the 2x2x1 neighbourhood (+0 / +1) of the
+// launch are the taps (1,1), (1,2), (2,1), (2,2) of this kernel's 3x3 stencil — with 4 channel groups a K-step is exactly one tap, so the five other K-steps are
+// skipped at compile time and the packed weights [4 taps][NT][64][8] are sconv's.  Every fine output row is written as TZ consecutive 32-byte voxels.
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int CC = 0, bool PS = false>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   static_assert(CC == 0 || CIN == 8, "compact inputs are one zero-extended channel group");
+  static_assert(!PS || (CIN == 32 && NT == 4 && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1)), "pixel-shuffle launches: 32 input channels, four class tiles, plain / statistics epilogue");
   constexpr bool C1 = CC != 0;
   constexpr bool STATS = MODE == 1 || MODE == 4 || MODE == 5, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr bool BIN = MODE == 5;  // statistics + the preceding BatchNorm -> Dropout -> PReLU block applied to the input on load
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
-  constexpr int KSTEPS = (9 * G + 3) / 4, W_BYTES = WREG ? 0 : KSTEPS * NT * 1024;
+  constexpr int KSTEPS = (9 * G + 3) / 4, KSW = PS ? 4 : KSTEPS, W_BYTES = WREG ? 0 : KSW * NT * 1024;  // (KSW: K-steps that have packed weights)
   constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
@@ -106,16 +112,16 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 
   if constexpr (!WREG)
     for (int i = tid; i < W_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Wl)[i] = reinterpret_cast<const uint4*>(k.wpack)[i];
-  bf16x8 wreg[WREG ? KSTEPS : 1][WREG ? NT : 1];
+  bf16x8 wreg[WREG ? KSW : 1][WREG ? NT : 1];
   if constexpr (WREG) {
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks)
+    for (int ks = 0; ks < KSW; ++ks)
 #pragma unroll
       for (int t = 0; t < NT; ++t) wreg[ks][t] = *reinterpret_cast<const bf16x8*>(k.wpack + ((ks * NT + t) * 64 + lane) * 16);
   }
   for (int i = tid; i < MC_NR * PLANE_BYTES / 16; i += 256) reinterpret_cast<uint4*>(Rl)[i] = make_uint4(0u, 0u, 0u, 0u);  // rows outside the image stay zero: they are never fetched
   for (int i = tid; i < NT * 16; i += 256) {
-    const bool ok = i < cout;
+    const bool ok = PS || i < cout;  // (PS: every class tile carries the real channels 0 .. cout_mod - 1)
     const int cv = k.cout_mod > 0 ? i % k.cout_mod : i;
     epi[i] = ((ok && k.bias) ? k.bias[cv] : 0.f) + ((ok && k.bias2) ? k.bias2[cv] : 0.f);
     epi[NT * 16 + i] = (ok && k.scale) ? k.scale[cv] : 1.f;
@@ -299,8 +305,9 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
 
   // output voxel of M-tile m (this lane's column) at x: ((n*X + x)*Y + y0 + (wave*MT + m)*RPM + rr)*Z + z0 + zz
-  const int64_t ocol = col0 + (int64_t)((wave * MT) * RPM + rr) * Z + zz;
-  const int64_t oplane = (int64_t)Y * Z;
+  // PS: fine voxel (n, 2x + px, 2(y0 + row) + py, z0 + zz) of the (2X, 2Y, Z) output; ocol = its (px, py) = (0, 0) corner at x = 0, oplane = two fine planes
+  const int64_t ocol = PS ? (((int64_t)n * 2 * X) * (2 * Y) + 2 * (y0 + (wave * MT) * RPM + rr)) * Z + z0 + zz : col0 + (int64_t)((wave * MT) * RPM + rr) * Z + zz;
+  const int64_t oplane = PS ? (int64_t)4 * Y * Z : (int64_t)Y * Z;
   auto out_ch = [&](int t) -> int { return t * 16 + g * 4; };
 
   uint2 auxv[AUXM ? MT : 1][AUXM ? NT : 1], auxn[AUXM ? MT : 1][AUXM ? NT : 1];
@@ -398,11 +405,15 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
+      if constexpr (PS) {
+        if (ks != 4 && ks != 5 && ks != 7 && ks != 8) continue;  // taps (dx, dy) in {0, +1}^2 of the 3x3 stencil: K-step = tap with four channel groups
+      }
+      const int wks = PS ? (ks == 4 ? 0 : (ks == 5 ? 1 : (ks == 7 ? 2 : 3))) : ks;  // tap dx * 2 + dy of the packed weights
       bf16x8 w[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        if constexpr (WREG) w[t] = wreg[ks][t];
-        else w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (ks * NT + t) * 1024);
+        if constexpr (WREG) w[t] = wreg[wks][t];
+        else w[t] = *reinterpret_cast<const bf16x8*>(Wlane + (wks * NT + t) * 1024);
       }
       const char* hb = Rl + koff[ks] + (dxk[ks] == 0 ? sm1 : (dxk[ks] == 1 ? s0 : sp1));
 #pragma unroll
@@ -425,13 +436,13 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
       constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int64_t ovox = ovox0 + (int64_t)m * RPM * Z;
+        const int64_t ovox = ovox0 + (int64_t)m * RPM * Z * (PS ? 2 : 1);
         float gt = 1.f;
         if constexpr (AUXM) gt = k.aux_mode == 4 ? 1.f + gatev[m] : 1.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           const int c = t * 16 + g * 4;
-          if (c >= cout) continue;
+          if (!PS && c >= cout) continue;
           const float4 bi = *reinterpret_cast<const float4*>(epi + c);
           float val[4] = {acc[m][t][0] + bi.x, acc[m][t][1] + bi.y, acc[m][t][2] + bi.z, acc[m][t][3] + bi.w};
           if constexpr (STATS) {
@@ -479,7 +490,9 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
               val[2] = vsseg_fma_unpacked(av.z, gt, val[2]); val[3] = vsseg_fma_unpacked(av.w, gt, val[3]);
             }
           }
-          char* op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + ovox * k.out_vox_bytes + out_ch(t) * (int)out_es;
+          char* op;
+          if constexpr (PS) op = k.out0 + (ovox + (int64_t)(t >> 1) * (2 * Y) * Z + (t & 1) * Z) * k.out_vox_bytes + g * 8;  // class (px, py) = (t >> 1, t & 1): + px fine planes, + py fine rows
+          else op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + ovox * k.out_vox_bytes + out_ch(t) * (int)out_es;
           if constexpr (KIND != 2) {
             st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
           } else if (vec_store) {
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     for (int i = tid; i < 2 * NT * 16; i += 256) {
       const int which = i / (NT * 16), c = i - which * NT * 16;
       const float v = (red[i] + red[2 * NT * 16 + i]) + (red[4 * NT * 16 + i] + red[6 * NT * 16 + i]);
-      if (c < cout) vsseg_fx_add(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)v, VSSEG_FX_STAT, k.fxflag);
+      if (PS || c < cout) vsseg_fx_add(&st[which * k.stats_stride + (k.cout_mod > 0 ? c % k.cout_mod : c)], (double)v, VSSEG_FX_STAT, k.fxflag);
     }
   }
 }
@@ -612,7 +625,32 @@ template <int CIN, int NT, int TZ, int MT> static int mc_launch_c1(const MconvK&
   if (k.aux_mode) return mc_launch_c1_mode<CIN, NT, TZ, MT, 2, 1>(k, grid, s);
   return mc_launch_c1_mode<CIN, NT, TZ, MT, 0, 1>(k, grid, s);
 }
+template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds_ps() {  // pixel-shuffle launches stage 4 of the 9 K-steps of weights
+  constexpr int G = CIN / 8, RS = TZ * G, RPM = 16 / TZ, ROWS = MT * 4 * RPM + 2;
+  constexpr int red = 4 * 2 * NT * 16 * 4;
+  const int lds = (WREG ? 0 : 4 * NT * 1024) + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
+  return lds > red ? lds : red;
+}
+template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(const MconvK& k, int grid, hipStream_t s) {
+  if constexpr (CIN == 32 && NT == 4) {
+    static bool init = false;
+    const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
+    if (!init) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      init = true;
+    }
+    if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, fused output-parity classes)");
+    return VSSEG_OK;
+  } else {
+    vsseg_set_error("vsseg_igemm: the marching kernel runs fused output-parity classes for 32 input channels and 4 class tiles only");
+    return VSSEG_EINVAL;
+  }
+}
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
+  if (k.ps) return mc_launch_ps<CIN, NT, TZ, MT, WREG>(k, grid, s);
   if (k.in_sc) {  // the preceding BatchNorm -> Dropout -> PReLU block applied on load: the second convolutions of the level-0 / level-1 encoder units
     if constexpr ((CIN == 16 && NT == 1) || (CIN == 32 && NT == 2)) {
       if (k.stats && !k.in_gate && !k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 5, WREG>(k, grid, s);
@@ -648,6 +686,23 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   *why = nullptr;
   auto no = [&](const char* w) { *why = w; return (const McEntry*)nullptr; };
   if (d->in.dtype != VSSEG_BF16) return no("input is not bf16");
+  const bool ps = d->os[0] == 2 && d->os[1] == 2 && d->os[2] == 1;  // fused output-parity classes of a stride-(2,2,1) transposed convolution: coarse lattice in, (2x, 2y, z) out, 4 taps
+  if (ps) {
+    if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 4 || d->ck != 32 || d->nt != 4 || d->ksteps != 4) return no("pixel-shuffle launches need one chunk of 32 input channels, 4 taps, 4 class tiles");
+    if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = 0");
+    if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || 2 * d->q[0] != d->out.x || 2 * d->q[1] != d->out.y || d->q[2] != d->out.z) return no("pixel-shuffle output must be (2x, 2y, z) of the lattice");
+    for (int t = 0; t < 4; ++t)
+      if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
+    if (d->out.c != 16 || d->cout_mod != 16 || d->out.ptr2 || d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || d->in.ptr2 || d->in.c != 32 || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15))
+      return no("pixel-shuffle launches need a one-part 32-channel input and a one-part 16-channel bf16 output (cout_mod = 16)");
+    if (d->accumulate || d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || d->in_bn_scale || d->keep_out) return no("pixel-shuffle launches support the plain and the statistics epilogue only");
+    const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
+    if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
+    if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
+    for (const McEntry& e : mc_table)
+      if (e.cin == 32 && e.nt == 4 && e.tz == tz && e.mt == mt && e.nr == 0) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
+    return no("no instantiation for this (channels, nt, tz, mtw)");
+  }
   if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 9) return no("needs nchunks = nsplit = 1 and the 9 taps of a 3x3x1 stencil");
   for (int a = 0; a < 3; ++a)
     if (d->is[a] != 1 || d->os[a] != 1 || d->oo[a] != 0) return no("stride-1 lattices only");
@@ -690,6 +745,7 @@ int vsseg_mconv_lds_bytes(const vsseg_igemm_desc* d) {
   const char* why;
   const McEntry* e = mc_find(d, &why);
   if (!e) { vsseg_set_error("vsseg_igemm: depth -5 / -6 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
+  if (d->os[0] == 2) return (d->depth == -6 ? e->lds_wreg() : e->lds()) - 5 * d->nt * 1024 * (d->depth == -6 ? 0 : 1);  // pixel shuffle: 4 of the 9 K-steps of weights in LDS
   return d->depth == -6 ? e->lds_wreg() : e->lds();
 }
 
@@ -734,6 +790,7 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.fxflag = vsseg_fx_flag();
   k.zeros = zeros;
   k.act = d->act; k.cout = d->out.c; k.cout_mod = d->cout_mod;
+  k.ps = d->os[0] == 2;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.lx = d->tile[0] > k.X ? k.X : d->tile[0];
   k.nxs = (k.X + k.lx - 1) / k.lx; k.nyb = k.Y / d->tile[1]; k.nzb = k.Z / d->tile[2];

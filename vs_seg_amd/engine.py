@@ -233,8 +233,8 @@ class Plan:
                 # (planner.shuffle_plan): the per-class launches each read the whole input
                 kreal, nreal = P.gemm_dims(kind, Lr.wshape)
                 sps = P.shuffle_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
-                if sps is not None:
-                    return [_Choice([sp], woff, wshape=tuple(Lr.wshape)) for sp in sps]
+                if sps is not None:  # (+ the marching variants where they exist: measured against the streaming launch by the tuner; the untuned lowering keeps the streaming one)
+                    return [_Choice([sp] + (P.march_shuffle_plans(sp, self.n) if (self.tune and eng.march_shuffle) else []), woff, wshape=tuple(Lr.wshape)) for sp in sps]
             alt = None
             if eng.class_split and not fold and absorbed is None:
                 # ... and those of the 3x3x3 stride-(2,2,2) transitions of the deep levels as ONE launch of the general kernel (workgroup row = class)
@@ -344,6 +344,8 @@ class Plan:
         d.tile = L.i3(pl.tile)
         d.mtw, d.nt, d.nsplit, d.ck, d.nchunks, d.ksteps, d.depth = pl.mtw, pl.nt, pl.nsplit, pl.ck, pl.nchunks, pl.ksteps, pl.depth
         d.res_tiles = pl.res_tiles
+        if P.is_shuffle(pl):  # fused output-parity classes: output channel tile t is class t, its channels are the real channels 0..nc-1
+            d.cout_mod = pl.nc
         d.class_split = len(pl.classes) if pl.classes is not None else 0
         for s_, c_ in enumerate(pl.classes or ()):  # workgroup row s_ = lattice class s_: its output offset and its taps (indices into the union tap table above)
             d.class_oo[s_][0], d.class_oo[s_][1], d.class_oo[s_][2] = c_.oo
@@ -515,8 +517,6 @@ class Plan:
             else:
                 self._register(ch, pl)
         self._fill_desc(d, pl)
-        if pl.depth == -4:  # fused output-parity classes: output channel tile t is class t, its channels are the real channels 0..nc-1
-            d.cout_mod = pl.nc
         if not probe:
             self._wpack_fixups.append((d, ch.map_off))
             if pl.res_tiles:
@@ -525,9 +525,9 @@ class Plan:
         nvalid = nb  # output voxels this lattice class writes
         for a, oa in enumerate((out.x, out.y, out.z)):
             nvalid *= min(pl.q[a], -(-(oa - pl.cls.oo[a]) // pl.cls.os[a]))
-        if pl.depth == -4:
+        if P.is_shuffle(pl):
             nvalid = nb * out.x * out.y * out.z * (pl.nt * 16 // pl.nc) // 4  # the parity classes this launch writes
-        taps_eff = 2.25 if pl.depth == -4 else pl.ntaps
+        taps_eff = 2.25 if P.is_shuffle(pl) else pl.ntaps
         if pl.classes is not None:  # every output voxel, by the class it belongs to (27 / 8 taps per voxel on average for 3x3x3 stride 2)
             nvalid, taps_eff = nb * out.x * out.y * out.z, sum(len(c_.taps) for c_ in pl.classes) / len(pl.classes)
         es_in, es_out = (2 if inp.dtype == L.BF16 else 4), (2 if out.dtype == L.BF16 else 4)
@@ -1368,6 +1368,7 @@ class Engine:
         # the block in the second convolutions' loaders +0.15 / +0.07, in their backward +0.08 / +0.06: all VALU / latency bound), the wall clock of the step is unchanged
         # (28.79 against 28.87 ms, four alternating pairs on one box) — DESIGN.md §3.9.
         self.bn_onload = os.environ.get("VSSEG_BN_ONLOAD", "0") == "1" and not dry_run
+        self.march_shuffle = os.environ.get("VSSEG_MARCH_SHUFFLE", "1") != "0"  # marching variants of the fused-parity-classes launch of the level-1 -> level-0 transposed convolution as tuner candidates
         self.gate_onload_units = os.environ.get("VSSEG_GATE_ONLOAD_UNITS", "1") != "0"  # ... also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs

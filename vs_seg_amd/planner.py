@@ -384,6 +384,34 @@ def shuffle_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal) -> Opti
     return plans
 
 
+def is_shuffle(pl) -> bool:
+    """A launch that computes fused output-parity classes (pixel shuffle): the streaming kernel's depth -4 plans and their marching variants."""
+    return pl.depth == -4 or (pl.depth in MARCH_DEPTHS and tuple(pl.cls.os) == (2, 2, 1))
+
+
+def march_shuffle_plans(sp: "IgemmPlan", n=1) -> List["IgemmPlan"]:
+    """Marching-kernel variants (csrc/mconv.hip PS) of a fused-parity-classes plan of shuffle_plans: 32 input channels -> four classes of 16 channels (the level-1 ->
+    level-0 transposed convolution).  Same lattice class, taps and packed weights; tile = (coarse x steps per workgroup, coarse rows, z slices); every fine
+    output row is written as tz consecutive 32-byte voxels instead of the streaming kernel's 8x8x4 tiles."""
+    if sp.depth != -4 or sp.kc != 32 or sp.nc != 16 or sp.nt != 4 or tuple(sp.cls.oo) != (0, 0, 0):
+        return []
+    q, out = sp.q, []
+    for (c, t, tz, mt) in sorted(MARCH_SHAPES):
+        tyb = 64 * mt // tz
+        if (c, t) != (32, 4) or q[1] % tyb or q[2] % tz:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            for depth in ((-5, -6) if (c, t, tz, mt) in MARCH_WREG_SHAPES else (-5,)):
+                lds = march_lds_bytes(32, 4, tz, mt, depth == -6) - (0 if depth == -6 else 5 * 4 * 1024)  # 4 of the 9 K-steps of weights are staged
+                pl = dataclasses.replace(sp, tile=(lx, tyb, tz), mtw=mt, lds=lds, depth=depth)
+                if not any(o.tile == pl.tile and o.mtw == pl.mtw and o.depth == pl.depth for o in out):
+                    out.append(pl)
+    return out
+
+
 # ---- compute-bound kernel (csrc/cconv.hip): depth -3 -----------------------------------------------------------------------
 COMPUTE_TILE = (4, 8, 16)
 _TAPS_3x3x3 = [(t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1) for t in range(27)]
