@@ -1216,7 +1216,8 @@ def test_compute_kernel_equals_general_kernel(kind, cin, cout, dims, split):
 
 
 @pytest.mark.parametrize("kind,cin,cout,dims,mode", [("convT_fwd", 32, 16, (8, 16, 8), "stats"), ("convT_fwd", 32, 16, (16, 8, 4), "plain"), ("convT_fwd", 32, 16, (16, 64, 16), "stats"), ("convT_fwd", 32, 16, (8, 32, 8), "plain"), ("conv_dgrad", 16, 16, (8, 16, 8), "accumulate"),
-                                                     ("conv_dgrad", 16, 16, (16, 16, 4), "plain"), ("convT_fwd", 48, 32, (8, 16, 8), "stats"), ("conv_dgrad", 32, 32, (8, 8, 8), "accumulate")])
+                                                     ("conv_dgrad", 16, 16, (16, 16, 4), "plain"), ("convT_fwd", 48, 32, (8, 16, 8), "stats"), ("conv_dgrad", 32, 32, (8, 8, 8), "accumulate"),
+                                                     ("convT_fwd", 48, 32, (16, 32, 8), "stats"), ("convT_fwd", 48, 32, (8, 64, 16), "plain")])
 def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mode):
     """depth -4: the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient as ONE launch of the
     streaming kernel (coarse lattice, 2x2x1 neighbourhood, 4 x 16 output channels, pixel-shuffle store).  Must equal the four per-class
@@ -1281,6 +1282,23 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
             L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"marching fused classes {mp2.tile} depth {mp2.depth}")
             torch.cuda.synchronize()
             assert torch.equal(out_c, out_b), f"marching variant tile {mp2.tile} mtw {mp2.mtw} depth {mp2.depth} differs (max {float((out_c.float() - out_b.float()).abs().max())})"
+            if mode == "stats":
+                cc = H.stat_decode(sc).view(L.STAT_SHARDS, 2, -1).sum(0)
+                np.testing.assert_allclose(cc.cpu().numpy(), bb.cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+    # 48 -> 32 channels: ALL four classes as ONE marching launch (8 channel tiles, 6 channel groups) against the two streaming launches: bit-identical
+    allp = P.march_shuffle_all_plans(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal, n) if mode != "accumulate" else []
+    assert bool(allp) == (kind == "convT_fwd" and cin == 48 and cout == 32 and dims[1] % 32 == 0)
+    for mp in allp:
+        for lx in sorted({mp.tile[0], max(1, dims[0] // 3)}):
+            mp2 = dataclasses.replace(mp, tile=(lx, mp.tile[1], mp.tile[2]))
+            out_c = torch.full_like(out_a, float("nan"))
+            sc = stats_buf()
+            d = H.igemm_desc(mp2, H.pack(mp2, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_c), cout_mod=nout, **(dict(stats=sc.data_ptr(), stats_stride=nout) if mode == "stats" else {}))
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"marching all classes {mp2.tile}")
+            torch.cuda.synchronize()
+            assert torch.equal(out_c, out_b), f"all-class marching launch tile {mp2.tile} mtw {mp2.mtw} differs (max {float((out_c.float() - out_b.float()).abs().max())})"
             if mode == "stats":
                 cc = H.stat_decode(sc).view(L.STAT_SHARDS, 2, -1).sum(0)
                 np.testing.assert_allclose(cc.cpu().numpy(), bb.cpu().numpy(), rtol=1e-5, atol=1e-3)

@@ -79,14 +79,20 @@ struct MconvK {
 // CC = 1 / 2 (CIN 8 only): the input is a COMPACT one- / two-channel tensor [N][X][Y][Z][CC] (2 / 4 bytes per voxel: the network input, the pre-sigmoid gradient of an
 // attention map; the gradient of the two logits) instead of its zero-extension to one 8-channel group (16 bytes per voxel, most of them zeros read from HBM): the thread
 // that owns a plane slot loads the voxel's value(s) one step ahead (ordinary load into a register) and writes the zero-extended 16-byte piece into the ring itself.
-// PS (CIN 32, NT 4): the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution as ONE marching launch on the COARSE lattice ("pixel shuffle",
-// as sconv.hip's TAPS 4): output channel tile t is class (px, py) = (t >> 1, t & 1), stored at fine voxel (2x + px, 2y + py, z); the 2x2x1 neighbourhood (+0 / +1) of the
-// launch are the taps (1,1), (1,2), (2,1), (2,2) of this kernel's 3x3 stencil — with 4 channel groups a K-step is exactly one tap, so the five other K-steps are
-// skipped at compile time and the packed weights [4 taps][NT][64][8] are sconv's.  Every fine output row is written as TZ consecutive 32-byte voxels.
-template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int CC = 0, bool PS = false>
+// PS = TPC > 0 (NT = 4 * TPC): ALL four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution as ONE marching launch on the COARSE lattice ("pixel
+// shuffle", as sconv.hip's TAPS 4): output channel tile t is tile t % TPC of class (px, py) = ((t / TPC) >> 1, (t / TPC) & 1), stored at fine voxel (2x + px, 2y + py, z).
+// The K loop runs the 4 taps of the 2x2x1 neighbourhood (+0 / +1: the lower-right corner of this kernel's 3x3 stencil, the other five taps are never multiplied), K-group
+// p = ks*4 + g -> (tap p / G = dx*2 + dy, piece p % G); packed weights [(4G + 3) / 4][NT][64][8].  Every fine output row is written as TZ consecutive voxels.
+// G need not be a power of two (48 input channels: mc_mod).
+template <int G> __device__ __forceinline__ int mc_mod(int v) {  // v mod G, v may be negative
+  if constexpr ((G & (G - 1)) == 0) return v & (G - 1);
+  else return ((v % G) + G) % G;
+}
+template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int CC = 0, int TPC = 0>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
+  constexpr bool PS = TPC > 0;
   static_assert(CC == 0 || CIN == 8, "compact inputs are one zero-extended channel group");
-  static_assert(!PS || (CIN == 32 && NT == 4 && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1)), "pixel-shuffle launches: 32 input channels, four class tiles, plain / statistics epilogue");
+  static_assert(!PS || (NT == 4 * TPC && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1)), "pixel-shuffle launches: four classes of TPC tiles, plain / statistics epilogue");
   constexpr bool C1 = CC != 0;
   constexpr bool STATS = MODE == 1 || MODE == 4 || MODE == 5, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr bool BIN = MODE == 5;  // statistics + the preceding BatchNorm -> Dropout -> PReLU block applied to the input on load
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
-  constexpr int KSTEPS = (9 * G + 3) / 4, KSW = PS ? 4 : KSTEPS, W_BYTES = WREG ? 0 : KSW * NT * 1024;  // (KSW: K-steps that have packed weights)
+  constexpr int KSTEPS = PS ? (4 * G + 3) / 4 : (9 * G + 3) / 4, KSW = KSTEPS, W_BYTES = WREG ? 0 : KSW * NT * 1024;
   constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   for (int u = 0; u < NINST; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
     const int r = j / RS, within = j % RS, pp = within / TZ, z = within % TZ;
-    const int pc = (pp - 2 * (r * RS / 16)) & (G - 1);
+    const int pc = mc_mod<G>(pp - 2 * (r * RS / 16));
     const int gy = y0 + r - 1;
     const bool ok = j < PLANE_SLOTS && (unsigned)gy < (unsigned)Y;
     rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + (C1 ? 0 : pc * 16) : 0;
@@ -286,11 +292,12 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
     int p = ks * 4 + g;
-    if (p >= 9 * G) p -= 9 * G;  // padded K-groups: zero weights times a genuine tap of the same voxel (conflict-free like the real ones)
-    const int tap = p / G, pc = p % G, dy = tap % 3 - 1;
+    constexpr int NTAPG = (PS ? 4 : 9) * G;
+    if (p >= NTAPG) p -= NTAPG;  // padded K-groups: zero weights times a genuine tap of the same voxel (conflict-free like the real ones)
+    const int tap = p / G, pc = p % G, dy = PS ? (tap & 1) : tap % 3 - 1;  // PS: tap = dx*2 + dy with dx, dy in {0, +1}
     const int row = 1 + rr + dy;  // + the M-tile's first row (a multiple of RPM: it does not change the swizzle term)
-    koff[ks] = (row * RS + ((pc + 2 * (row * RS / 16)) & (G - 1)) * TZ + zz) * 16 + wave * (MT * MT_BYTES);
-    dxk[ks] = tap / 3;
+    koff[ks] = (row * RS + mc_mod<G>(pc + 2 * (row * RS / 16)) * TZ + zz) * 16 + wave * (MT * MT_BYTES);
+    dxk[ks] = PS ? 1 + (tap >> 1) : tap / 3;
   }
   const unsigned out_es = k.out_f32 ? 4u : 2u;
   const bool vec_store = (cout & 3) == 0;
@@ -405,10 +412,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      if constexpr (PS) {
-        if (ks != 4 && ks != 5 && ks != 7 && ks != 8) continue;  // taps (dx, dy) in {0, +1}^2 of the 3x3 stencil: K-step = tap with four channel groups
-      }
-      const int wks = PS ? (ks == 4 ? 0 : (ks == 5 ? 1 : (ks == 7 ? 2 : 3))) : ks;  // tap dx * 2 + dy of the packed weights
+      const int wks = ks;
       bf16x8 w[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
             }
           }
           char* op;
-          if constexpr (PS) op = k.out0 + (ovox + (int64_t)(t >> 1) * (2 * Y) * Z + (t & 1) * Z) * k.out_vox_bytes + g * 8;  // class (px, py) = (t >> 1, t & 1): + px fine planes, + py fine rows
+          if constexpr (PS) op = k.out0 + (ovox + (int64_t)((t / TPC) >> 1) * (2 * Y) * Z + ((t / TPC) & 1) * Z) * k.out_vox_bytes + (t % TPC) * 32 + g * 8;  // class (px, py): + px fine planes, + py fine rows
           else op = (t * 16 >= k.out_csplit ? k.out1 : k.out0) + ovox * k.out_vox_bytes + out_ch(t) * (int)out_es;
           if constexpr (KIND != 2) {
             st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
@@ -625,29 +629,34 @@ template <int CIN, int NT, int TZ, int MT> static int mc_launch_c1(const MconvK&
   if (k.aux_mode) return mc_launch_c1_mode<CIN, NT, TZ, MT, 2, 1>(k, grid, s);
   return mc_launch_c1_mode<CIN, NT, TZ, MT, 0, 1>(k, grid, s);
 }
-template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds_ps() {  // pixel-shuffle launches stage 4 of the 9 K-steps of weights
+template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds_ps() {  // pixel-shuffle launches: (4G + 3) / 4 K-steps of weights
   constexpr int G = CIN / 8, RS = TZ * G, RPM = 16 / TZ, ROWS = MT * 4 * RPM + 2;
   constexpr int red = 4 * 2 * NT * 16 * 4;
-  const int lds = (WREG ? 0 : 4 * NT * 1024) + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
+  const int lds = (WREG ? 0 : ((4 * G + 3) / 4) * NT * 1024) + MC_NR * ((ROWS * RS * 16 + 255) / 256 * 256) + 5 * NT * 16 * 4 + 16;
   return lds > red ? lds : red;
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(const MconvK& k, int grid, hipStream_t s) {
-  if constexpr (CIN == 32 && NT == 4) {
+  if constexpr ((CIN == 32 && NT == 4) || (CIN == 48 && NT == 8 && !WREG)) {
+    constexpr int TPC = NT / 4;
     static bool init = false;
     const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
     if (!init) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       init = true;
     }
-    if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
-    else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
     VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, fused output-parity classes)");
     return VSSEG_OK;
   } else {
-    vsseg_set_error("vsseg_igemm: the marching kernel runs fused output-parity classes for 32 input channels and 4 class tiles only");
+    vsseg_set_error("vsseg_igemm: the marching kernel runs fused output-parity classes for 32 -> 4 x 16 and 48 -> 4 x 32 channels only");
     return VSSEG_EINVAL;
   }
+}
+template <int CIN, int NT, int TZ, int MT> static int mc_launch_psonly(const MconvK& k, int grid, hipStream_t s) {  // table entries that exist for pixel-shuffle launches only
+  if (!k.ps) { vsseg_set_error("vsseg_igemm: this marching-kernel shape is instantiated for fused output-parity classes only"); return VSSEG_EINVAL; }
+  return mc_launch_ps<CIN, NT, TZ, MT, false>(k, grid, s);
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.ps) return mc_launch_ps<CIN, NT, TZ, MT, WREG>(k, grid, s);
@@ -672,6 +681,7 @@ struct McEntry { int cin, nt, tz, mt; mc_fn_t fn; int (*lds)(); mc_fn_t fn_wreg;
 #define MC_E(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, nullptr, nullptr}
 #define MC_1(N, Z, M) {8, N, Z, M, mc_launch<8, N, Z, M, false>, mc_lds<8, N, Z, M, false>, nullptr, nullptr, 0, mc_launch_c1<8, N, Z, M>}  // one zero-extended channel group, also from a COMPACT one-channel tensor
 #define MC_W(C, N, Z, M) {C, N, Z, M, mc_launch<C, N, Z, M, false>, mc_lds<C, N, Z, M, false>, mc_launch<C, N, Z, M, true>, mc_lds<C, N, Z, M, true>}  // + the depth -6 twin (weights in registers)
+#define MC_P(C, N, Z, M) {C, N, Z, M, mc_launch_psonly<C, N, Z, M>, mc_lds_ps<C, N, Z, M, false>, nullptr, nullptr}  // fused output-parity classes only (48 -> 4 x 32 channels)
 #define MC_R(C, N, R, Z, M) {C, N, Z, M, mc_launch_res<C, N, Z, M, false, R>, mc_lds<C, N, Z, M, false>, mc_launch_res<C, N, Z, M, true, R>, mc_lds<C, N, Z, M, true>, R}  // + R residual tiles (res_tiles)
 // (input channels, 16-channel output tiles, TZ, M-tiles per wave): rows per workgroup TYB = 64 * MT / TZ
 static const McEntry mc_table[] = {
@@ -680,6 +690,7 @@ static const McEntry mc_table[] = {
     MC_E(16, 1, 4, 2), MC_E(16, 1, 8, 4), MC_W(16, 2, 4, 2), MC_W(16, 2, 8, 4), MC_W(32, 1, 4, 2), MC_W(32, 2, 4, 2), MC_1(1, 8, 4), MC_1(2, 8, 4),  // 32-row columns: more, longer marches at batch 1 (sliding-window predictor)
     MC_W(32, 1, 2, 4), MC_W(32, 1, 4, 4), MC_W(32, 1, 2, 2), MC_W(32, 2, 4, 4), MC_W(32, 2, 2, 4), MC_W(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_W(32, 4, 2, 2), MC_W(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
     MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1),                                                    // 64 -> 32 / 16
+    MC_P(48, 8, 4, 2), MC_P(48, 8, 8, 4), MC_P(48, 8, 2, 1), MC_P(48, 8, 4, 4),                                                    // level-2 -> level-1 transposed convolution: 48 -> 4 classes x 32
     MC_R(16, 2, 2, 8, 4), MC_R(16, 2, 2, 8, 8), MC_R(16, 2, 2, 4, 4), MC_R(16, 2, 2, 4, 2), MC_R(64, 2, 2, 2, 1), MC_R(64, 2, 2, 2, 2)};   // ResidualUnit first convolutions of level 1 with their 1x1x1 residual convolution: 16 -> 32 + 32, 64 -> 32 + 32
 
 static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
@@ -688,19 +699,20 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   if (d->in.dtype != VSSEG_BF16) return no("input is not bf16");
   const bool ps = d->os[0] == 2 && d->os[1] == 2 && d->os[2] == 1;  // fused output-parity classes of a stride-(2,2,1) transposed convolution: coarse lattice in, (2x, 2y, z) out, 4 taps
   if (ps) {
-    if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 4 || d->ck != 32 || d->nt != 4 || d->ksteps != 4) return no("pixel-shuffle launches need one chunk of 32 input channels, 4 taps, 4 class tiles");
+    const int tpc = d->ck == 48 ? 2 : 1;
+    if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 4 || (d->ck != 32 && d->ck != 48) || d->nt != 4 * tpc || d->ksteps != (4 * (d->ck / 8) + 3) / 4) return no("pixel-shuffle launches need one chunk of 32 / 48 input channels, 4 taps, 4 / 8 class tiles");
     if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = 0");
     if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || 2 * d->q[0] != d->out.x || 2 * d->q[1] != d->out.y || d->q[2] != d->out.z) return no("pixel-shuffle output must be (2x, 2y, z) of the lattice");
     for (int t = 0; t < 4; ++t)
       if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
-    if (d->out.c != 16 || d->cout_mod != 16 || d->out.ptr2 || d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || d->in.ptr2 || d->in.c != 32 || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15))
-      return no("pixel-shuffle launches need a one-part 32-channel input and a one-part 16-channel bf16 output (cout_mod = 16)");
+    if (d->out.c != 16 * tpc || d->cout_mod != 16 * tpc || d->out.ptr2 || d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || d->in.ptr2 || d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15))
+      return no("pixel-shuffle launches need a one-part 32 / 48-channel input and a one-part 16 / 32-channel bf16 output (cout_mod = channels)");
     if (d->accumulate || d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || d->in_bn_scale || d->keep_out) return no("pixel-shuffle launches support the plain and the statistics epilogue only");
     const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
     if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
     if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
     for (const McEntry& e : mc_table)
-      if (e.cin == 32 && e.nt == 4 && e.tz == tz && e.mt == mt && e.nr == 0) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
+      if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt && e.nr == 0) return (d->depth == -6 && !e.fn_wreg) ? no("no weights-in-registers instantiation (depth -6) for this shape") : &e;
     return no("no instantiation for this (channels, nt, tz, mtw)");
   }
   if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 9) return no("needs nchunks = nsplit = 1 and the 9 taps of a 3x3x1 stencil");
@@ -745,7 +757,7 @@ int vsseg_mconv_lds_bytes(const vsseg_igemm_desc* d) {
   const char* why;
   const McEntry* e = mc_find(d, &why);
   if (!e) { vsseg_set_error("vsseg_igemm: depth -5 / -6 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
-  if (d->os[0] == 2) return (d->depth == -6 ? e->lds_wreg() : e->lds()) - 5 * d->nt * 1024 * (d->depth == -6 ? 0 : 1);  // pixel shuffle: 4 of the 9 K-steps of weights in LDS
+  if (d->os[0] == 2 && d->ck == 32) return (d->depth == -6 ? e->lds_wreg() : e->lds()) - 5 * d->nt * 1024 * (d->depth == -6 ? 0 : 1);  // pixel shuffle: 4 of the 9 K-steps of weights in LDS (the 48-channel entries' lds() is already the pixel-shuffle figure)
   return d->depth == -6 ? e->lds_wreg() : e->lds();
 }
 

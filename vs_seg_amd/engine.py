@@ -234,7 +234,11 @@ class Plan:
                 kreal, nreal = P.gemm_dims(kind, Lr.wshape)
                 sps = P.shuffle_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal)
                 if sps is not None:  # (+ the marching variants where they exist: measured against the streaming launch by the tuner; the untuned lowering keeps the streaming one)
-                    return [_Choice([sp] + (P.march_shuffle_plans(sp, self.n) if (self.tune and eng.march_shuffle) else []), woff, wshape=tuple(Lr.wshape)) for sp in sps]
+                    got = [_Choice([sp] + (P.march_shuffle_plans(sp, self.n) if (self.tune and eng.march_shuffle) else []), woff, wshape=tuple(Lr.wshape)) for sp in sps]
+                    allc = P.march_shuffle_all_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, self.n) if (self.tune and eng.march_shuffle and len(sps) == 2) else []
+                    if allc:  # 32 output channels: ONE marching launch for all four classes against the two streaming launches (decided by measurement, _use_class_split)
+                        got[0].alt = _Choice(allc, woff, wshape=tuple(Lr.wshape))
+                    return got
             alt = None
             if eng.class_split and not fold and absorbed is None:
                 # ... and those of the 3x3x3 stride-(2,2,2) transitions of the deep levels as ONE launch of the general kernel (workgroup row = class)

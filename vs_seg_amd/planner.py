@@ -389,6 +389,49 @@ def is_shuffle(pl) -> bool:
     return pl.depth == -4 or (pl.depth in MARCH_DEPTHS and tuple(pl.cls.os) == (2, 2, 1))
 
 
+def march_shuffle_all_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, n=1) -> List["IgemmPlan"]:
+    """ALL four parity classes of a stride-(2,2,1) 3x3x1 transposed convolution with 32 output channels as ONE marching launch (csrc/mconv.hip, TPC = 2: 48 input
+    channels -> 4 classes x 2 tiles; the level-2 -> level-1 transposed convolution) where shuffle_plans needs one streaming launch per px, each reading the whole input.
+    Channel tile t is tile t % 2 of class t // 2; packed weights [6 K-steps][8 tiles][64][8] over the 2x2x1 tap neighbourhood."""
+    if kind != "convT_fwd" or tuple(kernel) != (3, 3, 1) or tuple(stride) != (2, 2, 1) or es != 2 or (nreal, kc) != (32, 48) or kc != kreal:
+        return []
+    classes = lattice_classes(kind, kernel, stride)
+    if [tuple(c.oo) for c in classes] != [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)]:
+        return []
+    taps = [((dx, dy, 0), (0, 0, 0)) for dx in (0, 1) for dy in (0, 1)]
+    g, tpc, nt = kc // 8, 2, 8
+    ksteps = (4 * g + 3) // 4
+    kidx = np.full((4, 4), -1, np.int64)  # [class][tap] -> flat kernel index
+    for ci, cl in enumerate(classes):
+        for off, w in cl.taps:
+            kidx[ci, off[0] * 2 + off[1]] = (w[0] * wshape[3] + w[1]) * wshape[4] + w[2]
+    ks, t, lane, j = np.meshgrid(np.arange(ksteps), np.arange(nt), np.arange(64), np.arange(8), indexing="ij")
+    p = ks * 4 + (lane >> 4)
+    tap, cg = np.minimum(p // g, 3), p % g
+    c, nn = cg * 8 + j, (t % tpc) * 16 + (lane & 15)
+    d = kidx[t // tpc, tap]
+    valid = (p < 4 * g) & (d >= 0) & (c < kreal) & (nn < nreal)
+    flat = weight_flat_index(kind, wshape, np.where(valid, c, 0), np.where(valid, nn, 0), np.where(valid, d, 0))
+    pm = np.where(valid, flat, -1).astype(np.int32).reshape(-1)
+    cls = LatticeClass((2, 2, 1), (0, 0, 0), (1, 1, 1), taps)
+    out = []
+    for (tz, mt) in ((4, 2), (8, 4), (2, 1), (4, 4)):  # the MC_P entries of csrc/mconv.hip
+        tyb = 64 * mt // tz
+        rows = mt * 4 * (16 // tz) + 2
+        lds = ksteps * nt * 1024 + MARCH_RING * round_up(rows * tz * g * 16, 256) + 5 * nt * 16 * 4 + 16
+        if q[1] % tyb or q[2] % tz or lds > 160 * 1024:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (lx, tyb, tz), mt, nt, 1, kc, 1, ksteps, lds, -5)
+            pl.pack_map = pm
+            if not any(o.tile == pl.tile and o.mtw == pl.mtw for o in out):
+                out.append(pl)
+    return out
+
+
 def march_shuffle_plans(sp: "IgemmPlan", n=1) -> List["IgemmPlan"]:
     """Marching-kernel variants (csrc/mconv.hip PS) of a fused-parity-classes plan of shuffle_plans: 32 input channels -> four classes of 16 channels (the level-1 ->
     level-0 transposed convolution).  Same lattice class, taps and packed weights; tile = (coarse x steps per workgroup, coarse rows, z slices); every fine
