@@ -1217,7 +1217,9 @@ def test_compute_kernel_equals_general_kernel(kind, cin, cout, dims, split):
 
 @pytest.mark.parametrize("kind,cin,cout,dims,mode", [("convT_fwd", 32, 16, (8, 16, 8), "stats"), ("convT_fwd", 32, 16, (16, 8, 4), "plain"), ("convT_fwd", 32, 16, (16, 64, 16), "stats"), ("convT_fwd", 32, 16, (8, 32, 8), "plain"), ("conv_dgrad", 16, 16, (8, 16, 8), "accumulate"),
                                                      ("conv_dgrad", 16, 16, (16, 16, 4), "plain"), ("convT_fwd", 48, 32, (8, 16, 8), "stats"), ("conv_dgrad", 32, 32, (8, 8, 8), "accumulate"),
-                                                     ("convT_fwd", 48, 32, (16, 32, 8), "stats"), ("convT_fwd", 48, 32, (8, 64, 16), "plain")])
+                                                     ("convT_fwd", 48, 32, (16, 32, 8), "stats"), ("convT_fwd", 48, 32, (8, 64, 16), "plain"),
+                                                     ("conv_dgrad", 16, 16, (16, 64, 8), "accumulate"), ("conv_dgrad", 16, 16, (8, 32, 8), "plain"), ("conv_dgrad", 32, 32, (8, 32, 8), "accumulate"),
+                                                     ("conv_dgrad", 32, 32, (16, 64, 8), "plain")])
 def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mode):
     """depth -4: the four output-parity classes of a stride-(2,2,1) 3x3x1 transposed convolution / data gradient as ONE launch of the
     streaming kernel (coarse lattice, 2x2x1 neighbourhood, 4 x 16 output channels, pixel-shuffle store).  Must equal the four per-class
@@ -1272,13 +1274,13 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
         np.testing.assert_allclose(bb[0, :nout].cpu().numpy(), want.sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2)
     # the marching variants of the launch (csrc/mconv.hip PS; 32 -> 4 x 16 channels): same taps, packed weights, K order and MFMA order as the streaming launch: bit-identical
     mps = P.march_shuffle_plans(pls[0], n) if len(pls) == 1 else []
-    assert bool(mps) == (kind == "convT_fwd" and cin == 32 and cout == 16 and dims[1] % 32 == 0)  # (column blocks of 32 or 64 coarse rows)
+    assert bool(mps) == (((kind == "convT_fwd" and cin == 32) or (kind == "conv_dgrad" and cin == 16)) and cout == 16 and dims[1] % 32 == 0)  # (column blocks of 32 or 64 coarse rows)
     for mp in mps:
         for lx in sorted({mp.tile[0], max(1, dims[0] // 3)}):  # (also with x segments that do not divide the extent)
             mp2 = dataclasses.replace(mp, tile=(lx, mp.tile[1], mp.tile[2]))
-            out_c = torch.full_like(out_a, float("nan"))
+            out_c = prev.clone() if mode == "accumulate" else torch.full_like(out_a, float("nan"))
             sc = stats_buf()
-            d = H.igemm_desc(mp2, H.pack(mp2, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_c), cout_mod=nout, **(dict(stats=sc.data_ptr(), stats_stride=nout) if mode == "stats" else {}))
+            d = H.igemm_desc(mp2, H.pack(mp2, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_c), cout_mod=nout, **(dict(stats=sc.data_ptr(), stats_stride=nout) if mode == "stats" else kw))
             L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"marching fused classes {mp2.tile} depth {mp2.depth}")
             torch.cuda.synchronize()
             assert torch.equal(out_c, out_b), f"marching variant tile {mp2.tile} mtw {mp2.mtw} depth {mp2.depth} differs (max {float((out_c.float() - out_b.float()).abs().max())})"
@@ -1288,14 +1290,14 @@ def test_fused_parity_classes_equal_per_class_launches(kind, cin, cout, dims, mo
 
 
     # 48 -> 32 channels: ALL four classes as ONE marching launch (8 channel tiles, 6 channel groups) against the two streaming launches: bit-identical
-    allp = P.march_shuffle_all_plans(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal, n) if mode != "accumulate" else []
-    assert bool(allp) == (kind == "convT_fwd" and cin == 48 and cout == 32 and dims[1] % 32 == 0)
+    allp = P.march_shuffle_all_plans(kind, tuple(w.shape), k, st, dims, 2, inp_cl.shape[-1], nreal, kreal, n)
+    assert bool(allp) == (((kind == "convT_fwd" and cin == 48) or (kind == "conv_dgrad" and cin == 32)) and cout == 32 and dims[1] % 32 == 0)
     for mp in allp:
         for lx in sorted({mp.tile[0], max(1, dims[0] // 3)}):
             mp2 = dataclasses.replace(mp, tile=(lx, mp.tile[1], mp.tile[2]))
-            out_c = torch.full_like(out_a, float("nan"))
+            out_c = prev.clone() if mode == "accumulate" else torch.full_like(out_a, float("nan"))
             sc = stats_buf()
-            d = H.igemm_desc(mp2, H.pack(mp2, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_c), cout_mod=nout, **(dict(stats=sc.data_ptr(), stats_stride=nout) if mode == "stats" else {}))
+            d = H.igemm_desc(mp2, H.pack(mp2, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_c), cout_mod=nout, **(dict(stats=sc.data_ptr(), stats_stride=nout) if mode == "stats" else kw))
             L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"marching all classes {mp2.tile}")
             torch.cuda.synchronize()
             assert torch.equal(out_c, out_b), f"all-class marching launch tile {mp2.tile} mtw {mp2.mtw} differs (max {float((out_c.float() - out_b.float()).abs().max())})"

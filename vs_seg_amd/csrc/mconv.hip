@@ -92,7 +92,7 @@ template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG, int NR = 0, int 
 __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr bool PS = TPC > 0;
   static_assert(CC == 0 || CIN == 8, "compact inputs are one zero-extended channel group");
-  static_assert(!PS || (NT == 4 * TPC && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1)), "pixel-shuffle launches: four classes of TPC tiles, plain / statistics epilogue");
+  static_assert(!PS || (NT == 4 * TPC && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1 || MODE == 2)), "pixel-shuffle launches: four classes of TPC tiles; plain / statistics / accumulating epilogue");
   constexpr bool C1 = CC != 0;
   constexpr bool STATS = MODE == 1 || MODE == 4 || MODE == 5, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr bool BIN = MODE == 5;  // statistics + the preceding BatchNorm -> Dropout -> PReLU block applied to the input on load
@@ -324,7 +324,14 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
       const int64_t vox0 = ocol + (int64_t)(xb - 1 + i) * oplane;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int64_t vox = vox0 + (int64_t)m * RPM * Z;
+        const int64_t vox = vox0 + (int64_t)m * RPM * Z * (PS ? 2 : 1);
+        if constexpr (PS) {  // accumulate: the previous gradient at the fine voxels this step stores to (same addresses as the store)
+          gv[m] = 0.f;
+#pragma unroll
+          for (int t = 0; t < NT; ++t)
+            av[m][t] = *reinterpret_cast<const uint2*>(k.aux0 + (vox + (int64_t)((t / (PS ? TPC : 1)) >> 1) * (2 * Y) * Z + ((t / (PS ? TPC : 1)) & 1) * Z) * k.aux_vox_bytes + (t % (PS ? TPC : 1)) * 32 + g * 8);
+          continue;
+        }
         gv[m] = k.aux_mode == 4 ? k.gate[vox] : (k.aux_mode == 5 ? bf2f(k.x1c[vox]) : 0.f);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -636,7 +643,7 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds_ps() {  
   return lds > red ? lds : red;
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(const MconvK& k, int grid, hipStream_t s) {
-  if constexpr ((CIN == 32 && NT == 4) || (CIN == 48 && NT == 8 && !WREG)) {
+  if constexpr ((CIN == 32 && NT == 4) || (CIN == 48 && NT == 8 && !WREG)) {  // the transposed convolutions: plain (eval) / statistics epilogue
     constexpr int TPC = NT / 4;
     static bool init = false;
     const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
@@ -645,12 +652,27 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(co
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       init = true;
     }
+    if (k.aux_mode) { vsseg_set_error("vsseg_igemm: this pixel-shuffle shape has no accumulating instantiation"); return VSSEG_EINVAL; }
     if (k.stats) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 1, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
     else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
     VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, fused output-parity classes)");
     return VSSEG_OK;
+  } else if constexpr (((CIN == 16 && NT == 4) || (CIN == 32 && NT == 8)) && !WREG) {  // the data gradients of the strided convolutions: plain / accumulating epilogue
+    constexpr int TPC = NT / 4;
+    static bool init = false;
+    const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
+    if (!init) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 2, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      init = true;
+    }
+    if (k.stats) { vsseg_set_error("vsseg_igemm: this pixel-shuffle shape has no statistics instantiation"); return VSSEG_EINVAL; }
+    if (k.aux_mode) hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 2, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    else hipLaunchKernelGGL((mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), dim3((unsigned)grid), dim3(256), lds, s, k);
+    VSSEG_LAUNCH_CHECK("vsseg_igemm (marching, fused output-parity classes)");
+    return VSSEG_OK;
   } else {
-    vsseg_set_error("vsseg_igemm: the marching kernel runs fused output-parity classes for 32 -> 4 x 16 and 48 -> 4 x 32 channels only");
+    vsseg_set_error("vsseg_igemm: the marching kernel runs fused output-parity classes for 16 / 32 -> 4 x 16, 32 / 48 -> 4 x 32 channels only");
     return VSSEG_EINVAL;
   }
 }
@@ -691,6 +713,7 @@ static const McEntry mc_table[] = {
     MC_W(32, 1, 2, 4), MC_W(32, 1, 4, 4), MC_W(32, 1, 2, 2), MC_W(32, 2, 4, 4), MC_W(32, 2, 2, 4), MC_W(32, 2, 2, 2), MC_E(32, 4, 4, 4), MC_W(32, 4, 2, 2), MC_W(32, 4, 4, 2),  // 32 -> 2 / 16 / 32 / 64
     MC_W(64, 2, 2, 2), MC_W(64, 2, 2, 1), MC_W(64, 1, 2, 2), MC_W(64, 1, 2, 1),                                                    // 64 -> 32 / 16
     MC_P(48, 8, 4, 2), MC_P(48, 8, 8, 4), MC_P(48, 8, 2, 1), MC_P(48, 8, 4, 4),                                                    // level-2 -> level-1 transposed convolution: 48 -> 4 classes x 32
+    MC_P(16, 4, 8, 4), MC_P(16, 4, 4, 2), MC_P(16, 4, 4, 4), MC_P(16, 4, 8, 8), MC_P(32, 8, 4, 2), MC_P(32, 8, 8, 4), MC_P(32, 8, 2, 1), MC_P(32, 8, 4, 4),  // data gradients of the stride-(2,2,1) convolutions: 16 -> 4 x 16, 32 -> 4 x 32
     MC_R(16, 2, 2, 8, 4), MC_R(16, 2, 2, 8, 8), MC_R(16, 2, 2, 4, 4), MC_R(16, 2, 2, 4, 2), MC_R(64, 2, 2, 2, 1), MC_R(64, 2, 2, 2, 2)};   // ResidualUnit first convolutions of level 1 with their 1x1x1 residual convolution: 16 -> 32 + 32, 64 -> 32 + 32
 
 static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
@@ -699,15 +722,15 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
   if (d->in.dtype != VSSEG_BF16) return no("input is not bf16");
   const bool ps = d->os[0] == 2 && d->os[1] == 2 && d->os[2] == 1;  // fused output-parity classes of a stride-(2,2,1) transposed convolution: coarse lattice in, (2x, 2y, z) out, 4 taps
   if (ps) {
-    const int tpc = d->ck == 48 ? 2 : 1;
-    if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 4 || (d->ck != 32 && d->ck != 48) || d->nt != 4 * tpc || d->ksteps != (4 * (d->ck / 8) + 3) / 4) return no("pixel-shuffle launches need one chunk of 32 / 48 input channels, 4 taps, 4 / 8 class tiles");
+    const int tpc = d->nt / 4;
+    if (d->nchunks != 1 || d->nsplit != 1 || d->ntaps != 4 || (d->ck != 16 && d->ck != 32 && d->ck != 48) || (d->nt != 4 && d->nt != 8) || d->ksteps != (4 * (d->ck / 8) + 3) / 4) return no("pixel-shuffle launches need one chunk of 16 / 32 / 48 input channels, 4 taps, 4 / 8 class tiles");
     if (d->is[0] != 1 || d->is[1] != 1 || d->is[2] != 1 || d->oo[0] || d->oo[1] || d->oo[2]) return no("pixel-shuffle launches need is = 1, os = (2, 2, 1), oo = 0");
     if (d->q[0] != d->in.x || d->q[1] != d->in.y || d->q[2] != d->in.z || 2 * d->q[0] != d->out.x || 2 * d->q[1] != d->out.y || d->q[2] != d->out.z) return no("pixel-shuffle output must be (2x, 2y, z) of the lattice");
     for (int t = 0; t < 4; ++t)
       if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
     if (d->out.c != 16 * tpc || d->cout_mod != 16 * tpc || d->out.ptr2 || d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || d->in.ptr2 || d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15))
       return no("pixel-shuffle launches need a one-part 32 / 48-channel input and a one-part 16 / 32-channel bf16 output (cout_mod = channels)");
-    if (d->accumulate || d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || d->in_bn_scale || d->keep_out) return no("pixel-shuffle launches support the plain and the statistics epilogue only");
+    if (d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || d->in_bn_scale || d->keep_out || (d->accumulate && d->stats)) return no("pixel-shuffle launches support the plain, the statistics and the accumulating epilogue only");
     const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
     if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
     if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
@@ -757,7 +780,7 @@ int vsseg_mconv_lds_bytes(const vsseg_igemm_desc* d) {
   const char* why;
   const McEntry* e = mc_find(d, &why);
   if (!e) { vsseg_set_error("vsseg_igemm: depth -5 / -6 (marching kernel) not applicable: %s", why); return VSSEG_EINVAL; }
-  if (d->os[0] == 2 && d->ck == 32) return (d->depth == -6 ? e->lds_wreg() : e->lds()) - 5 * d->nt * 1024 * (d->depth == -6 ? 0 : 1);  // pixel shuffle: 4 of the 9 K-steps of weights in LDS (the 48-channel entries' lds() is already the pixel-shuffle figure)
+  if (d->os[0] == 2 && d->ck == 32 && d->nt == 4) return (d->depth == -6 ? e->lds_wreg() : e->lds()) - 5 * d->nt * 1024 * (d->depth == -6 ? 0 : 1);  // pixel shuffle on a general entry: 4 of the 9 K-steps of weights in LDS (the MC_P entries' lds() is already the pixel-shuffle figure)
   return d->depth == -6 ? e->lds_wreg() : e->lds();
 }
 

@@ -393,8 +393,8 @@ def march_shuffle_all_plans(kind, wshape, kernel, stride, q, es, kc, nreal, krea
     """ALL four parity classes of a stride-(2,2,1) 3x3x1 transposed convolution with 32 output channels as ONE marching launch (csrc/mconv.hip, TPC = 2: 48 input
     channels -> 4 classes x 2 tiles; the level-2 -> level-1 transposed convolution) where shuffle_plans needs one streaming launch per px, each reading the whole input.
     Channel tile t is tile t % 2 of class t // 2; packed weights [6 K-steps][8 tiles][64][8] over the 2x2x1 tap neighbourhood."""
-    if kind != "convT_fwd" or tuple(kernel) != (3, 3, 1) or tuple(stride) != (2, 2, 1) or es != 2 or (nreal, kc) != (32, 48) or kc != kreal:
-        return []
+    if kind not in ("convT_fwd", "conv_dgrad") or tuple(kernel) != (3, 3, 1) or tuple(stride) != (2, 2, 1) or es != 2 or (kind, nreal, kc) not in (("convT_fwd", 32, 48), ("conv_dgrad", 32, 32)) or kc != kreal:
+        return []  # (the level-2 -> level-1 transposed convolution; the data gradient of the level-1 -> level-2 strided convolution)
     classes = lattice_classes(kind, kernel, stride)
     if [tuple(c.oo) for c in classes] != [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0)]:
         return []
@@ -436,9 +436,24 @@ def march_shuffle_plans(sp: "IgemmPlan", n=1) -> List["IgemmPlan"]:
     """Marching-kernel variants (csrc/mconv.hip PS) of a fused-parity-classes plan of shuffle_plans: 32 input channels -> four classes of 16 channels (the level-1 ->
     level-0 transposed convolution).  Same lattice class, taps and packed weights; tile = (coarse x steps per workgroup, coarse rows, z slices); every fine
     output row is written as tz consecutive 32-byte voxels instead of the streaming kernel's 8x8x4 tiles."""
-    if sp.depth != -4 or sp.kc != 32 or sp.nc != 16 or sp.nt != 4 or tuple(sp.cls.oo) != (0, 0, 0):
-        return []
+    if sp.depth != -4 or (sp.kind, sp.kc) not in (("convT_fwd", 32), ("conv_dgrad", 16)) or sp.nc != 16 or sp.nt != 4 or tuple(sp.cls.oo) != (0, 0, 0):
+        return []  # (the level-1 -> level-0 transposed convolution; the data gradient of the level-0 -> level-1 strided convolution)
     q, out = sp.q, []
+    if sp.kc == 16:  # entries that exist for pixel-shuffle launches only (MC_P of csrc/mconv.hip)
+        g, ksteps = 2, 2
+        for (tz, mt) in ((8, 4), (4, 2), (4, 4), (8, 8)):
+            tyb = 64 * mt // tz
+            rows = mt * 4 * (16 // tz) + 2
+            lds = ksteps * 4 * 1024 + MARCH_RING * round_up(rows * tz * g * 16, 256) + 5 * 4 * 16 * 4 + 16
+            if q[1] % tyb or q[2] % tz:
+                continue
+            cols = n * (q[1] // tyb) * (q[2] // tz)
+            for target in (512, 1024):
+                nxs = max(1, min(q[0] // 8, -(-target // cols)))
+                pl = dataclasses.replace(sp, tile=(-(-q[0] // nxs), tyb, tz), mtw=mt, lds=lds, depth=-5)
+                if not any(o.tile == pl.tile and o.mtw == pl.mtw for o in out):
+                    out.append(pl)
+        return out
     for (c, t, tz, mt) in sorted(MARCH_SHAPES):
         tyb = 64 * mt // tz
         if (c, t) != (32, 4) or q[1] % tyb or q[2] % tz:
