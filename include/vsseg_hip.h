@@ -335,6 +335,7 @@ int vsseg_crop_flip(const void* jobs, int32_t njobs, float* dst, const int32_t r
 int vsseg_normalize_intensity(const float* x, float* y, int64_t n, double* acc2, void* stream);
 
 /* Sliding-window blend (MONAI sliding_window_inference steps 6-7; call site ref:params/VSparams.py:568-574). */
+/* (seg == NULL: only cnt += w — the weight map of a window geometry, which does not depend on the data; cnt == NULL: only out += w * seg) */
 int vsseg_swi_accumulate(const float* seg /* [rx][ry][rz][c] */, const float* imap /* [rx][ry][rz] */, const int32_t roi[3], const int32_t start[3], int32_t c,
                          float* out /* [PX][PY][PZ][c] */, float* cnt /* [PX][PY][PZ] */, const int32_t pdims[3], void* stream);
 int vsseg_swi_finalize(const float* out, const float* cnt, const int32_t pdims[3], const int32_t pad_before[3], const int32_t dims[3], int32_t c, float* dst /* [X][Y][Z][c] */, void* stream);

@@ -13,12 +13,13 @@ __global__ void swi_accumulate_kernel(const float* __restrict__ seg, const float
     int y = (int)(r % ry), x = (int)(r / ry);
     const int64_t o = (((int64_t)(sx + x)) * py + (sy + y)) * pz + (sz + z);
     const float w = imap[i];
-    for (int k = 0; k < c; ++k) out[o * c + k] += w * seg[i * c + k];
-    cnt[o] += w;
+    if (seg != nullptr)
+      for (int k = 0; k < c; ++k) out[o * c + k] += w * seg[i * c + k];
+    if (cnt != nullptr) cnt[o] += w;
   }
 }
 extern "C" int vsseg_swi_accumulate(const float* seg, const float* imap, const int32_t roi[3], const int32_t start[3], int32_t c, float* out, float* cnt, const int32_t pdims[3], void* stream) {
-  VSSEG_CHECK(seg && imap && out && cnt && c >= 1, "vsseg_swi_accumulate: bad arguments");
+  VSSEG_CHECK(imap && ((seg && out) || cnt) && (!seg || out) && c >= 1, "vsseg_swi_accumulate: bad arguments");  // seg == NULL: only the weight map; cnt == NULL: only the blend
   for (int a = 0; a < 3; ++a) VSSEG_CHECK(start[a] >= 0 && start[a] + roi[a] <= pdims[a], "vsseg_swi_accumulate: window outside the padded volume (dim %d)", a);
   int64_t total = (int64_t)roi[0] * roi[1] * roi[2];
   hipLaunchKernelGGL(swi_accumulate_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), seg, imap, roi[0], roi[1], roi[2], start[0], start[1], start[2], c, out, cnt, pdims[0], pdims[1], pdims[2]);

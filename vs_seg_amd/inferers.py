@@ -113,6 +113,23 @@ def crop_all_windows(vol: torch.Tensor, b_and_starts, roi, pad_before) -> torch.
 
 
 _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
+_CNT_CACHE: Dict[tuple, torch.Tensor] = {}  # (device, padded extents, roi, window starts, importance map) -> sum of the window weights per voxel
+
+
+def _weight_sum(lib, device, padded, roi, starts, imap: torch.Tensor, stream) -> torch.Tensor:
+    """The denominator of the blend, sum of the importance maps of all windows that cover a voxel (MONAI's count_map): a function of the window geometry only, so it is
+    accumulated once per geometry — in window order, exactly as the per-volume buffer was — and kept (the four most recent geometries)."""
+    key = (str(device), tuple(padded), tuple(roi), tuple(tuple(s) for s in starts), imap.data_ptr())
+    cnt = _CNT_CACHE.get(key)
+    if cnt is None:
+        cnt = torch.zeros(tuple(padded), dtype=torch.float32, device=device)
+        for s0 in starts:
+            L.check(lib.vsseg_swi_accumulate(None, imap.data_ptr(), L.i3(roi), L.i3(s0), 1, None, cnt.data_ptr(), L.i3(padded), stream), "swi_accumulate")
+        torch.cuda.current_stream(device).synchronize()  # (once per geometry: later calls may read it from any stream)
+        while len(_CNT_CACHE) >= 4:
+            _CNT_CACHE.pop(next(iter(_CNT_CACHE)))
+        _CNT_CACHE[key] = cnt
+    return cnt
 
 
 def _side_stream(device, i: int) -> "torch.cuda.Stream":
@@ -149,8 +166,9 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         vol = vol.to(torch.float32).contiguous()
     imap = importance_map(roi, mode, inputs.device)
     slices = [(b, s) for b in range(B) for s in starts]
-    out = cnt = None
+    out = None
     stream = torch.cuda.current_stream().cuda_stream
+    cnt = _weight_sum(lib, inputs.device, padded, roi, starts, imap, stream)  # [padded]: the same for every batch element
     per_win = roi[0] * roi[1] * roi[2] * 4
     windows = crop_all_windows(vol, slices, roi, pad_before) if len(slices) * per_win <= (8 << 30) else None  # one crop launch per call (<= 8 GB of windows), else per group
     main = torch.cuda.current_stream()
@@ -175,18 +193,17 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
         C = seg.shape[-1]
         if out is None:
             out = torch.zeros((B, *padded, C), dtype=torch.float32, device=inputs.device)
-            cnt = torch.zeros((B, *padded), dtype=torch.float32, device=inputs.device)
         per = roi[0] * roi[1] * roi[2]
         pvox = padded[0] * padded[1] * padded[2]
         for i, (b, s) in enumerate(grp):
-            L.check(lib.vsseg_swi_accumulate(seg.data_ptr() + 4 * i * per * C, imap.data_ptr(), L.i3(roi), L.i3(s), C, out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr() + 4 * b * pvox, L.i3(padded), stream), "swi_accumulate")
+            L.check(lib.vsseg_swi_accumulate(seg.data_ptr() + 4 * i * per * C, imap.data_ptr(), L.i3(roi), L.i3(s), C, out.data_ptr() + 4 * b * pvox * C, None, L.i3(padded), stream), "swi_accumulate")
         if lanes:
             blended[gi % len(lanes)] = main.record_event()
     C = out.shape[-1]
     final = torch.empty((B, *img, C), dtype=torch.float32, device=inputs.device)
     pvox, ivox = padded[0] * padded[1] * padded[2], img[0] * img[1] * img[2]
     for b in range(B):
-        L.check(lib.vsseg_swi_finalize(out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr() + 4 * b * pvox, L.i3(padded), L.i3(pad_before), L.i3(img), C, final.data_ptr() + 4 * b * ivox * C, stream), "swi_finalize")
+        L.check(lib.vsseg_swi_finalize(out.data_ptr() + 4 * b * pvox * C, cnt.data_ptr(), L.i3(padded), L.i3(pad_before), L.i3(img), C, final.data_ptr() + 4 * b * ivox * C, stream), "swi_finalize")
     return final.permute(0, 4, 1, 2, 3)
 
 
