@@ -4,6 +4,7 @@
 #include "sconv.h"
 #include "cconv.h"
 #include "mconv.h"
+#include "dconv.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
@@ -185,6 +186,7 @@ extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && (d->depth == -2 || d->depth == -4)) return vsseg_sconv_lds_bytes(d);
   if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
   if (d && (d->depth == -5 || d->depth == -6)) return vsseg_mconv_lds_bytes(d);
+  if (d && d->depth == -7) return vsseg_dconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
@@ -210,6 +212,12 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_mconv_launch(d, z, as_stream(stream));
+  }
+  if (d && d->depth == -7) {  // deep-level kernel (dconv.hip: the small launches of levels 3-5 and the stride-2 transitions around them): same contract
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_dconv_launch(d, z, as_stream(stream));
   }
   IgemmK k;
   int lds = igemm_prepare(d, k);

@@ -244,8 +244,12 @@ class Plan:
                 # ... and those of the 3x3x3 stride-(2,2,2) transitions of the deep levels as ONE launch of the general kernel (workgroup row = class)
                 kreal, nreal = P.gemm_dims(kind, Lr.wshape)
                 csp = P.class_split_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, aux_es=aux_es, in_split=in_split) if kind in ("convT_fwd", "conv_dgrad") else None
-                if csp:  # an alternative to the per-class launches below, decided per op at lowering time (Plan._use_class_split)
-                    alt = _Choice(csp if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))
+                # ... or of the deep-level kernel (csrc/dconv.hip: a workgroup loads the halo of its coarse tile once and runs the classes one after the other)
+                dcp = P.deep_class_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, self.n, in_split) if (eng.deep != "0" and kind in ("convT_fwd", "conv_dgrad")) else []
+                if eng.deep == "force" and dcp:
+                    alt = _Choice(dcp if self.tune else dcp[:1], woff, wshape=tuple(Lr.wshape))
+                elif csp or (dcp and self.tune):  # an alternative to the per-class launches below, decided per op at lowering time (Plan._use_class_split)
+                    alt = _Choice(((csp or []) + dcp) if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -253,8 +257,17 @@ class Plan:
                     continue
                 if self.tune:
                     cands = P.candidate_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split, n=self.n)
+                    if eng.deep == "0":
+                        cands = [pl for pl in cands if pl.depth != -7]
+                    elif eng.deep == "force" and any(pl.depth == -7 for pl in cands):
+                        cands = [pl for pl in cands if pl.depth == -7]
                 else:
                     cands = [P.plan_igemm(kind, Lr.wshape, cls, q, eng.es, kc_pad=kc_pad, aux_es=aux_es, in_split=in_split)]
+                    if eng.deep == "force":  # untuned lowering with the deep-level kernel wherever it is offered (tests: the whole network through csrc/dconv.hip's domain)
+                        kr_, nr_ = P.gemm_dims(kind, Lr.wshape)
+                        dp = P.deep_plans(kind, Lr.wshape, cls, q, eng.es, kc_pad if kc_pad is not None else P.round_up(kr_, 8), nr_, kr_, self.n, in_split)
+                        if dp:
+                            cands = dp[:1]
                 out.append(_Choice(cands, woff, absorbed.layer.wshape if absorbed is not None else None, eng.layout.param_off[absorbed.layer.wkey][0] if absorbed is not None else 0, wshape=tuple(Lr.wshape)))
             out[0].alt = alt
             return out
@@ -449,13 +462,14 @@ class Plan:
         p0 = alt.cands[0]
         nb = kw.get("nb") or self.n
         if not self.tune:
-            return nb * p0.q[0] * p0.q[1] * p0.q[2] <= self.CLASS_SPLIT_MAX_VOXELS
+            return p0.depth == -7 or nb * p0.q[0] * p0.q[1] * p0.q[2] <= self.CLASS_SPLIT_MAX_VOXELS
         if alt.chosen is not None or chs[0].chosen is not None:  # a further launch of the same op (another sample): same decision
             return alt.chosen is not None
         key = (f"use_cs|{p0.kind}|w{alt.wshape}|q{p0.q}|n{nb}|es{self.eng.es}|kc{p0.kc}|acc{int(kw.get('accumulate', 0))}|res{int(kw.get('res_mode', 0))}"
                f"|st{int(bool(kw.get('stats')))}|two{int(bool(inp.ptr2))}{int(bool(out.ptr2))}" + ("|gate" if kw.get("gate") else ""))
         cache = _tune_cache()
-        if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
+        retune = {int(v) for v in os.environ.get("VSSEG_RETUNE_DEPTHS", "").split(",") if v.strip()}
+        if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force" and not any(pl.depth in retune for ch in (list(chs) + [alt]) for pl in ch.cands):
             return bool(cache[key])
         eng, lib = self.eng, self.eng.lib
         stream = torch.cuda.current_stream().cuda_stream
@@ -591,6 +605,8 @@ class Plan:
             return f"cconv<bf16,{pl.nt}>"
         if P.is_march(pl):
             return f"mconv<bf16,{pl.nt}>"
+        if pl.depth == -7:
+            return f"dconv<bf16,{pl.mtw},{pl.nt}>"
         return f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"
 
     def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:
@@ -1372,6 +1388,9 @@ class Engine:
         # the block in the second convolutions' loaders +0.15 / +0.07, in their backward +0.08 / +0.06: all VALU / latency bound), the wall clock of the step is unchanged
         # (28.79 against 28.87 ms, four alternating pairs on one box) — DESIGN.md §3.9.
         self.bn_onload = os.environ.get("VSSEG_BN_ONLOAD", "0") == "1" and not dry_run
+        # the deep-level kernel (csrc/dconv.hip, plans with depth -7) on the small launches of levels 3-5: "1" = a candidate the tuner measures, "0" = off, "force" = every launch
+        # it is offered for runs on it (the untuned lowering then too: how the tests send a whole network through it)
+        self.deep = os.environ.get("VSSEG_DEEP", "1")
         self.march_shuffle = os.environ.get("VSSEG_MARCH_SHUFFLE", "1") != "0"  # marching variants of the fused-parity-classes launch of the level-1 -> level-0 transposed convolution as tuner candidates
         self.gate_onload_units = os.environ.get("VSSEG_GATE_ONLOAD_UNITS", "1") != "0"  # ... also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
         self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient

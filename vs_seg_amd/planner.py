@@ -531,6 +531,101 @@ def compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split=0) -> Opti
     return IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, COMPUTE_TILE, 8, nt, nsplit, 16, kc // 16, 14, compute_lds_bytes(nt), -3)
 
 
+# ---- deep-level kernel (csrc/dconv.hip): depth -7 -------------------------------------------------------------------------
+DEEP_MAX_VOXELS = 1 << 18  # lattice voxels x batch up to which the deep-level kernel is offered (level 3 at batch 4: 196 608)
+DEEP_WAVES = 4
+
+
+def deep_red_tiles(mt, nt):
+    return mt * nt if mt * nt <= 24 else (mt * nt + 1) // 2
+
+
+def deep_lds_bytes(tile, is_, taps, ck, ksteps, mt, nt, classes: bool) -> int:
+    """Mirror of dc_check() in csrc/dconv.hip: K-group table | epilogue constants | statistics rows | halo (voxel stride padded to an odd number of 16-byte
+    units) | the four waves' accumulator slabs (their own space when every parity class re-reads the halo, else the halo's)."""
+    halo = 1
+    for a in range(3):
+        offs = [t[0][a] for t in taps]
+        halo *= (tile[a] - 1) * is_[a] + (max(offs) - min(offs) + 1)
+    vs = ((ck // 8) | 1) * 16
+    hb, rb = round_up(halo * vs, 1024), DEEP_WAVES * deep_red_tiles(mt, nt) * 1024  # (whole 1 KiB DMA rows)
+    off = round_up(ksteps * 16, 16) + 3 * nt * 64 + DEEP_WAVES * 2 * nt * 64
+    return off + (hb + rb if classes else max(hb, rb))
+
+
+def _deep_ok(tile, mt, nt):
+    return all(t & (t - 1) == 0 and t <= 128 for t in tile) and tile[0] * tile[1] * tile[2] == 16 * mt and mt * nt <= 40
+
+
+def deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1, in_split=0, limit=6) -> List["IgemmPlan"]:
+    """The depth -7 candidates: the deep-level kernel (csrc/dconv.hip) on the small bf16 launches — workgroups of 16 * mt lattice voxels x nt channel tiles whose
+    four waves split the K-steps, weight fragments straight from L2.  Any lattice class (stride-1, strided, one parity class of a transposed convolution)."""
+    nvox = n * q[0] * q[1] * q[2]
+    if es != 2 or nvox > DEEP_MAX_VOXELS or kc % 8 or (in_split and in_split % 8):
+        return []
+    nt_total = (nreal + 15) // 16
+    cks = sorted({c for c in range(8, kc + 1, 8) if kc % c == 0}, reverse=True)
+    out = []
+    for mt in (8, 4, 2):
+        if nvox < 16 * mt:
+            continue
+        tile = choose_tile(q, cls.taps, 16 * mt)
+        tiles = n * int(np.prod([-(-q[a] // tile[a]) for a in range(3)]))
+        got = 0
+        for nsplit in range(1, nt_total + 1):
+            nt = -(-nt_total // nsplit)
+            if nt > 6 or not _deep_ok(tile, mt, nt) or (nsplit > 1 and -(-nt_total // (nsplit - 1)) == nt):
+                continue
+            for ck in cks:
+                ksteps = (len(cls.taps) * (ck // 8) + 3) // 4
+                lds = deep_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, mt, nt, False)
+                if lds > LDS_LIMIT:
+                    continue
+                pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tuple(tile), mt, nt, nsplit, ck, kc // ck, ksteps, lds, -7)
+                pl.pack_map = pack_map(pl, wshape)
+                out.append((tiles * nsplit, pl))
+                got += 1
+                break  # the largest chunk that fits: fewest passes over the K loop
+            if got >= 2:
+                break
+    # prefer launches that fill the GPU once (256 CUs), then the larger tiles
+    out.sort(key=lambda r: (abs(np.log2(max(r[0], 1) / 256.0)) > 1.5, -r[1].mtw, r[1].nsplit))
+    return [pl for _, pl in out[:limit]]
+
+
+def deep_class_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, n=1, in_split=0) -> List["IgemmPlan"]:
+    """All output-parity classes of a transposed convolution / strided data gradient in ONE launch of the deep-level kernel: a workgroup loads the halo of its
+    coarse tile once and runs the classes one after the other (each with its own taps, packed weights [class][1][ksteps][nt][64][8] as class_split_plans)."""
+    nvox = n * q[0] * q[1] * q[2]
+    if kind not in ("convT_fwd", "conv_dgrad") or es != 2 or nvox > DEEP_MAX_VOXELS or kc % 8 or (in_split and in_split % 8):
+        return []
+    classes = lattice_classes(kind, kernel, stride)
+    nt = (nreal + 15) // 16
+    if not 2 <= len(classes) <= 8 or nt > 6:
+        return []
+    offs = sorted({off for c in classes for off, _ in c.taps})
+    if len(offs) > VSSEG_MAX_TAPS or max(len(c.taps) for c in classes) > 8:
+        return []
+    union = LatticeClass(classes[0].os, (0, 0, 0), classes[0].is_, [(off, (0, 0, 0)) for off in offs])
+    ksteps = (max(len(c.taps) for c in classes) * (kc // 8) + 3) // 4
+    out = []
+    for mt in (8, 4, 2):
+        if nvox < 16 * mt or not _deep_ok(choose_tile(q, union.taps, 16 * mt), mt, nt):
+            continue
+        tile = choose_tile(q, union.taps, 16 * mt)
+        lds = deep_lds_bytes(tile, union.is_, union.taps, kc, ksteps, mt, nt, True)
+        if lds > LDS_LIMIT:
+            continue
+        pl = IgemmPlan(kind, union, tuple(q), kc, nreal, kreal, tuple(tile), mt, nt, len(classes), kc, 1, ksteps, lds, -7)
+        pl.classes = classes
+        pl.pack_map = pack_map(pl, wshape)
+        out.append(pl)
+    return out
+
+
+VSSEG_MAX_TAPS = 27
+
+
 def _pow2_floor(v):
     p = 1
     while p * 2 <= v:
@@ -669,6 +764,7 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
         rest = rest + [cp]
     if not in_split_unsupported(in_split, kc):
         rest = rest + march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n)
+    rest = rest + deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n, in_split)
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
