@@ -501,7 +501,7 @@ def test_every_candidate_plan_gives_the_same_convolution(kind, k, cin, cout, dim
         inp_cl, want, nout, bias = H.to_cl(gy, H.DT[dt]), xd.grad, cin, None
     cls = P.lattice_classes(kind, k, (1, 1, 1))[0]
     cands = P.candidate_plans(kind, tuple(w.shape), cls, dims, inp_cl.element_size(), kc_pad=inp_cl.shape[-1], aux_es=inp_cl.element_size(), in_split=split)
-    assert len(cands) >= 2 and (dt == "fp32" or (len(cands) >= 4 and (any(c.depth == -1 for c in cands) or all(c.nt >= 3 for c in cands)) and len({(c.ck, c.mtw, c.nsplit) for c in cands}) >= 3))  # nt >= 3: producer / consumer kernels always prefetch
+    assert len(cands) >= 2 and (dt == "fp32" or (len(cands) >= 4 and (any(c.depth == -1 for c in cands) or all(c.nt >= 3 for c in cands if c.depth >= -1)) and len({(c.ck, c.mtw, c.nsplit) for c in cands}) >= 3))  # nt >= 3: producer / consumer kernels always prefetch
     parts = H._split_cl(inp_cl, split) if split else None
     for mode in ("plain", "stats", "accumulate"):
         for pl in cands:
@@ -1374,6 +1374,159 @@ def test_class_split_launch_equals_per_class_launches(kind, cin, cout, fine, mod
     bad = H.igemm_desc(pls[0], H.pack(pls[0], w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out_a))
     bad.nsplit = 4
     assert lib.vsseg_igemm(C.byref(bad), H.stream()) == L.EINVAL and b"class_split" in lib.vsseg_last_error()
+
+
+DEEP_CASES = [
+    # kind, kernel, stride, cin, cout, spatial size of the FINER side, mode, input split
+    ("conv_fwd", (3, 3, 3), (1, 1, 1), 160, 80, (6, 8, 8), "stats", 80),       # level-4 decoder unit on the two-part concat
+    ("conv_fwd", (3, 3, 3), (1, 1, 1), 96, 96, (12, 4, 16), "stats", 0),       # bottleneck
+    ("conv_fwd", (3, 3, 3), (1, 1, 1), 80, 40, (5, 3, 7), "relu", 0),          # attention conv1 of the bottleneck, ragged lattice (partial tiles)
+    ("conv_fwd", (3, 3, 3), (1, 1, 1), 40, 1, (6, 4, 8), "sigmoid", 0),        # attention conv2: one fp32 output channel
+    ("conv_fwd", (1, 1, 1), (1, 1, 1), 80, 96, (6, 4, 8), "plain", 0),         # residual convolution: one K-step group per wave at most
+    ("conv_fwd", (3, 3, 3), (2, 2, 2), 64, 64, (12, 8, 16), "stats", 0),       # strided convolution level 3 -> 4
+    ("conv_fwd", (3, 3, 3), (1, 1, 1), 64, 80, (6, 8, 8), "residual", 0),
+    ("conv_dgrad", (3, 3, 3), (1, 1, 1), 160, 80, (6, 8, 8), "accumulate", 0),  # K = 80 -> N = 160 = 2 x 5 tiles
+    ("conv_dgrad", (1, 1, 1), (1, 1, 1), 128, 64, (6, 8, 8), "accumulate", 0),  # N = 128 over 3 x 3 tiles: the last channel tile is padding (no auxiliary read past the row)
+    ("conv_dgrad", (3, 3, 3), (1, 1, 1), 80, 40, (6, 4, 8), "relumask", 0),
+    ("conv_dgrad", (3, 3, 3), (1, 1, 1), 96, 96, (12, 4, 16), "gate", 0),
+    ("convT_dgrad", (3, 3, 3), (2, 2, 2), 80, 64, (12, 8, 16), "plain", 0),
+    ("convT_fwd", (3, 3, 3), (2, 2, 2), 96, 80, (8, 8, 8), "stats", 0),         # the parity classes: per class AND all in one launch
+    ("convT_fwd", (3, 3, 3), (2, 2, 2), 80, 64, (12, 8, 16), "plain", 0),
+    ("conv_dgrad", (3, 3, 3), (2, 2, 2), 64, 64, (12, 8, 16), "accumulate", 0),
+    ("conv_dgrad", (3, 3, 3), (2, 2, 2), 80, 80, (7, 9, 6), "plain", 0),        # odd fine lattice: the classes with offset 1 are one voxel shorter
+]
+
+
+@pytest.mark.parametrize("kind,k,st,cin,cout,fine,mode,split", DEEP_CASES)
+def test_deep_kernel_matches_definition_and_general_kernel(kind, k, st, cin, cout, fine, mode, split):
+    """csrc/dconv.hip (launch plans with depth -7: the small launches of levels 3-5, ref:params/networks/nets/unet2d5_spvPA.py:56-89): every plan `planner.deep_plans` /
+    `deep_class_plans` offers computes the convolution of torch's fp64 definition with each epilogue the network uses (bias, BatchNorm statistics, activations, residual /
+    accumulate / ReLU mask / gated add, fp32 one-channel output, two-part input), on ragged lattices, with all parity classes in one launch — within the bf16 output
+    rounding, and within fp32 rounding of the general kernel (the four waves split the K sum: not bit-identical by construction); twice in a row gives identical bits."""
+    lib = L.lib()
+    dt, tdt, n = "bf16", torch.bfloat16, 2
+    torch.manual_seed(29)
+    transposed = kind.startswith("convT")
+    strided = tuple(st) != (1, 1, 1)
+    coarse = tuple((f + s - 1) // s for f, s in zip(fine, st))
+    if transposed:
+        w = _round(torch.randn(cin, cout, *k) / (cin * 27 / 8) ** 0.5, dt)
+    else:
+        w = _round(torch.randn(cout, cin, *k) / (cin * np.prod(k) / (8 if (strided and kind == "conv_dgrad") else 1)) ** 0.5, dt)
+    pad = P.same_pad(k)
+    if kind == "conv_fwd":
+        x = _round(torch.randn(n, cin, *fine), dt)
+        want = F.conv3d(x.double(), w.double(), stride=st, padding=pad)
+        inp, nout, q, odims = x, cout, tuple(want.shape[2:]), tuple(want.shape[2:])
+    elif kind == "convT_fwd":
+        x = _round(torch.randn(n, cin, *coarse), dt)
+        want = F.conv_transpose3d(x.double(), w.double(), stride=st, padding=1, output_padding=1)
+        inp, nout, q, odims = x, cout, coarse, tuple(want.shape[2:])
+    elif kind == "conv_dgrad":
+        xd = torch.zeros(n, cin, *fine, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xd, w.double(), stride=st, padding=pad)
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        want, inp, nout, q, odims = xd.grad, gy, cin, coarse if strided else fine, fine
+    else:  # convT_dgrad: dX of a transposed convolution = the strided convolution of dY
+        xd = torch.zeros(n, cin, *coarse, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose3d(xd, w.double(), stride=st, padding=1, output_padding=1)
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        want, inp, nout, q, odims = xd.grad, gy, cin, coarse, coarse
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    assert nreal == nout
+    inp_cl = H.to_cl(inp, tdt, P.round_up(kreal, 8))
+    parts = H._split_cl(inp_cl, split) if split else None
+    xin = H.two_part(*parts) if parts else H.tdesc(inp_cl)
+    f32out = mode == "sigmoid"
+    bias = torch.randn(nout) * 0.2
+    prev = H.to_cl(_round(torch.randn(n, nout, *odims), dt), tdt)
+    side = H.to_cl(_round(torch.randn(n, nout, *odims), dt), tdt)
+    gate = torch.rand(n, *odims, device="cuda")
+    kw, ref = dict(bias=bias.cuda().data_ptr()), want + bias.double().view(1, -1, 1, 1, 1)
+    keep = [bias]
+    if mode == "accumulate":
+        kw, ref = dict(accumulate=1), want + H.from_cl(prev).double()
+    elif mode == "residual":
+        kw.update(res=H.tdesc(side), res_mode=L.RES_ADD)
+        ref = ref + H.from_cl(side).double()
+    elif mode == "relumask":
+        kw, ref = dict(res=H.tdesc(side), res_mode=L.RES_RELUMASK), want * (H.from_cl(side) > 0).double()
+    elif mode == "gate":
+        kw, ref = dict(res=H.tdesc(side), res_mode=L.RES_GATE, gate=gate.data_ptr()), want + H.from_cl(side).double() * (1.0 + gate.cpu().double()).unsqueeze(1)
+    elif mode == "relu":
+        kw["act"], ref = L.ACT_RELU, ref.clamp(min=0)
+    elif mode == "sigmoid":
+        kw["act"], ref = L.ACT_SIGMOID, torch.sigmoid(ref)
+    bdev = bias.cuda()
+    if "bias" in kw:
+        kw["bias"] = bdev.data_ptr()
+    aux_es = 2 if mode in ("accumulate", "residual", "relumask", "gate") else 0
+
+    def fresh():
+        if mode == "accumulate":
+            return prev.clone()
+        return torch.zeros(n, *odims, nout, dtype=torch.float32 if f32out else tdt, device="cuda")
+
+    def stats_buf():
+        return torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+
+    def launch(plans):
+        out, sb = fresh(), stats_buf()
+        e = dict(kw, stats=sb.data_ptr(), stats_stride=P.round_up(nout, 16)) if mode == "stats" else kw
+        for pl in plans:
+            d = H.igemm_desc(pl, H.pack(pl, w, tdt), xin, H.tdesc(out), **e)
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"deep kernel {kind} tile={pl.tile} mt={pl.mtw} nt={pl.nt} ns={pl.nsplit} ck={pl.ck}")
+        torch.cuda.synchronize()
+        return out, H.stat_decode(sb).view(L.STAT_SHARDS, 2, -1).sum(0)
+
+    classes = P.lattice_classes(kind, k, st)
+    general, gstat = launch([P.plan_igemm(kind, tuple(w.shape), c_, q, 2, kc_pad=inp_cl.shape[-1], aux_es=aux_es, in_split=split) for c_ in classes])
+    tol = (1e-4 if f32out else 1.2e-2) * (float(ref.abs().max()) + 1e-12)
+    np.testing.assert_allclose(H.from_cl(general).numpy(), ref.float().numpy(), atol=tol)
+    variants = []
+    per_class = [P.deep_plans(kind, tuple(w.shape), c_, q, 2, inp_cl.shape[-1], nreal, kreal, n, split) for c_ in classes]
+    assert all(per_class), "the deep-level kernel is offered for every lattice class of these shapes"
+    for i in range(max(len(pc) for pc in per_class)):
+        variants.append([pc[min(i, len(pc) - 1)] for pc in per_class])
+    if len(classes) > 1:
+        cps = P.deep_class_plans(kind, tuple(w.shape), k, st, q, 2, inp_cl.shape[-1], nreal, kreal, n)
+        assert cps and all(pl.classes is not None and pl.depth == -7 for pl in cps)
+        variants += [[pl] for pl in cps]
+    assert all(pl.depth == -7 for v in variants for pl in v)
+    for v in variants:
+        tag = " | ".join(f"tile={pl.tile} mt={pl.mtw} nt={pl.nt} ns={pl.nsplit} ck={pl.ck} cls={len(pl.classes or [])}" for pl in v[:1])
+        out, st_ = launch(v)
+        np.testing.assert_allclose(H.from_cl(out).numpy(), ref.float().numpy(), atol=tol, err_msg=tag)
+        assert float((out.float() - general.float()).abs().max()) <= 2 * tol, tag
+        if mode == "stats":
+            np.testing.assert_allclose(st_.cpu().numpy(), gstat.cpu().numpy(), rtol=2e-4, atol=2e-2, err_msg=tag)
+            np.testing.assert_allclose(st_[0, :nout].cpu().numpy(), (want + bias.double().view(1, -1, 1, 1, 1)).sum((0, 2, 3, 4)).numpy(), rtol=2e-4, atol=5e-2, err_msg=tag)
+        again, st2 = launch(v)
+        assert torch.equal(again, out) and torch.equal(st2, st_), f"not run-to-run bit-identical: {tag}"
+
+
+def test_deep_kernel_rejects_what_it_does_not_cover():
+    """depth -7 outside the deep-level kernel's domain is an error with the reason in vsseg_last_error (no silent fallback)."""
+    lib = L.lib()
+    k = (3, 3, 3)
+    w = torch.randn(48, 32, *k)
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    pl = P.deep_plans("conv_fwd", tuple(w.shape), cls, (8, 8, 8), 2, 32, 48, 32, 1)[0]
+    x = torch.zeros(1, 8, 8, 8, 32, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 8, 8, 8, 48, dtype=torch.bfloat16, device="cuda")
+    wp = H.pack(pl, w, torch.bfloat16)
+    d = H.igemm_desc(pl, wp, H.tdesc(x), H.tdesc(out))
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) == 0
+    for field, val, why in (("mtw", 3, b"mtw"), ("cout_mod", 16, b"z-folded"), ("ck", 24, b"nchunks x ck")):
+        bad = H.igemm_desc(pl, wp, H.tdesc(x), H.tdesc(out))
+        setattr(bad, field, val)
+        assert lib.vsseg_igemm(C.byref(bad), H.stream()) == L.EINVAL and why in lib.vsseg_last_error(), field
+    xf = torch.zeros(1, 8, 8, 8, 32, device="cuda")
+    bad = H.igemm_desc(pl, wp, H.tdesc(xf), H.tdesc(out))
+    assert lib.vsseg_igemm(C.byref(bad), H.stream()) == L.EINVAL and b"bf16" in lib.vsseg_last_error()
+    torch.cuda.synchronize()
 
 
 def test_compute_kernel_rejects_what_it_does_not_cover():

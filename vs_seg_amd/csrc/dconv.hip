@@ -26,8 +26,10 @@ constexpr int dc_red_tiles(int mt, int nt) { return mt * nt <= 24 ? mt * nt : (m
 // K-steps of weight fragments in flight per wave.  A fragment comes from L2 (~0.7-1 us under load) and a K-step is MT*NT MFMAs of 16 cycles (80 ns at 4 x 3 tiles): with a
 // ring of 3 the level-5 launches waited ~0.5 us per K-step (first version: 13 us per launch, 10 of them in this wait).  One wave per SIMD: 512 registers per lane.
 constexpr int dc_ring(int mt, int nt) {
-  const int r = (400 - mt * nt * 4 - mt * 8 - 60) / (nt * 4);
-  return r < 3 ? 3 : (r > 12 ? 12 : r);
+  // fragments and operands must sit in the 256 architectural VGPRs (the accumulators go to the AGPRs): ring + two operand sets + ~70 for addressing
+  int r = (230 - 70 - mt * 8 - (mt * nt >= 32 ? 32 : 0)) / (nt * 4);
+  if (r * nt > 60) r = 60 / nt;  // vmcnt counts at most 63 outstanding operations
+  return r < 3 ? 3 : (r > 16 ? 16 : r);
 }
 
 struct DconvK {
@@ -39,6 +41,7 @@ struct DconvK {
   const float *bias, *bias2, *scale, *shift, *alpha;
   double* stats;
   unsigned* fxflag;
+  unsigned long long* prof;  // tuning build (-DVSSEG_DC_PROF): cycle counters of workgroup 0 / wave 0 per phase
   const void* zeros;
   int in_csplit, in_vox_bytes;
   int out_csplit, out_vox_bytes, out_f32, cout;
@@ -65,7 +68,8 @@ __device__ __forceinline__ unsigned dc_div(unsigned n, unsigned magic) { return 
 template <int MT, int NT>
 __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
   constexpr int TILES = MT * NT, RT = dc_red_tiles(MT, NT), ROUNDS = (TILES + RT - 1) / RT, RING = dc_ring(MT, NT);
-  static_assert(ROUNDS <= 2, "slab rounds");
+  constexpr int MR = RT / NT;  // M-tiles per slab round
+  static_assert(ROUNDS <= 2 && RT % NT == 0, "slab rounds hold whole M-tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* ktab = reinterpret_cast<int*>(smem);                        // [class][K-steps x 4 K-groups] -> LDS byte offset of the group's 16 bytes relative to the voxel
   float* epi = reinterpret_cast<float*>(smem + k.lds_epi);         // bias | scale | shift, NT*16 each
@@ -79,6 +83,28 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
   const bool classes = k.nclass > 0;
   const int row0 = classes ? 0 : (int)blockIdx.y;
   const int c_base = row0 * NT * 16;
+#ifdef VSSEG_DC_PROF
+  unsigned long long pt[6];
+  pt[0] = __builtin_readcyclecounter();
+#define DC_MARK(i) pt[i] = __builtin_readcyclecounter()
+#else
+#define DC_MARK(i)
+#endif
+  // Small tables, one element per lane (read with shuffles: no dependent memory round trip per K-group when the K-group table is built):
+  // tap -> halo-voxel offset, (class, tap) -> tap of the union table, class -> tap count.  Issued first: they are back long before they are used.
+  const int tapofs_l = kp->tapofs[lane < VSSEG_MAX_TAPS ? lane : 0];
+  const int ctap_l = kp->class_tap[lane >> 3][lane & 7];
+  const int cnt_l = kp->class_ntaps[lane & 7];
+  // per-channel epilogue constants of this workgroup's channel tiles (class mode: all channels): loads issued here, stored to LDS behind the halo DMAs
+  const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
+  float e_bias = 0.f, e_scale = 1.f, e_shift = 0.f;
+  if (tid < NT * 16) {
+    const int c = c_base + tid;
+    const bool ok = c < k.cout;
+    e_bias = ((ok && k.bias) ? k.bias[c] : 0.f) + ((ok && k.bias2) ? k.bias2[c] : 0.f);
+    e_scale = (ok && k.scale) ? k.scale[c] : 1.f;
+    e_shift = (ok && k.scale) ? k.shift[c] : 0.f;
+  }
 
   // ---- this workgroup's tile of the output lattice (neighbouring tiles -> the same XCD: they share halo lines in its L2) ----
   int q0[3], smp;
@@ -88,58 +114,14 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
     t = dc_div(b, k.mg_t1); q0[1] = (int)(b - t * k.ntile[1]) << k.tl[1]; b = t;
     t = dc_div(b, k.mg_t0); q0[0] = (int)(b - t * k.ntile[0]) << k.tl[0]; smp = (int)t;
   }
-  // per-channel epilogue constants of this workgroup's channel tiles (class mode: all channels)
-  const float alpha = (k.act == VSSEG_ACT_PRELU && k.alpha) ? *k.alpha : 0.f;
-  for (int i = tid; i < NT * 16; i += DC_THREADS) {
-    const int c = c_base + i;
-    const bool ok = c < k.cout;
-    epi[i] = ((ok && k.bias) ? k.bias[c] : 0.f) + ((ok && k.bias2) ? k.bias2[c] : 0.f);
-    epi[NT * 16 + i] = (ok && k.scale) ? k.scale[c] : 1.f;
-    epi[2 * NT * 16 + i] = (ok && k.scale) ? k.shift[c] : 0.f;
-  }
-  // K-group tables: K-group p = ks*4 + g of a class -> (tap p / cgs, channel group p % cgs) -> byte offset inside the halo relative to the voxel
-  {
-    const int per = k.ksteps * 4, ncl = classes ? k.nclass : 1;
-    for (int e = tid; e < per * ncl; e += DC_THREADS) {
-      const int cl = e / per, p = e - cl * per;
-      const int ntaps_c = classes ? kp->class_ntaps[cl] : k.ntaps;
-      const unsigned tap = dc_div((unsigned)p, k.mg_cgs);
-      const int cg = p - (int)tap * k.cgs;
-      int off = 0;  // padded K-groups: zero weights times the voxel's own (finite) data
-      if ((int)tap < ntaps_c) off = kp->tapofs[classes ? kp->class_tap[cl][tap] : (int)tap] * k.vs + cg * 16;
-      ktab[e] = off;
-    }
-  }
-  // ---- this lane's voxel of every M-tile: v = m*16 + l15 -> (vx, vy, vz) inside the tile ----
-  int abase[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int v = m * 16 + l15;
-    const int vz = v & ((1 << k.tl[2]) - 1), vy = (v >> k.tl[2]) & ((1 << k.tl[1]) - 1), vx = v >> (k.tl[2] + k.tl[1]);
-    abase[m] = ((vx * k.is[0] * k.halo[1] + vy * k.is[1]) * k.halo[2] + vz * k.is[2]) * k.vs;
-  }
-  float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
-
   const int g0x = q0[0] * k.is[0] + k.omin[0], g0y = q0[1] * k.is[1] + k.omin[1], g0z = q0[2] * k.is[2] + k.omin[2];
   const int hvox = k.halo[0] * k.halo[1] * k.halo[2];
   const int64_t in_base = (int64_t)smp * k.X * k.Y * k.Z;
 
-  f32x4 acc[MT][NT];
-  auto zero_acc = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-
   // ---- halo of one channel chunk: HBM / L2 -> LDS by LDS-DMA (16 bytes per lane, 1 KiB per instruction, every instruction of the chunk in flight at once; no registers).
   //      LDS slot s = voxel * cgp + piece, cgp = cgs | 1: the DMA writes LDS in lane order, so the padding slot of a voxel (and everything outside the tensor: the
-  //      convolution's zero padding) is simply fetched from the zero page ----
-  auto load_halo = [&](int ch) __attribute__((always_inline)) {
+  //      convolution's zero padding) is simply fetched from the zero page.  ISSUE only: the caller waits (counted) after it has issued more work ----
+  auto issue_halo = [&](int ch) __attribute__((always_inline)) {
     const int c0 = ch * k.ck, cgp = k.cgs | 1, slots = hvox * cgp, rows = (slots + 63) >> 6;
     for (int row = wave; row < rows; row += DC_WAVES) {
       const unsigned sl = (unsigned)(row * 64 + lane);
@@ -153,54 +135,153 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
       const char* src = (c >= k.in_csplit ? k.in1 : k.in0) + (in_base + ((int64_t)gx * k.Y + gy) * k.Z + gz) * k.in_vox_bytes + c * 2;
       vsseg_dma16(ok ? (const void*)src : k.zeros, halo + row * 1024);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed; the barrier that follows publishes them
   };
 
-  // ---- K loop over `cnt` K-steps of this wave: weight fragments straight from L2 (RING steps in flight, `wstep` bytes apart), operand fragments from the halo;
-  //      the operand fragments of step i+1 and the K-group offset of step i+2 are read while step i multiplies ----
-  auto k_loop = [&](const char* wsrc, int64_t wstep, const int* kt, int ktstep, int cnt) __attribute__((always_inline)) {
-    bf16x8 wb[RING][NT];
+  // ---- K loop over `cnt` K-steps of this wave: weight fragments straight from L2 (RING steps in flight, `wstep` bytes apart), operand fragments from the halo.
+  //      k_preload issues the first RING steps' fragments (always RING * NT loads, from clamped steps) — BEFORE the halo has landed, so that both latencies overlap;
+  //      k_run multiplies; the operand fragments of step i+1 and the K-group offset of step i+2 are read while step i multiplies ----
+  f32x4 acc[MT][NT];
+  bf16x8 wb[RING][NT];
+  auto k_preload = [&](const char* wsrc, int64_t wstep, int cnt) __attribute__((always_inline)) {
+    if (cnt <= 0) wsrc = k.wpack + lane * 16;  // a wave without K-steps (fewer than 4 in the pass) still issues its RING * NT loads (wait_halo counts them): from the first fragments
+    const int last = cnt > 0 ? cnt - 1 : 0;
 #pragma unroll
-    for (int dd = 0; dd < RING; ++dd)
-      if (dd < cnt) {
+    for (int dd = 0; dd < RING; ++dd) {
+      const int sc = dd < last ? dd : last;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wb[dd][t] = *reinterpret_cast<const bf16x8*>(wsrc + dd * wstep + t * 1024);
-      }
+      for (int t = 0; t < NT; ++t) wb[dd][t] = *reinterpret_cast<const bf16x8*>(wsrc + sc * wstep + t * 1024);
+    }
+  };
+  int abase[MT];
+  auto k_run = [&](const char* wsrc, int64_t wstep, const int* kt, int ktstep, int cnt) __attribute__((always_inline)) {
     if (cnt <= 0) return;
-    bf16x8 a[MT], an[MT];
-    {
+    // The steady-state loop has NO branch inside: every load is unconditional from a clamped K-step (the last groups re-fetch the final fragment, harmlessly).  With
+    // `if (i + RING < cnt)` around the refills hipcc's wait-count pass lost the order of the pending loads at the control-flow merges and put vmcnt(4..0) in front of
+    // every K-step — i.e. it waited for the refill it had just issued.
+    // APF: the operand fragments of step i+1 are read while step i multiplies (a second register set); with 8 M-tiles a step is >= 8 * NT MFMAs and hipcc interleaves the
+    // step's own reads with them — the second set would only cost 32 registers there.
+    constexpr bool APF = MT <= 4;
+    const int last = cnt - 1;
+    bf16x8 a[MT], an[APF ? MT : 1];
+    int koff1;
+    if constexpr (APF) {
       const int koff0 = kt[0];
 #pragma unroll
       for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff0);
+      koff1 = kt[(1 < last ? 1 : last) * ktstep];
+    } else {
+      koff1 = kt[0];
     }
-    int koff1 = cnt > 1 ? kt[ktstep] : 0;
-    for (int i0 = 0; i0 < cnt; i0 += RING) {
+    int i = 0;
+    for (; i + RING <= cnt; i += RING) {
 #pragma unroll
       for (int dd = 0; dd < RING; ++dd) {
-        const int i = i0 + dd;
-        if (i < cnt) {
-          const int koff2 = i + 2 < cnt ? kt[(i + 2) * ktstep] : 0;
-          if (i + 1 < cnt) {
+        const int ii = i + dd;
+        const int nx = APF ? ii + 2 : ii + 1;
+        const int koff2 = kt[(nx < last ? nx : last) * ktstep];
+        if constexpr (APF) {
 #pragma unroll
-            for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff1);
-          }
+          for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff1);
+        } else {
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff1);
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dd][t], a[m], acc[m][t], 0, 0, 0);
-          if (i + RING < cnt) {
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) wb[dd][t] = *reinterpret_cast<const bf16x8*>(wsrc + (int64_t)(i + RING) * wstep + t * 1024);
-          }
+          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dd][t], a[m], acc[m][t], 0, 0, 0);
+        const int rs = ii + RING < last ? ii + RING : last;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) wb[dd][t] = *reinterpret_cast<const bf16x8*>(wsrc + (int64_t)rs * wstep + t * 1024);
+        if constexpr (APF) {
 #pragma unroll
           for (int m = 0; m < MT; ++m) a[m] = an[m];
-          koff1 = koff2;
         }
+        koff1 = koff2;
+      }
+    }
+    const int rem = cnt - i;  // < RING: the fragments of these K-steps are already in the ring
+#pragma unroll
+    for (int dd = 0; dd < RING - 1; ++dd) {
+      if (dd < rem) {
+        const int ii = i + dd;
+        const int nx = APF ? ii + 2 : ii + 1;
+        const int koff2 = kt[(nx < last ? nx : last) * ktstep];
+        if constexpr (APF) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff1);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff1);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[dd][t], a[m], acc[m][t], 0, 0, 0);
+        if constexpr (APF) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) a[m] = an[m];
+        }
+        koff1 = koff2;
       }
     }
   };
+  // the DMAs of issue_halo are older than the RING * NT fragment loads of k_preload (VMEM operations of a wave retire in issue order): this wave's halo pieces have
+  // landed once at most that many operations are outstanding.  (hipcc does not count the inline-assembly DMAs: its own waits can only come out longer)
+  auto wait_halo = [&]() __attribute__((always_inline)) {
+    constexpr int N = RING * NT;
+    static_assert(N <= 63, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  };
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
 
-  // ---- epilogue of one accumulator tile (M-tile m, channel tile T) whose `parts` partial sums sit in the slabs at position j of waves w0, w0+1, ... ----
+  // ================= prologue: everything that touches memory is issued first =================
+  const int nks0 = (k.ntaps * k.cgs + 3) >> 2;
+  const int cnt0 = nks0 > wave ? (nks0 - 1 - wave) / DC_WAVES + 1 : 0;   // one class: K-steps wave, wave + 4, ...
+  const int cl_first = classes ? kp->wave_cls[wave][0] : 0;
+  const int ncls_w = classes ? kp->wave_ncls[wave] : 0;
+  DC_MARK(1);
+  issue_halo(0);
+  if (!classes) k_preload(k.wpack + ((int64_t)(row0 * k.nchunks) * k.ksteps + wave) * (NT * 1024) + lane * 16, (int64_t)DC_WAVES * NT * 1024, cnt0);
+  else k_preload(k.wpack + (int64_t)cl_first * k.ksteps * (NT * 1024) + lane * 16, (int64_t)NT * 1024, (__shfl(cnt_l, cl_first) * k.cgs + 3) >> 2);
+  if (tid < NT * 16) { epi[tid] = e_bias; epi[NT * 16 + tid] = e_scale; epi[2 * NT * 16 + tid] = e_shift; }
+  // K-group tables: K-group p = ks*4 + g of a class -> (tap p / cgs, channel group p % cgs) -> byte offset inside the halo relative to the voxel
+  {
+    const int per = k.ksteps * 4, ncl = classes ? k.nclass : 1;
+    for (int e0 = 0; e0 < per * ncl; e0 += DC_THREADS) {  // (uniform trip count: the shuffles below need every lane)
+      const int e = e0 + tid;
+      const int ec = e < per * ncl ? e : 0;
+      const int cl = ec / per, p = ec - cl * per;
+      const int ntaps_c = classes ? __shfl(cnt_l, cl) : k.ntaps;
+      const unsigned tap = dc_div((unsigned)p, k.mg_cgs);
+      const int cg = p - (int)tap * k.cgs;
+      const int tc = (int)tap < ntaps_c ? (int)tap : 0;
+      const int ti = classes ? __shfl(ctap_l, cl * 8 + (tc & 7)) : tc;
+      const int to = __shfl(tapofs_l, ti & 31);
+      if (e < per * ncl) ktab[e] = (int)tap < ntaps_c ? to * k.vs + cg * 16 : 0;  // padded K-groups: zero weights times the voxel's own (finite) data
+    }
+  }
+  // this lane's voxel of every M-tile: v = m*16 + l15 -> (vx, vy, vz) inside the tile
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int v = m * 16 + l15;
+    const int vz = v & ((1 << k.tl[2]) - 1), vy = (v >> k.tl[2]) & ((1 << k.tl[1]) - 1), vx = v >> (k.tl[2] + k.tl[1]);
+    abase[m] = ((vx * k.is[0] * k.halo[1] + vy * k.is[1]) * k.halo[2] + vz * k.is[2]) * k.vs;
+  }
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
+  zero_acc();
+  DC_MARK(2);
+
+  // ---- epilogue of M-tile m, channel tile T: its `parts` partial sums sit in the slabs at position j of waves w0, w0+1, ... ----
   auto tile_epilogue = [&](auto tc, int m, int j, int w0, int parts, int oo0, int oo1, int oo2) __attribute__((always_inline)) {
     constexpr int T = decltype(tc)::value;
     f32x4 s = *reinterpret_cast<const f32x4*>(red + ((w0 * RT + j) * 64 + lane) * 16);
@@ -216,7 +297,7 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
     const int cl16 = T * 16 + g * 4, c = c_base + cl16;
     const float4 bi = *reinterpret_cast<const float4*>(epi + cl16);
     float val[4] = {s[0] + bi.x, s[1] + bi.y, s[2] + bi.z, s[3] + bi.w};
-    if (!vok) return;
+    if (!vok | (c >= k.cout)) return;  // (channels past the last real one of a padded channel tile: nothing to add, nothing to load — the auxiliary row ends at cout)
     if (k.stats) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { ssum[T][e] += val[e]; ssq[T][e] += val[e] * val[e]; }
@@ -266,6 +347,16 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
       }
     }
   };
+  // all NT channel tiles of M-tile m (independent: their slab reads, auxiliary loads and stores overlap)
+  auto mtile_epilogue = [&](int m, int r, int w0, int parts, int oo0, int oo1, int oo2) __attribute__((always_inline)) {
+    const int j0 = (m - r * MR) * NT;
+    tile_epilogue(std::integral_constant<int, 0>{}, m, j0, w0, parts, oo0, oo1, oo2);
+    if constexpr (NT > 1) tile_epilogue(std::integral_constant<int, 1>{}, m, j0 + 1, w0, parts, oo0, oo1, oo2);
+    if constexpr (NT > 2) tile_epilogue(std::integral_constant<int, 2>{}, m, j0 + 2, w0, parts, oo0, oo1, oo2);
+    if constexpr (NT > 3) tile_epilogue(std::integral_constant<int, 3>{}, m, j0 + 3, w0, parts, oo0, oo1, oo2);
+    if constexpr (NT > 4) tile_epilogue(std::integral_constant<int, 4>{}, m, j0 + 4, w0, parts, oo0, oo1, oo2);
+    if constexpr (NT > 5) tile_epilogue(std::integral_constant<int, 5>{}, m, j0 + 5, w0, parts, oo0, oo1, oo2);
+  };
   // this wave's accumulators of slab round R -> its slab (registers are indexed statically: this part is unrolled; the epilogues are loops)
   auto write_round = [&](auto rc) __attribute__((always_inline)) {
     constexpr int R = decltype(rc)::value;
@@ -276,64 +367,52 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
 
   if (!classes) {
     // ================= one lattice class: the waves split the K-steps (wave w: K-steps w, w+4, ...), partial sums meet in the slabs =================
-    const int nks = (k.ntaps * k.cgs + 3) >> 2;
-    const int cnt = nks > wave ? (nks - 1 - wave) / DC_WAVES + 1 : 0;
-    zero_acc();
     for (int ch = 0; ch < k.nchunks; ++ch) {
-      if (ch > 0) __syncthreads();  // every wave finished the previous chunk's K loop
-      load_halo(ch);
-      __syncthreads();              // halo (and the tables) visible
-      k_loop(k.wpack + ((int64_t)(row0 * k.nchunks + ch) * k.ksteps + wave) * (NT * 1024) + lane * 16, (int64_t)DC_WAVES * NT * 1024, ktab + wave * 4 + g, DC_WAVES * 4, cnt);
+      const char* wsrc = k.wpack + ((int64_t)(row0 * k.nchunks + ch) * k.ksteps + wave) * (NT * 1024) + lane * 16;
+      if (ch > 0) {
+        __syncthreads();  // every wave finished the previous chunk's K loop
+        issue_halo(ch);
+        k_preload(wsrc, (int64_t)DC_WAVES * NT * 1024, cnt0);
+      }
+      wait_halo();
+      __syncthreads();    // halo (and the tables) visible
+      DC_MARK(3);
+      k_run(wsrc, (int64_t)DC_WAVES * NT * 1024, ktab + wave * 4 + g, DC_WAVES * 4, cnt0);
     }
+    DC_MARK(4);
     for (int r = 0; r < ROUNDS; ++r) {
       __syncthreads();  // K loops done with the halo (the slabs overlap it) / previous round's slabs consumed
       if (r == 0) write_round(std::integral_constant<int, 0>{});
       else write_round(std::integral_constant<int, ROUNDS - 1>{});
       __syncthreads();
-      auto per_t = [&](auto tc) __attribute__((always_inline)) {
-        constexpr int T = decltype(tc)::value;
-        for (int m = 0; m < MT; ++m) {
-          const int i = m * NT + T;
-          if (i < r * RT || i >= (r + 1) * RT || (i & (DC_WAVES - 1)) != wave) continue;  // tile i belongs to wave i % 4 (wave-uniform)
-          tile_epilogue(tc, m, i - r * RT, 0, DC_WAVES, k.oo[0], k.oo[1], k.oo[2]);
-        }
-      };
-      per_t(std::integral_constant<int, 0>{});
-      if constexpr (NT > 1) per_t(std::integral_constant<int, 1>{});
-      if constexpr (NT > 2) per_t(std::integral_constant<int, 2>{});
-      if constexpr (NT > 3) per_t(std::integral_constant<int, 3>{});
-      if constexpr (NT > 4) per_t(std::integral_constant<int, 4>{});
-      if constexpr (NT > 5) per_t(std::integral_constant<int, 5>{});
+      for (int m = r * MR + wave; m < (r + 1) * MR && m < MT; m += DC_WAVES)  // M-tile m belongs to wave (m - r * MR) % 4
+        mtile_epilogue(m, r, 0, DC_WAVES, k.oo[0], k.oo[1], k.oo[2]);
     }
   } else {
     // ================= all parity classes: the halo is loaded once, every wave computes WHOLE classes (all K-steps, all tiles): no partial sums, no barriers =================
-    load_halo(0);
+    wait_halo();
     __syncthreads();
-    for (int ci = 0; ci < kp->wave_ncls[wave]; ++ci) {
+    DC_MARK(3);
+    for (int ci = 0; ci < ncls_w; ++ci) {
       const int cl = kp->wave_cls[wave][ci];
-      const int nks = (kp->class_ntaps[cl] * k.cgs + 3) >> 2;
-      zero_acc();
-      k_loop(k.wpack + (int64_t)cl * k.ksteps * (NT * 1024) + lane * 16, (int64_t)NT * 1024, ktab + cl * k.ksteps * 4 + g, 4, nks);
+      const int nks = (__shfl(cnt_l, cl) * k.cgs + 3) >> 2;
+      const char* wsrc = k.wpack + (int64_t)cl * k.ksteps * (NT * 1024) + lane * 16;
+      if (ci > 0) { zero_acc(); k_preload(wsrc, (int64_t)NT * 1024, nks); }
+      k_run(wsrc, (int64_t)NT * 1024, ktab + cl * k.ksteps * 4 + g, 4, nks);
+      const int oo0 = kp->class_oo[cl][0], oo1 = kp->class_oo[cl][1], oo2 = kp->class_oo[cl][2];
       for (int r = 0; r < ROUNDS; ++r) {  // through this wave's own slab (every lane reads back what it wrote): the epilogue stays a loop
         if (r == 0) write_round(std::integral_constant<int, 0>{});
         else write_round(std::integral_constant<int, ROUNDS - 1>{});
-        auto per_t = [&](auto tc) __attribute__((always_inline)) {
-          constexpr int T = decltype(tc)::value;
-          for (int m = 0; m < MT; ++m) {
-            const int i = m * NT + T;
-            if (i < r * RT || i >= (r + 1) * RT) continue;
-            tile_epilogue(tc, m, i - r * RT, wave, 1, kp->class_oo[cl][0], kp->class_oo[cl][1], kp->class_oo[cl][2]);
-          }
-        };
-        per_t(std::integral_constant<int, 0>{});
-        if constexpr (NT > 1) per_t(std::integral_constant<int, 1>{});
-        if constexpr (NT > 2) per_t(std::integral_constant<int, 2>{});
-        if constexpr (NT > 3) per_t(std::integral_constant<int, 3>{});
-        if constexpr (NT > 4) per_t(std::integral_constant<int, 4>{});
-        if constexpr (NT > 5) per_t(std::integral_constant<int, 5>{});
+        for (int m = r * MR; m < (r + 1) * MR && m < MT; ++m) mtile_epilogue(m, r, wave, 1, oo0, oo1, oo2);
       }
     }
+    DC_MARK(4);
   }
+  DC_MARK(5);
+#ifdef VSSEG_DC_PROF
+  if (k.prof && blockIdx.x == 8 && blockIdx.y == 0 && tid == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&k.prof[i], pt[i + 1] - pt[i]);
+#endif
 
   if (k.stats) {  // per-channel sum / sum of squares of this workgroup's voxels -> the layer's sharded statistics (fixed-point atomics: order-independent)
 #pragma unroll
@@ -499,6 +578,20 @@ int vsseg_dconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.stats = d->stats; k.stats_stride = d->stats_stride;
   k.fxflag = vsseg_fx_flag();
   VSSEG_CHECK(k.fxflag, "vsseg_igemm: could not allocate the flag word");
+  k.prof = nullptr;
+#ifdef VSSEG_DC_PROF
+  static unsigned long long* prof = nullptr;
+  if (!prof) (void)hipMalloc(&prof, 8 * 8);
+  (void)hipMemsetAsync(prof, 0, 8 * 8, s);
+  k.prof = prof;
+  struct ProfPrint { unsigned long long* p; hipStream_t s; ~ProfPrint() {
+    if (!getenv("VSSEG_DC_PROF_PRINT")) return;
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, p, sizeof(h), hipMemcpyDeviceToHost);
+    fprintf(stderr, "dconv prof (workgroup 8, wave 0; cycles): setup %llu | issue halo + preload + tables %llu | halo wait + barrier %llu | k-loop %llu | reduce+epilogue %llu\n", h[0], h[1], h[2], h[3], h[4]);
+  } } pp{prof, s};
+#endif
   k.zeros = zeros;
   k.act = d->act;
   k.X = d->in.x; k.Y = d->in.y; k.Z = d->in.z; k.OX = d->out.x; k.OY = d->out.y; k.OZ = d->out.z;

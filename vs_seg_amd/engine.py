@@ -408,9 +408,16 @@ class Plan:
                 wpr = torch.empty(mr.numel(), dtype=eng.tdtype, device=eng.device)
                 L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), mr.data_ptr(), None, wpr.data_ptr(), mr.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
                 d.wpack_res = wpr.data_ptr()
+            if os.environ.get("VSSEG_TUNE_TRACE"):  # debugging aid: name every candidate before it runs, finish it before the next one
+                import sys
+                print(f"[tune] {pl.kind} depth={pl.depth} q={pl.q} tile={pl.tile} mtw={pl.mtw} nt={pl.nt} ns={pl.nsplit} ck={pl.ck} kc={pl.kc} nc={pl.nc} in=({d.inp.c},{d.inp.pitch},{d.inp.n},{d.inp.x},{d.inp.y},{d.inp.z},two={bool(d.inp.ptr2)}) "
+                      f"out=({d.out.c},{d.out.pitch},dt={d.out.dtype},two={bool(d.out.ptr2)}) acc={d.accumulate} res={d.res_mode} stats={bool(d.stats)} cls={d.class_split}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
             if lib.vsseg_igemm(C.byref(d), stream):  # a candidate the kernel rejects is simply not chosen
                 times.append(float("inf"))
                 continue
+            if os.environ.get("VSSEG_TUNE_TRACE"):
+                torch.cuda.synchronize()
             best = float("inf")
             for _ in range(self.eng.tune_reps):  # best of N single launches (N = 5: with 3 the choice between near-equal plans flipped from run to run by up to 0.5 ms per step)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
