@@ -74,7 +74,7 @@ def summarize_events(events):
     return agg
 
 
-BARS_FP32 = dict(loss_abs=2e-5, logits_rel_l2=1e-4, att_max_abs=2e-4, grad_cos=0.9999, grad_rel_l2_median=3e-3, grad_rel_l2_worst=1.5e-1, prelu_sign_agreement=0.95, prelu_rel_median=2e-2)
+BARS_FP32 = dict(loss_abs=2e-5, logits_rel_l2=1e-4, att_max_abs=2e-4, grad_cos=0.9999, grad_rel_l2_median=3e-3, grad_rel_l2_worst=1.5e-1, prelu_err_over_terms_worst=1e-4, bn_err_over_terms_worst=2e-3)
 
 
 def parity_block(args, dev):
@@ -183,26 +183,53 @@ def cpu_baseline(budget_s=25.0):
     shape = (PATCH[0] // 2, PATCH[1], PATCH[2])
     t = step(shape)
     frac = (shape[0] * shape[1] * shape[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
-    # "all host cores, same box" (north_star) beside it, BOUNDED: the same step on a 64x64x32 patch with every host core in a child process that is given 20 s — on the
-    # 256-thread hosts of this pool the oracle's small convolutions oversubscribe so badly (measured once: 163 s for this 0.2 s step) that an unbounded run would
-    # turn the bench command into a ten-minute one; a run that does not finish is reported as such, with the 16-thread time of the same sample beside it
-    small = (64, 64, 32)
-    sfrac = (small[0] * small[1] * small[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
-    t16 = min(step(small), step(small))
+    # "all host cores, same box" (north_star) as a NUMBER: one process with every host thread oversubscribes the oracle's small convolutions (measured once: 163 s for a
+    # 0.2 s step at 256 threads), so the box is filled the way a user would fill it — P = host_cores // 16 processes x 16 threads, each pinned to its own 16 cores, each
+    # running one training step on its own quarter patch AT THE SAME TIME (they share the memory system; ~5 GB of RAM each, P capped by MemAvailable).  Throughput of
+    # the box = P x 0.25 patch / slowest process.  Bounded: the children get 90 s.
     import subprocess
 
-    code = ("import sys, time, torch; sys.path.insert(0, %r); import bench; torch.set_num_threads(%d); "
-            "f = bench._cpu_step_fn(); f(%r); t = f(%r); print('ALLCORES', t)" % (ROOT, ncpu, small, small))
-    tall, note = None, ""
+    q_shape = (PATCH[0] // 4, PATCH[1], PATCH[2])
+    qfrac = (q_shape[0] * q_shape[1] * q_shape[2]) / (PATCH[0] * PATCH[1] * PATCH[2])
     try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=20.0)
-        tall = next((float(ln.split()[1]) for ln in out.stdout.splitlines() if ln.startswith("ALLCORES")), None)
-        if tall is None:
-            note = "the child process failed: " + out.stderr[-200:]
-    except subprocess.TimeoutExpired:
-        note = f"did not finish a warm-up + one step within 20 s with {ncpu} threads (thread oversubscription of small convolutions)"
-    all_cores = dict(cores=ncpu, value=(sfrac / tall) if tall else None, unit="patches/s", same_sample_with_headline_threads=sfrac / t16,
-                     sample=f"the same step on a {small[0]}x{small[1]}x{small[2]} patch ({sfrac:.4f} of a benchmark patch): " + (f"{tall:.2f} s with {ncpu} threads" if tall else note) + f", {t16:.2f} s with {cores}; scaled by voxels")
+        avail_gb = next(int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")) / 1e6
+    except (OSError, StopIteration):
+        avail_gb = 32.0
+    nproc = max(1, min(ncpu // cores, int(avail_gb // 8), 16))
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(ncpu))
+    code = ("import os, sys, time, torch; sys.path.insert(0, %r); idx = int(sys.argv[1]); cpus = %r; mine = cpus[idx * %d:(idx + 1) * %d];\n"
+            "try:\n    os.sched_setaffinity(0, mine)\nexcept (AttributeError, OSError):\n    pass\n"
+            "import bench; torch.set_num_threads(%d); f = bench._cpu_step_fn(); f((32, 32, 16)); print('READY', flush=True); sys.stdin.readline(); t = f(%r); print('T', t, flush=True)"
+            % (ROOT, cpus, cores, cores, cores, q_shape))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(i)], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(nproc)]
+    times, note = [], ""
+    t_dead = time.perf_counter() + 90.0
+    try:
+        for pr in procs:  # every child has imported torch and run its warm-up step before any of them starts the timed one
+            ln = pr.stdout.readline()
+            if not ln.startswith("READY"):
+                raise RuntimeError("a child process failed: " + pr.stderr.read()[-200:])
+        for pr in procs:
+            pr.stdin.write("go\n")
+            pr.stdin.flush()
+        for pr in procs:
+            out, _ = pr.communicate(timeout=max(1.0, t_dead - time.perf_counter()))
+            times.append(next(float(ln.split()[1]) for ln in out.splitlines() if ln.startswith("T ")))
+    except (subprocess.TimeoutExpired, RuntimeError, StopIteration) as e:
+        note = f"{type(e).__name__}: {e}"[:200]
+        times = []
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    tq = step(q_shape)  # the same quarter patch alone on the headline's 16 threads, for scale
+    all_cores = dict(cores=nproc * cores, processes=nproc, threads_per_process=cores, host_cores=ncpu, value=(nproc * qfrac / max(times)) if times else None, unit="patches/s",
+                     single_process_same_sample=qfrac / tq,
+                     sample=(f"{nproc} processes x {cores} threads (each pinned to its own cores), one training step each on a {q_shape[0]}x{q_shape[1]}x{q_shape[2]} patch ({qfrac:.2f} of a benchmark patch) at the same time: "
+                             + (f"slowest {max(times):.2f} s, fastest {min(times):.2f} s" if times else f"no number ({note})") + f"; one such process alone: {tq:.2f} s; scaled by voxels"))
     return dict(value=frac / t, unit="patches/s", cores=cores, host_cores=ncpu, kind="port", all_cores=all_cores,
                 sample=f"1 training step (fwd+Dice_spvPA+bwd+Adam, fp32, batch 1) of the oracle on a {shape[0]}x{shape[1]}x{shape[2]} patch = {frac:.3f} of a 384x128x128 patch in {t:.2f} s, scaled by voxels")
 
@@ -404,6 +431,23 @@ def main():
         for swb in (2, 4):  # the same blend with 2 / 4 windows per predictor call (identical result: eval-mode BatchNorm has no cross-sample term)
             t = time_swi(swb)
             swi[f"sw_batch_size_{swb}"] = dict(volumes_per_sec=args.swi_volumes * world / t, ms_per_volume=1e3 * t / args.swi_volumes)
+        # BASELINE config 5's other half — "patches scattered + logits RCCL all-gather": ONE volume's windows spread over the ranks (latency mode), the window logits
+        # all-gathered, every rank blending in reference order (parallel.sharded_sliding_window_inference; bit-identical to one GPU).  Timed where there is a group to
+        # gather through: world > 1, or one rank with VSSEG_FORCE_COLLECTIVES=1 (the RCCL branch on a single GPU).
+        if world > 1 or DP._collectives_on():
+            with torch.no_grad():
+                for _ in range(2):
+                    DP.sharded_sliding_window_inference(vol, PATCH, pred, overlap=0.5, mode="gaussian")
+                barrier()
+                s0 = time.perf_counter()
+                for _ in range(args.swi_volumes):
+                    DP.sharded_sliding_window_inference(vol, PATCH, pred, overlap=0.5, mode="gaussian")
+                barrier()
+                wdt = DP.allreduce_max_float(time.perf_counter() - s0, dev)
+            per_rank = -(-14 // world)
+            swi["window_sharded"] = dict(ms_per_volume=1e3 * wdt / args.swi_volumes, volumes_per_sec=args.swi_volumes / wdt, windows_per_rank=per_rank,
+                                         allgather_mb=world * per_rank * 2 * PATCH[0] * PATCH[1] * PATCH[2] * 4 / 1e6,
+                                         note="one 512x512x120 volume at a time: its 14 windows round-robin over the ranks, fp32 window logits all-gathered (RCCL), blended on every rank in reference order")
         model.train()
 
     # ---- BASELINE config 5: a TCIA-shaped synthetic T2 set, cases sharded over ranks, Dice scores all-gathered (timed with the gather)

@@ -132,6 +132,35 @@ def golden_net_train(only=None):
         model.train()
         x, y = synth_input(seed, shape), synth_label(seed, shape)
         loss_fn = Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=att, hardness_weighting=hard)
+        # Sum of the ABSOLUTE terms of every scalar-like gradient that is one cancelling sum over a whole activation tensor (round 5): the PReLU slope
+        # d(alpha) = sum over the negative branch of dA * x, and BatchNorm's d(gamma)[c] = sum dz * xhat, d(beta)[c] = sum dz.  tests/parity_check.py bars
+        # |got - want| / sum|terms|: an error measured against what was summed, which tells "the sum cancels to ~0" from "wrong" (a sign count cannot).
+        gabs = {}
+
+        def hook_act(name):
+            def fwd(mod, inp, out):
+                xin = inp[0].detach()
+                out.register_hook(lambda g: gabs.__setitem__(name + ".weight", np.array([float((g.double() * xin.double())[xin < 0].abs().sum())])))
+            return fwd
+
+        def hook_norm(name):
+            def fwd(mod, inp, out):
+                yin = inp[0].detach().double()
+                red = (0, 2, 3, 4)
+                xhat = (yin - yin.mean(red, keepdim=True)) / torch.sqrt(yin.var(red, unbiased=False, keepdim=True) + mod.eps)
+
+                def bwd(g):
+                    g = g.double()
+                    gabs[name + ".weight"] = (g * xhat).abs().sum(red).numpy()
+                    gabs[name + ".bias"] = g.abs().sum(red).numpy()
+                out.register_hook(bwd)
+            return fwd
+
+        for mname, mod in model.named_modules():
+            if isinstance(mod, torch.nn.PReLU):
+                mod.register_forward_hook(hook_act(mname))
+            elif isinstance(mod, torch.nn.BatchNorm3d):
+                mod.register_forward_hook(hook_norm(mname))
         logits, atts = model(x)
         logits.retain_grad()
         for a in atts:
@@ -156,6 +185,9 @@ def golden_net_train(only=None):
         d["grad_sums"] = json.dumps(gs)
         for k, v in gsub.items():
             d["gsub:" + k] = v
+        for k, v in gabs.items():  # same sub-sampling as gsub: element i of gabs:<key> is the sum of |terms| of element i of gsub:<key>
+            assert k in gsub, k
+            d["gabs:" + k] = v[:: max(1, v.size // 64)][:64].astype(np.float64)
         sd = model.state_dict()
         for k, v in sd.items():
             if "running_" in k:

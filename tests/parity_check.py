@@ -25,9 +25,18 @@ from tests.helpers import load, synth_input, synth_label
 # element's gradient by O(1), i.e. ~5 % relative L2 per activation layer, accumulating in quadrature along the backward path
 # (measured: 0.03-0.3 % on the decoder top, 4-6 % on the level-0 encoder, 13-22 % on the level-2..4 encoder whose only gradient
 # path crosses ~25 layers; the fp32 compute mode agrees to 1e-4..3e-3 on the same tensors — tools/diag_bf16_grads.py).
-# The 25 PReLU slopes are single scalars, each a heavily cancelling sum over a whole activation tensor: their bf16 values are
-# reported (`grad_scalar_rel_worst`) but carry no bar.
-BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4, prelu_sign_agreement=0.8, prelu_rel_median=0.5)
+# The 26 PReLU slopes are single scalars, each a heavily cancelling sum over a whole activation tensor: their relative errors
+# (`grad_scalar_rel_worst`, `prelu_rel_median`) and sign agreement are reported; the bar is on the error over the summed terms (below).
+# Round 5: the slopes (and BatchNorm's gamma / beta gradients, also sums over a whole activation tensor) ARE barred now, by the measure that tells "cancels to ~0" from
+# "wrong": |got - want| / sum|terms|, the error against WHAT WAS SUMMED (the goldens carry sum|dA * x| over the negative branch per slope, sum|dz * xhat| / sum|dz| per
+# BatchNorm channel: `gabs:<key>`, tests/golden/make_goldens.py).  In the reference the slope gradients are 4e-5 .. 2e-2 of their terms (level-1 encoder unit0: -3.1e-4 of
+# 2.03), so a sign count measures nothing: a slope whose sum cancels to 1.5e-4 of its terms changes sign under ANY 0.1 % perturbation of the terms.  Sign agreement and the
+# relative errors stay in the output as reported fields.  Where the bars sit and why: measured on the bf16 path 1.3e-4 median / 2.0e-3 .. 6.1e-3 worst over the 26
+# slopes (22-24 of them under 2e-3; the worst are the level-4/5 layers whose dA has crossed ~25 bf16-stored layers, 13-22 % relative L2), 3e-3 median / 5e-2 worst over the
+# BatchNorm channels (worst: single bottleneck channels, 768 voxels per channel); the fp32 mode gives 2e-5 / 4e-4.  A WRONG gradient — a PReLU branch decided on another
+# tensor, a keep-mask that does not match the forward's, a dropped residual term — moves these ratios by O(0.1 .. 1): the bars (1e-2 slopes, 1e-1 BatchNorm) sit a
+# factor 10 under that and a factor 2 over the bf16 noise; `prelu_over_2e-3` lists the slopes above the tighter 2e-3.
+BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4, prelu_err_over_terms_worst=1e-2, bn_err_over_terms_worst=1e-1)
 
 
 def golden_train_case(name="net_train_b1_384x128x128.npz"):
@@ -88,6 +97,23 @@ def train_step_metrics(model, loss_fn, batch: int = 1, golden: str = "net_train_
     # Reported one by one against the golden: sign agreement and the median relative error are barred (a slope that trains in the wrong direction
     # would show here), the worst relative error is the slope whose reference gradient is itself ~0 (the sum cancels to 1e-3 of its terms)
     slopes = [(float(p.grad.double()), float(g["gsub:" + k][0]), k) for k, p in model.named_parameters() if k.endswith("act.weight")]
+    if slopes and ("gabs:" + slopes[0][2]) in g.files:
+        eot = [(abs(a - b) / (float(g["gabs:" + k][0]) + 1e-30), k) for a, b, k in slopes]
+        out["prelu_err_over_terms_worst"], out["prelu_err_over_terms_worst_slope"] = max(eot)
+        out["prelu_err_over_terms_median"] = sorted(e for e, _ in eot)[len(eot) // 2]
+        out["prelu_over_2e-3"] = [k for e, k in eot if e > 2e-3]
+        # slopes whose sign differs from the golden's: (error / sum|terms|, |reference gradient| / sum|terms|) — a sign can only survive an error smaller than the cancellation
+        out["prelu_disagree_detail"] = {k: [round(e, 7), round(abs(b) / (float(g["gabs:" + k][0]) + 1e-30), 7)] for (e, k), (a, b, _) in zip(eot, slopes) if (a > 0) != (b > 0)}
+        out["prelu_cancellation_min"] = min(abs(b) / (float(g["gabs:" + k][0]) + 1e-30) for _, b, k in slopes)  # |reference gradient| / sum|terms| of the most cancelling slope
+        bn = []
+        for k, p in model.named_parameters():
+            if (k.endswith("norm.weight") or k.endswith("norm.bias")) and ("gabs:" + k) in g.files:
+                gk = p.grad.double().flatten().cpu()
+                sub = gk[:: max(1, gk.numel() // 64)][:64].numpy()
+                bn.append((float(np.max(np.abs(sub - g["gsub:" + k].astype(np.float64)) / (g["gabs:" + k] + 1e-30))), k))
+        if bn:
+            out["bn_err_over_terms_worst"], out["bn_err_over_terms_worst_tensor"] = max(bn)
+            out["bn_err_over_terms_median"] = sorted(e for e, _ in bn)[len(bn) // 2]
     if slopes:
         agree = [1.0 if (a > 0) == (b > 0) else 0.0 for a, b, _ in slopes]
         rel = sorted(abs(a - b) / (abs(b) + 1e-30) for a, b, _ in slopes)
@@ -102,4 +128,4 @@ def train_step_metrics(model, loss_fn, batch: int = 1, golden: str = "net_train_
 def passes(m: Dict[str, float], bars=BARS) -> bool:
     return (m["loss_abs"] <= bars["loss_abs"] and m["logits_rel_l2"] <= bars["logits_rel_l2"] and m["att_max_abs"] <= bars["att_max_abs"] and m["grad_cos"] >= bars["grad_cos"]
             and m["grad_rel_l2_median"] <= bars["grad_rel_l2_median"] and m["grad_rel_l2_worst"] <= bars["grad_rel_l2_worst"]
-            and m.get("prelu_sign_agreement", 1.0) >= bars.get("prelu_sign_agreement", 0.0) and m.get("prelu_rel_median", 0.0) <= bars.get("prelu_rel_median", float("inf")))
+            and m.get("prelu_err_over_terms_worst", 0.0) <= bars.get("prelu_err_over_terms_worst", float("inf")) and m.get("bn_err_over_terms_worst", 0.0) <= bars.get("bn_err_over_terms_worst", float("inf")))

@@ -35,3 +35,6 @@ def test_bench_gpus_2_starts_two_ranks_and_prints_one_line():
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 8 and r["config"]["parallelism"] == "dp2"
     assert r["sharded_cases"]["cases"] == 2 and len(r["sharded_cases"]["scores"]) == 2
     assert r["value"] > 0 and r["sliding_window"]["volumes_per_sec"] > 0 and "cpu_baseline" not in r
+    # the latency mode of BASELINE config 5 ("patches scattered + logits all-gather"): one volume's 14 windows over the two ranks, window logits gathered, timed
+    ws = r["sliding_window"]["window_sharded"]
+    assert ws["ms_per_volume"] > 0 and ws["windows_per_rank"] == 7 and abs(ws["allgather_mb"] - 2 * 7 * 2 * 384 * 128 * 128 * 4 / 1e6) < 1e-6

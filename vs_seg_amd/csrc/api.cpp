@@ -15,13 +15,21 @@ extern "C" void vsseg_set_error(const char* fmt, ...) {
 extern "C" const char* vsseg_last_error(void) { return g_err; }
 extern "C" int vsseg_version(void) { return 2; }
 
-// Sticky flag of the fixed-point accumulators (csrc/common.h, vsseg_fx_add): one word of device memory per process (one process per GPU).
+// Sticky flag of the fixed-point accumulators (csrc/common.h, vsseg_fx_add): one word of device memory PER DEVICE (the current device of the calling thread: one
+// process per GPU is the product's layout, a second device in the same process gets its own word), allocated once under a lock.  nullptr only if the allocation
+// failed: every launcher checks (VSSEG_FX_FLAG in common.h) instead of handing a null pointer to a kernel.
+#include <mutex>
 unsigned* vsseg_fx_flag() {
-  static unsigned* f = nullptr;
-  if (!f) {
-    if (hipMalloc(reinterpret_cast<void**>(&f), 256) != hipSuccess || hipMemset(f, 0, 256) != hipSuccess) f = nullptr;
+  static std::mutex mu;
+  static unsigned* flags[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!flags[dev]) {
+    unsigned* f = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&f), 256) == hipSuccess && hipMemset(f, 0, 256) == hipSuccess) flags[dev] = f;
   }
-  return f;
+  return flags[dev];
 }
 extern "C" int vsseg_fx_status(int32_t reset, void* stream) {
   unsigned* f = vsseg_fx_flag();

@@ -199,6 +199,10 @@ constexpr double VSSEG_FX_STAT = 1048576.0;         // 2^20
 constexpr double VSSEG_FX_GRAD = 17592186044416.0;  // 2^44
 constexpr double VSSEG_FX_LIMIT = 4503599627370496.0;  // 2^52, in fixed-point units
 unsigned* vsseg_fx_flag();  // api.cpp: the sticky range / non-finite flag word in device memory (nullptr if it could not be allocated)
+// the flag word of the current device for a launcher, or an error return: a kernel is never handed a null flag pointer
+#define VSSEG_FX_FLAG(var, who)                                                                    \
+  unsigned* var = vsseg_fx_flag();                                                                 \
+  VSSEG_CHECK(var, who ": could not allocate the fixed-point range flag word on the current device")
 __device__ __forceinline__ void vsseg_fx_add(double* slot, double v, double scale, unsigned* flag) {
   double s = v * scale;
   if (!(fabs(s) < VSSEG_FX_LIMIT)) {  // out of range or not finite

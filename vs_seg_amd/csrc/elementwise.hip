@@ -177,7 +177,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, int stride,
 extern "C" int vsseg_bn_finalize(const double* stats, int32_t stride, int32_t c, double count, const float* gamma, const float* beta, float eps, float momentum,
                                  float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd, float* scale, float* shift, void* stream) {
   VSSEG_CHECK(stats && gamma && beta && mean && invstd && scale && shift && c > 0 && c <= stride, "vsseg_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), stats, stride, c, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd, scale, shift, vsseg_fx_flag());
+  VSSEG_FX_FLAG(fxflag, "vsseg_bn_finalize");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), stats, stride, c, count, gamma, beta, eps, momentum, running_mean, running_var, num_batches, mean, invstd, scale, shift, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_bn_finalize");
   return VSSEG_OK;
 }
@@ -443,7 +444,8 @@ extern "C" int vsseg_bn_act_bwd_reduce(vsseg_tensor y, vsseg_tensor dout, const 
   const int budget = 65536;  // fp64 flush atomics per launch the grid is sized for (measured)
   const int cap = (int)std::min<int64_t>(256 * 8, std::max<int64_t>(192, std::min<int64_t>(items / ((int64_t)blk * 16), y.c <= 16 ? 256 * 3 : budget / (3 * y.c))));
   int grid = grid_for((nv * cgs + 1) / 2, blk, cap);  // 2 voxels in flight per thread (measured: 2 beats 4)
-  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in, vsseg_fx_flag()));
+  VSSEG_FX_FLAG(fxflag, "vsseg_bn_act_bwd_reduce");
+  DISPATCH_T(y.dtype, hipLaunchKernelGGL((bn_act_bwd_reduce_kernel<T, 2>), dim3(grid), dim3(blk), lds, as_stream(stream), (const T*)y.ptr, y.pitch, (const T*)dout.ptr, dout.pitch, a, cgs, nv, sums, stride, alpha_acc, keep_in, fxflag));
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_reduce");
   return VSSEG_OK;
 }
@@ -468,7 +470,8 @@ __global__ void bn_act_bwd_finalize_kernel(const double* __restrict__ sums, int 
 extern "C" int vsseg_bn_act_bwd_finalize(const double* sums, int32_t stride, const double* alpha_acc, int32_t c, double count, float* dgamma, float* dbeta, float* dalpha,
                                          float* mean_dz, float* mean_dzx, float* dres_bias, void* stream) {
   VSSEG_CHECK(sums && alpha_acc && dgamma && dbeta && dalpha && mean_dz && mean_dzx && c > 0, "vsseg_bn_act_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx, dres_bias, vsseg_fx_flag());
+  VSSEG_FX_FLAG(fxflag, "vsseg_bn_act_bwd_finalize");
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3(c), dim3(256), 0, as_stream(stream), sums, stride, alpha_acc, c, count, dgamma, dbeta, dalpha, mean_dz, mean_dzx, dres_bias, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_bn_act_bwd_finalize");
   return VSSEG_OK;
 }

@@ -73,7 +73,8 @@ __global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitc
 extern "C" int vsseg_dice_pred_sums(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, double* sums, void* stream) {
   VSSEG_CHECK(logits && label && sums && pitch >= 2 && pitch % 2 == 0 && n >= 1, "vsseg_dice_pred_sums: bad arguments");
   dim3 g(grid_for(nvox, 256, 1024), n);
-  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums, vsseg_fx_flag());
+  VSSEG_FX_FLAG(fxflag, "vsseg_dice_pred_sums");
+  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_pred_sums");
   return VSSEG_OK;
 }
@@ -94,7 +95,8 @@ __global__ void dice_att_sums_kernel(const float* __restrict__ att, const float*
 extern "C" int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t nvox, double* sums, void* stream) {
   VSSEG_CHECK(att && label && sums && n >= 1, "vsseg_dice_att_sums: bad arguments");
   dim3 g(grid_for(nvox, 256, 1024), n);
-  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(256), 0, as_stream(stream), att, label, nvox, sums, vsseg_fx_flag());
+  VSSEG_FX_FLAG(fxflag, "vsseg_dice_att_sums");
+  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(256), 0, as_stream(stream), att, label, nvox, sums, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_sums");
   return VSSEG_OK;
 }
@@ -125,7 +127,8 @@ __global__ void dice_finalize_kernel(const double* pred_sums, const double* att_
 }
 extern "C" int vsseg_dice_finalize(const double* pred_sums, const double* att_sums, int32_t n, int32_t nlevels, float* loss, float* coef, void* stream) {
   VSSEG_CHECK(pred_sums && loss && coef && (nlevels == 0 || att_sums), "vsseg_dice_finalize: bad arguments");
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), pred_sums, att_sums, n, nlevels, loss, coef, vsseg_fx_flag());
+  VSSEG_FX_FLAG(fxflag, "vsseg_dice_finalize");
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, as_stream(stream), pred_sums, att_sums, n, nlevels, loss, coef, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_finalize");
   return VSSEG_OK;
 }

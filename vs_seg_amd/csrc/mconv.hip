@@ -822,7 +822,8 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
-  k.fxflag = vsseg_fx_flag();
+  VSSEG_FX_FLAG(fxflag_, "vsseg_igemm (marching kernel)");
+  k.fxflag = fxflag_;
   k.zeros = zeros;
   k.act = d->act; k.cout = d->out.c; k.cout_mod = d->cout_mod;
   k.ps = d->os[0] == 2;

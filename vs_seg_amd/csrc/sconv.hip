@@ -433,7 +433,8 @@ int vsseg_sconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.bias = d->bias; k.bias2 = d->bias2; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha;
   k.stats = d->stats; k.stats_stride = d->stats_stride;
-  k.fxflag = vsseg_fx_flag();
+  VSSEG_FX_FLAG(fxflag_, "vsseg_igemm (streaming kernel)");
+  k.fxflag = fxflag_;
   k.zeros = zeros;
   k.act = d->act; k.cout = d->depth == -4 ? d->nt * 16 : d->out.c; k.cout_mod = d->cout_mod;
   k.ps_cls0 = d->depth == -4 ? 2 * d->oo[0] : 0;

@@ -375,7 +375,7 @@ class Plan:
         p0 = ch.cands[0]
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
                f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else "")
-               + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else "") + ("|c1" if (d.inp.c == 1 and p0.kc == 8) else "")
+               + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else "") + ("|c1" if (d.inp.c == 1 and p0.kc == 8) else ("|c2" if (d.inp.c == 2 and d.inp.pitch == 2 and p0.kc == 8) else ""))
                + ("|bin" if bool(d.in_bn_scale) else "") + ("|ko" if bool(d.keep_out) else ""))
         cache = _tune_cache()
         hit = cache.get(key)
@@ -1449,18 +1449,38 @@ class Engine:
         """Data parallel: rank 0 lowers the training plan (measuring whatever the shipped / cached plans do not cover), broadcasts its measured
         choices, and the other ranks lower from those — every rank then runs the same kernels with the same memory footprint, and the step stays
         bit-reproducible across ranks and processes.  Training plans only: every rank creates them at the same step (DataParallelTrainer), which an
-        eval plan (a rank without test cases never lowers one) does not guarantee.  Single process: plain lowering."""
+        eval plan (a rank without test cases never lowers one) does not guarantee.  Single process: plain lowering.
+
+        COLLECTIVE: under data parallel the first train-mode forward of a (batch, size) signature issues a broadcast, so every rank must reach it (they do: the
+        trainer steps in lock step).  If rank 0 fails while lowering (out of memory, a rejected launch) it broadcasts the error instead of its plan choices and every
+        rank raises — nobody is left waiting in the broadcast until the RCCL timeout; ranks whose VSSEG_AUTOTUNE mode differs from rank 0's are an error, too."""
         import torch.distributed as dist
 
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or self.dry_run or os.environ.get("VSSEG_AUTOTUNE", "1") == "0":
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) or self.dry_run:
             return Plan(self, *key[:3])
+        mode = os.environ.get("VSSEG_AUTOTUNE", "1")
         if dist.get_rank() == 0:
-            pl = Plan(self, *key[:3])
-            dist.broadcast_object_list([dict(_tune_cache())], src=0)
+            msg = dict(mode=mode, error=None, cache=None)
+            pl = None
+            try:
+                pl = Plan(self, *key[:3])
+                if mode != "0":
+                    msg["cache"] = dict(_tune_cache())
+            except BaseException as e:  # (re-raised below, after the other ranks have been told)
+                msg["error"] = f"{type(e).__name__}: {e}"
+                dist.broadcast_object_list([msg], src=0)
+                raise
+            dist.broadcast_object_list([msg], src=0)
             return pl
         box = [None]
         dist.broadcast_object_list(box, src=0)
-        _tune_cache().update(box[0])
+        msg = box[0]
+        if msg["error"] is not None:
+            raise RuntimeError(f"vs_seg_amd: rank 0 failed while lowering the training plan {key[:3]}: {msg['error']}")
+        if msg["mode"] != mode:
+            raise RuntimeError(f"vs_seg_amd: VSSEG_AUTOTUNE differs between ranks (rank 0: {msg['mode']!r}, rank {dist.get_rank()}: {mode!r}): the ranks would run different kernels")
+        if msg["cache"] is not None:
+            _tune_cache().update(msg["cache"])
         return Plan(self, *key[:3])
 
     def min_multiple(self):

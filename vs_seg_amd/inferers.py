@@ -116,19 +116,20 @@ _SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 _CNT_CACHE: Dict[tuple, torch.Tensor] = {}  # (device, padded extents, roi, window starts, importance map) -> sum of the window weights per voxel
 
 
-def _weight_sum(lib, device, padded, roi, starts, imap: torch.Tensor, stream) -> torch.Tensor:
+def _weight_sum(lib, device, padded, roi, starts, imap: torch.Tensor, stream, mode_key=None) -> torch.Tensor:
     """The denominator of the blend, sum of the importance maps of all windows that cover a voxel (MONAI's count_map): a function of the window geometry only, so it is
     accumulated once per geometry — in window order, exactly as the per-volume buffer was — and kept (the four most recent geometries)."""
-    key = (str(device), tuple(padded), tuple(roi), tuple(tuple(s) for s in starts), imap.data_ptr())
-    cnt = _CNT_CACHE.get(key)
+    key = (str(device), tuple(padded), tuple(roi), tuple(tuple(s) for s in starts), mode_key)
+    hit = _CNT_CACHE.get(key)
+    cnt = hit[0] if hit is not None else None
     if cnt is None:
         cnt = torch.zeros(tuple(padded), dtype=torch.float32, device=device)
         for s0 in starts:
             L.check(lib.vsseg_swi_accumulate(None, imap.data_ptr(), L.i3(roi), L.i3(s0), 1, None, cnt.data_ptr(), L.i3(padded), stream), "swi_accumulate")
-        torch.cuda.current_stream(device).synchronize()  # (once per geometry: later calls may read it from any stream)
+        torch.cuda.current_stream(device).synchronize()  # (once per geometry: later calls may read it from any stream; `stream` IS this device's current stream, see the caller)
         while len(_CNT_CACHE) >= 4:
             _CNT_CACHE.pop(next(iter(_CNT_CACHE)))
-        _CNT_CACHE[key] = cnt
+        _CNT_CACHE[key] = (cnt, imap)  # keyed by what defines the map (roi, mode, device — as _IMAP_CACHE), and holding the map itself: an address can be reused, a key cannot
     return cnt
 
 
@@ -167,11 +168,11 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     imap = importance_map(roi, mode, inputs.device)
     slices = [(b, s) for b in range(B) for s in starts]
     out = None
-    stream = torch.cuda.current_stream().cuda_stream
-    cnt = _weight_sum(lib, inputs.device, padded, roi, starts, imap, stream)  # [padded]: the same for every batch element
+    main = torch.cuda.current_stream(inputs.device)  # launch stream and synchronisation point are the SAME stream object: the current stream of the inputs' device
+    stream = main.cuda_stream
+    cnt = _weight_sum(lib, inputs.device, padded, roi, starts, imap, stream, mode_key=str(mode))  # [padded]: the same for every batch element
     per_win = roi[0] * roi[1] * roi[2] * 4
     windows = crop_all_windows(vol, slices, roi, pad_before) if len(slices) * per_win <= (8 << 30) else None  # one crop launch per call (<= 8 GB of windows), else per group
-    main = torch.cuda.current_stream()
     ngroups = -(-len(slices) // sw_batch_size)
     lanes = [_side_stream(inputs.device, i) for i in range(min(int(concurrent_groups), ngroups))] if concurrent_groups > 1 and ngroups > 1 else []
     ready = main.record_event() if lanes else None  # the windows (and the volume) are complete on the caller's stream

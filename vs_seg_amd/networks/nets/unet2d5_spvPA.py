@@ -207,9 +207,14 @@ class UNet2d5_spvPA(nn.Module):
         return logits, self.att_maps
 
     def segmentation_predictor(self):
-        """`lambda x: model(x)[0]` (the predictor the reference hands to sliding_window_inference, ref:params/VSparams.py:560) marked `stream_safe`:
+        """The predictor for `sliding_window_inference` (the reference hands it `lambda x: model(x)[0]`, ref:params/VSparams.py:560), marked `stream_safe`:
         eval forwards of this model issued on different HIP streams use separate plans (activation buffers, packed weights, hipGraph), so the
-        inferer may keep two window groups in flight (vs_seg_amd.inferers.sliding_window_inference, `concurrent_groups`)."""
+        inferer may keep two window groups in flight (vs_seg_amd.inferers.sliding_window_inference, `concurrent_groups`).
+
+        ALIASING CONTRACT — this is NOT a drop-in for `lambda x: model(x)[0]` outside an inferer: in eval mode the returned logits are a VIEW of the calling stream's
+        plan buffer and the NEXT call on the same HIP stream overwrites them (whatever `model.reuse_output_buffers` says).  A caller that keeps two outputs alive
+        (test-time augmentation, ensembling, a custom inferer that batches its blends) must `.clone()` each result — or use `lambda x: model(x)[0]`, which copies.
+        The inferers of this package consume a group's logits before they let that stream run its next group."""
 
         def predictor(x):
             # logits only, as a VIEW of the stream's own plan buffer (no copy of the logits, no copies of the six attention maps the inferer never looks at):
@@ -218,6 +223,8 @@ class UNet2d5_spvPA(nn.Module):
                 return self(x)[0]
             if not x.is_cuda:
                 raise RuntimeError("vs_seg_amd.UNet2d5_spvPA runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
+            if x.dim() != 5 or x.shape[1] != self.in_channels:  # (the same validation as forward())
+                raise ValueError(f"expected input [B,{self.in_channels},X,Y,Z], got {tuple(x.shape)}")
             self._ensure_flat()
             keep, self.reuse_output_buffers = self.reuse_output_buffers, True
             try:

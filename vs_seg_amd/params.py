@@ -261,6 +261,14 @@ class VSparams:
                 for i, v in enumerate(lv.tolist()):
                     logger.info("{}/{}, train_loss: {:.4f}".format(i + 1, denom, v))
             epoch_loss = float(lv.sum()) / max(step, 1)
+            if not np.isfinite(epoch_loss):
+                # the fixed-point accumulators (BatchNorm statistics, backward sums, Dice sums) flag an out-of-range or non-finite partial sum and every kernel that decodes
+                # them returns NaN from then on (include/vsseg_hip.h): name that cause once and clear the flag, so that a later epoch is not poisoned by it
+                from ._lib import fx_status
+
+                if fx_status(reset=True):
+                    logger.error("epoch {}: a fixed-point partial sum left its range or was NaN / Inf (diverging activations or gradients, or a loss scale beyond 256): "
+                                 "the statistics / loss of the affected steps are NaN; the flag was reset".format(epoch + 1))
             epoch_loss_values.append(epoch_loss)
             logger.info("epoch {} average loss: {:.4f}".format(epoch + 1, epoch_loss))
 
