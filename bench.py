@@ -173,11 +173,20 @@ def cpu_baseline(budget_s=25.0):
     """The oracle timed on the host cores: one fwd+loss+bwd+Adam step, batch 1 (bounded sample)."""
     ncpu = os.cpu_count() or 1
     step = _cpu_step_fn()
-    # A bounded sample (about 15 s of CPU work): 16 threads — on the 2-socket hosts of this pool "all host cores" is 5-10x SLOWER for this oracle (thread
-    # oversubscription of small convolutions; calibrating 8 / 16 / 32 / all cores was measured once: 16 threads won, 0.046 vs 0.032 patches/s at
-    # 256 threads, and the calibration itself cost six minutes of the bench command) — one warm-up step on a small patch, then one full training
-    # step on half a benchmark patch, scaled by voxels
-    cores = min(16, ncpu)
+    # A bounded sample (about 15 s of CPU work) on the cores the container may use, at most 16 threads per process: one warm-up step on a small patch, then one full
+    # training step on half a benchmark patch, scaled by voxels.  (Rounds 2-4 found "all 256 host threads" 5-800x SLOWER than 16 and blamed oversubscription of the
+    # oracle's small convolutions; round 5 read the cgroup: the box grants 16 cores of CPU time, 256 threads were simply throttled.)
+    # the cores this process may actually USE: the container's cgroup CPU quota (cpu.max) — the GPU boxes of this pool show 256 hardware threads and grant 16 cores of
+    # CPU time (measured: cpu.max = 1600000 100000), which is why 256 threads were 800x slower than 16 — and the affinity mask
+    quota = float(ncpu)
+    try:
+        q_, per_ = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q_ != "max":
+            quota = float(q_) / float(per_)
+    except (OSError, ValueError):
+        pass
+    usable = max(1, min(ncpu, int(quota + 0.5)))
+    cores = min(16, usable)
     torch.set_num_threads(cores)
     step((64, 64, 32))
     shape = (PATCH[0] // 2, PATCH[1], PATCH[2])
@@ -195,7 +204,7 @@ def cpu_baseline(budget_s=25.0):
         avail_gb = next(int(ln.split()[1]) for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")) / 1e6
     except (OSError, StopIteration):
         avail_gb = 32.0
-    nproc = max(1, min(ncpu // cores, int(avail_gb // 8), 16))
+    nproc = max(1, min(usable // cores, int(avail_gb // 8), 16))
     try:
         cpus = sorted(os.sched_getaffinity(0))
     except AttributeError:
@@ -219,16 +228,16 @@ def cpu_baseline(budget_s=25.0):
             out, _ = pr.communicate(timeout=max(1.0, t_dead - time.perf_counter()))
             times.append(next(float(ln.split()[1]) for ln in out.splitlines() if ln.startswith("T ")))
     except (subprocess.TimeoutExpired, RuntimeError, StopIteration) as e:
-        note = f"{type(e).__name__}: {e}"[:200]
+        note = f"{type(e).__name__} (90 s bound)" if isinstance(e, subprocess.TimeoutExpired) else f"{type(e).__name__}: {e}"[:160]
         times = []
     finally:
         for pr in procs:
             if pr.poll() is None:
                 pr.kill()
     tq = step(q_shape)  # the same quarter patch alone on the headline's 16 threads, for scale
-    all_cores = dict(cores=nproc * cores, processes=nproc, threads_per_process=cores, host_cores=ncpu, value=(nproc * qfrac / max(times)) if times else None, unit="patches/s",
+    all_cores = dict(cores=nproc * cores, processes=nproc, threads_per_process=cores, host_cores=ncpu, usable_cores=usable, cgroup_cpu_quota=quota, value=(nproc * qfrac / max(times)) if times else None, unit="patches/s",
                      single_process_same_sample=qfrac / tq,
-                     sample=(f"{nproc} processes x {cores} threads (each pinned to its own cores), one training step each on a {q_shape[0]}x{q_shape[1]}x{q_shape[2]} patch ({qfrac:.2f} of a benchmark patch) at the same time: "
+                     sample=(f"this container may use {usable} of the host's {ncpu} hardware threads (cgroup cpu.max / affinity): {nproc} processes x {cores} threads (each pinned to its own cores), one training step each on a {q_shape[0]}x{q_shape[1]}x{q_shape[2]} patch ({qfrac:.2f} of a benchmark patch) at the same time: "
                              + (f"slowest {max(times):.2f} s, fastest {min(times):.2f} s" if times else f"no number ({note})") + f"; one such process alone: {tq:.2f} s; scaled by voxels"))
     return dict(value=frac / t, unit="patches/s", cores=cores, host_cores=ncpu, kind="port", all_cores=all_cores,
                 sample=f"1 training step (fwd+Dice_spvPA+bwd+Adam, fp32, batch 1) of the oracle on a {shape[0]}x{shape[1]}x{shape[2]} patch = {frac:.3f} of a 384x128x128 patch in {t:.2f} s, scaled by voxels")
