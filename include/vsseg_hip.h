@@ -118,21 +118,6 @@ typedef struct {
   const void* in1;         /* VSSEG_RES_IN1: one-channel tensor [N][X][Y][Z] in the compute dtype (bf16) */
   const float* in1_w;      /* [cout] weights and */
   const float* in1_b;      /* [cout] bias of the 1 -> cout convolution */
-  /* The BatchNorm(train) -> Dropout -> PReLU block BETWEEN two convolutions of a ResidualUnit (ref:params/networks/blocks/convolutions.py:148-156, 223-236) without
-   * its own pass over HBM (marching kernel, statistics epilogue, 16 -> 16 and 32 -> 32 channels only):
-   *   in_bn_scale != NULL: `in` is the RAW output y of the preceding convolution; the block (folded scale / shift of its BatchNorm, PReLU slope, keep-mask bytes
-   *     [voxel][in.c / 8] or NULL, dropout p) is applied ON LOAD — bit-identical to reading the tensor vsseg_bn_act_fwd(y) would have written, which then never exists;
-   *   keep_out != NULL (any statistics launch of the marching kernel): the launch also draws the keep-mask bytes [voxel][out.c / 8] of the block behind ITS output,
-   *     exactly the bytes vsseg_bn_act_fwd(out, p = keep_p, keep_seed, keep_salt) would store (same Philox counter per (voxel, 8-channel group)). */
-  const float* in_bn_scale;
-  const float* in_bn_shift;
-  const float* in_bn_alpha;
-  const uint8_t* in_bn_keep;
-  float in_bn_p;
-  float keep_p;
-  uint8_t* keep_out;
-  uint64_t keep_seed;      /* value, or device address with keep_salt | VSSEG_SEED_INDIRECT (as for vsseg_bn_act_fwd) */
-  uint32_t keep_salt;
 } vsseg_igemm_desc;
 
 /* Weight gradient: dW[t][cP][cH] += sum_q P[q][cP] * H[q*hs + off_t][cH]  (fp32 atomics into the flat grad buffer).
@@ -187,19 +172,12 @@ typedef struct {
   float* dw_res;           /* IN/OUT: its weight gradient [cout][cin] fp32, += */
   const float* x_gate;     /* optional fp32 attention map [N][X][Y][Z] of x: x[v] is multiplied by (1 + x_gate[v]) on load (AttentionBlock2 in front of the unit, never
                             * materialised; x may then be the two-part concat); dx is the gradient of the GATED tensor.  64 input channels with dres == dout only. */
-  /* optional (x_bn_scale != NULL; 16 -> 16 and 32 -> 32 channels without a residual convolution): `x` is the RAW output of the preceding convolution of the unit and
-   * its BatchNorm -> Dropout -> PReLU block is applied on load (as vsseg_igemm_desc.in_bn_*: the activated tensor the forward never wrote); dx is the gradient of the
-   * ACTIVATED tensor, i.e. the `dout` of that preceding block. */
-  const float* x_bn_scale;
-  const float* x_bn_shift;
-  const float* x_bn_alpha;
-  const uint8_t* x_bn_keep; /* keep-mask bytes [voxel][x.c / 8] of that block, or NULL */
-  float x_bn_p;
 } vsseg_conv_bwd_desc;
 int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 2: fixed-point accumulators documented + vsseg_fx_status (1: the buffers below were described as plain doubles) */
+int vsseg_version(void); /* 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+                            * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------
  * Every `double*` accumulator of this ABI — vsseg_igemm_desc.stats and vsseg_bn_finalize's `stats`, the `sums` / `alpha_acc` of

@@ -734,118 +734,6 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
                 np.testing.assert_allclose(H.stat_decode(stats).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
-BLOCK_ON_LOAD_CASES = [
-    # channels (cin == cout), dims, (tz, mtw) of the marching forward plan, x steps per workgroup, (x steps, rows, tz) of the fused backward launch
-    (16, (10, 64, 16), (8, 4), 4, (4, 32, 8)),   # level-0 encoder unit: 3 x segments, two row blocks, two z blocks
-    (16, (5, 128, 8), (4, 4), 5, (5, 64, 4)),
-    (16, (6, 64, 8), (8, 8), 3, (3, 32, 4)),
-    (32, (6, 64, 8), (4, 2), 3, (3, 32, 4)),     # level-1 encoder unit (plans with the weights in LDS and in registers)
-    (32, (5, 64, 4), (2, 2), 5, (5, 64, 2)),
-]
-
-
-@pytest.mark.parametrize("p_drop", [0.0, 0.1])
-@pytest.mark.parametrize("c,dims,shape,lx,btile", BLOCK_ON_LOAD_CASES)
-def test_batchnorm_block_applied_on_load(c, dims, shape, lx, btile, p_drop):
-    """The BatchNorm -> Dropout -> PReLU block BETWEEN the two convolutions of a ResidualUnit without its own pass (ref:params/networks/blocks/convolutions.py:148-156,
-    223-236): (a) a statistics launch of the marching kernel draws the keep-mask bytes of its output's block (keep_out) — the bytes vsseg_bn_act_fwd stores;
-    (b) the next convolution reads the RAW output and applies the block on load (in_bn_*): output and statistics bit-identical to the launch on the tensor
-    vsseg_bn_act_fwd wrote; (c) so does the fused backward of that convolution for its x operand (x_bn_*): dx and dw bit-identical."""
-    lib = L.lib()
-    k, n, S = (3, 3, 1), 2, H.stream()
-    torch.manual_seed(41)
-    x0 = _round(torch.randn(n, c, *dims), "bf16")                       # input of the first convolution
-    w0 = _round(torch.randn(c, c, *k) / (c * 9) ** 0.5, "bf16")
-    w1 = _round(torch.randn(c, c, *k) / (c * 9) ** 0.5, "bf16")
-    b0, b1 = torch.randn(c).cuda(), torch.randn(c).cuda()
-    x0cl = H.to_cl(x0, torch.bfloat16)
-    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
-    tz, mtw = shape
-    mps = [pl for pl in P.march_plans("conv_fwd", tuple(w0.shape), cls, dims, 2, c, c, c, n=n) if (pl.tile[2], pl.mtw) == (tz, mtw)]
-    assert mps, "no marching plan for this shape"
-    nvox = n * int(np.prod(dims))
-    sc, sh, al = (torch.rand(c) + 0.5).cuda(), (torch.randn(c) * 0.3).cuda(), torch.tensor([0.25], device="cuda")
-    seed, salt = 0x5151AA, 9
-    for mp in mps:  # (depth -5, and -6 where the shape has the twin)
-        mp = dataclasses.replace(mp, tile=(lx, mp.tile[1], mp.tile[2]))
-        mp.pack_map = P.pack_map(mp, tuple(w0.shape))
-        wp0, wp1 = H.pack(mp, w0, torch.bfloat16), H.pack(mp, w1, torch.bfloat16)
-        # ---- (a) first convolution: raw output y0 + statistics (+ the keep-mask bytes of its block)
-        y0 = torch.full((n, *dims, c), float("nan"), dtype=torch.bfloat16, device="cuda")
-        st0 = torch.zeros(L.STAT_SHARDS * 2 * c, dtype=torch.float64, device="cuda")
-        kw = dict(bias=b0.data_ptr(), stats=st0.data_ptr(), stats_stride=c)
-        keep_conv = None
-        if p_drop > 0:
-            keep_conv = torch.full((nvox * c // 8,), 0x5A, dtype=torch.uint8, device="cuda")
-            kw.update(keep_out=keep_conv.data_ptr(), keep_p=p_drop, keep_seed=seed, keep_salt=salt)
-        d = H.igemm_desc(mp, wp0, H.tdesc(x0cl), H.tdesc(y0), **kw)
-        L.check(lib.vsseg_igemm(C.byref(d), S), "igemm conv0")
-        # ---- the block as its own pass
-        a0 = torch.zeros_like(y0)
-        keep_ref = torch.zeros(nvox * c // 8, dtype=torch.uint8, device="cuda") if p_drop > 0 else None
-        L.check(lib.vsseg_bn_act_fwd(H.tdesc(y0), sc.data_ptr(), sh.data_ptr(), al.data_ptr(), p_drop, seed, salt, L.Tensor(), 0, H.tdesc(a0), keep_ref.data_ptr() if keep_ref is not None else None, S))
-        torch.cuda.synchronize()
-        if p_drop > 0:
-            assert torch.equal(keep_conv, keep_ref), "keep-mask bytes drawn by the convolution launch differ from vsseg_bn_act_fwd's"
-            frac = float(torch.tensor([bin(int(v)).count("1") for v in keep_ref[:4096].cpu()]).sum()) / (8 * 4096)
-            assert abs(frac - (1 - p_drop)) < 0.02
-        # ---- (b) second convolution on the materialised tensor / on the raw one with the block on load
-        outs = []
-        for on_load in (False, True):
-            y1 = torch.full((n, *dims, c), float("nan"), dtype=torch.bfloat16, device="cuda")
-            st1 = torch.zeros(L.STAT_SHARDS * 2 * c, dtype=torch.float64, device="cuda")
-            kw = dict(bias=b1.data_ptr(), stats=st1.data_ptr(), stats_stride=c)
-            if on_load:
-                kw.update(in_bn_scale=sc.data_ptr(), in_bn_shift=sh.data_ptr(), in_bn_alpha=al.data_ptr(), in_bn_p=p_drop, in_bn_keep=keep_ref.data_ptr() if keep_ref is not None else None)
-            d = H.igemm_desc(mp, wp1, H.tdesc(y0 if on_load else a0), H.tdesc(y1), **kw)
-            L.check(lib.vsseg_igemm(C.byref(d), S), f"igemm conv1 on_load={on_load}")
-            torch.cuda.synchronize()
-            outs.append((y1, st1))
-        assert torch.equal(outs[0][0], outs[1][0]), f"depth {mp.depth}: block applied on load differs (max {float((outs[0][0].float() - outs[1][0].float()).abs().max())})"
-        assert torch.equal(outs[0][1].view(torch.int64), outs[1][1].view(torch.int64)), "statistics differ"  # (fixed-point slots: compared as the integers they are)
-        want = F.conv3d(H.from_cl(a0).double(), w1.double(), b1.double().cpu(), padding=P.same_pad(k))
-        np.testing.assert_allclose(H.from_cl(outs[1][0]).numpy(), want.float().numpy(), atol=_tol("bf16", want))
-    # an epilogue the hook is not instantiated with is refused loudly
-    d = H.igemm_desc(mp, wp1, H.tdesc(y0), H.tdesc(y1), bias=b1.data_ptr(), in_bn_scale=sc.data_ptr(), in_bn_shift=sh.data_ptr(), in_bn_alpha=al.data_ptr(), in_bn_p=0.0)
-    assert lib.vsseg_igemm(C.byref(d), S) == L.EINVAL and b"in_bn" in lib.vsseg_last_error()
-    # ---- (c) the fused backward of the second convolution: x = a0 materialised / raw y0 with the block on load
-    y1 = outs[0][0]
-    da = H.to_cl(_round(torch.randn(n, c, *dims), "bf16"), torch.bfloat16)
-    vec = torch.zeros(6, c, device="cuda")
-    vec[0], vec[1] = torch.randn(c) * 0.2 + 0.2, torch.rand(c) + 0.5
-    gam, bet = (torch.rand(c) + 0.5).cuda(), (torch.randn(c) * 0.1).cuda()
-    vec[2] = gam * vec[1]
-    vec[3] = bet - vec[0] * vec[2]
-    vec[4], vec[5] = torch.randn(c) * 0.05, torch.randn(c) * 0.05
-    keep1 = None
-    if p_drop > 0:
-        keep1 = torch.zeros(nvox * c // 8, dtype=torch.uint8, device="cuda")
-        L.check(lib.vsseg_bn_act_fwd(H.tdesc(y1), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr(), p_drop, seed, salt + 1, L.Tensor(), 0, H.tdesc(torch.zeros_like(y1)), keep1.data_ptr(), S))
-    dcls = P.lattice_classes("conv_dgrad", k, (1, 1, 1))[0]
-    dp = P.march_plans("conv_dgrad", tuple(w1.shape), dcls, dims, 2, c, c, c, n=n)[0]
-    dp.pack_map = P.pack_map(dp, tuple(w1.shape))
-    wpd = H.pack(dp, w1, torch.bfloat16)
-    scr = torch.zeros(16 * 1024 * 1024, dtype=torch.float32, device="cuda")
-    res = []
-    for on_load in (False, True):
-        dx = torch.full((n, *dims, c), float("nan"), dtype=torch.bfloat16, device="cuda")
-        dw = torch.zeros(c * c * 9, dtype=torch.float32, device="cuda")
-        fd = L.ConvBwdDesc()
-        fd.y, fd.dout, fd.x, fd.dx = H.tdesc(y1), H.tdesc(da), H.tdesc(y0 if on_load else a0), H.tdesc(dx)
-        fd.mean, fd.invstd, fd.gamma, fd.scale, fd.shift, fd.alpha = vec[0].data_ptr(), vec[1].data_ptr(), gam.data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), al.data_ptr()
-        fd.mean_dz, fd.mean_dzx, fd.p_drop, fd.keep = vec[4].data_ptr(), vec[5].data_ptr(), p_drop, keep1.data_ptr() if keep1 is not None else None
-        fd.wpack, fd.dw, fd.tile = wpd.data_ptr(), dw.data_ptr(), L.i3(btile)
-        fd.scratch, fd.scratch_elems = scr.data_ptr(), scr.numel()
-        if on_load:
-            fd.x_bn_scale, fd.x_bn_shift, fd.x_bn_alpha, fd.x_bn_p, fd.x_bn_keep = sc.data_ptr(), sh.data_ptr(), al.data_ptr(), p_drop, keep_ref.data_ptr() if keep_ref is not None else None
-        L.check(lib.vsseg_conv_bwd_fused(C.byref(fd), S), f"conv_bwd_fused on_load={on_load}")
-        torch.cuda.synchronize()
-        res.append((dx, dw))
-    assert torch.equal(res[0][0], res[1][0]), "data gradient differs"
-    assert torch.equal(res[0][1], res[1][1]), "weight gradient differs"
-    assert float(res[0][1].abs().max()) > 0
-
-
 FUSED_BWD_CASES = [
     # cin, cout, dims, (x steps, rows, tz) of the fused launch
     (16, 16, (10, 64, 16), (4, 32, 8)),   # level-0 unit: two row blocks, two z blocks, three x segments (4 + 4 + 2)

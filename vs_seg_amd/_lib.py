@@ -80,15 +80,6 @@ class IgemmDesc(C.Structure):
         ("in1", C.c_void_p),
         ("in1_w", C.c_void_p),
         ("in1_b", C.c_void_p),
-        ("in_bn_scale", C.c_void_p),
-        ("in_bn_shift", C.c_void_p),
-        ("in_bn_alpha", C.c_void_p),
-        ("in_bn_keep", C.c_void_p),
-        ("in_bn_p", C.c_float),
-        ("keep_p", C.c_float),
-        ("keep_out", C.c_void_p),
-        ("keep_seed", C.c_uint64),
-        ("keep_salt", C.c_uint32),
     ]
 
 
@@ -145,11 +136,6 @@ class ConvBwdDesc(C.Structure):
         ("wpack_res", C.c_void_p),
         ("dw_res", C.c_void_p),
         ("x_gate", C.c_void_p),
-        ("x_bn_scale", C.c_void_p),
-        ("x_bn_shift", C.c_void_p),
-        ("x_bn_alpha", C.c_void_p),
-        ("x_bn_keep", C.c_void_p),
-        ("x_bn_p", C.c_float),
     ]
 
 

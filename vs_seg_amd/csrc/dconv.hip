@@ -467,7 +467,7 @@ static const char* dc_check(const vsseg_igemm_desc* d, DcGeom& gm) {
   if (d->out.c % 4 && d->out.ptr2) return "two-part output needs whole 4-channel groups";
   if (d->out.dtype == VSSEG_BF16 && (d->out.pitch & 3) && d->out.c >= 4) return "output pitch";
   if (d->cout_mod > 0) return "z-folded launches are not supported";
-  if (d->in_gate || d->res_tiles || d->in1 || d->in_bn_scale || d->keep_out || d->res_mode == 5) return "marching-kernel-only features (in_gate / res_tiles / in1 / in_bn / keep_out)";
+  if (d->in_gate || d->res_tiles || d->in1 || d->res_mode == 5) return "marching-kernel-only features (in_gate / res_tiles / in1)";
   if (d->stats && (d->accumulate || d->res_mode != VSSEG_RES_NONE)) return "statistics combined with a residual";
   if (d->accumulate && d->res_mode != VSSEG_RES_NONE) return "accumulate combined with a residual";
   if (d->accumulate || d->res_mode != VSSEG_RES_NONE) {

@@ -232,7 +232,7 @@ __global__ void bn_act_fwd_kernel(const T* __restrict__ y, int yp, const float* 
 #pragma unroll
       for (int j = 0; j < 8; ++j) r.v[j] = x1 * w1[j] + b1[j];
     }
-    bn_fwd_act8(x, keep, alpha, inv_keep, sc, sh, x);  // (bn_bwd.h: shared with the kernels that apply the block on load)
+    bn_fwd_act8(x, keep, alpha, inv_keep, sc, sh, x);  // (bn_bwd.h)
     if constexpr (RES != 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) x.v[j] += r.v[j];

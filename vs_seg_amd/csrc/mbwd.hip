@@ -36,11 +36,6 @@ struct MbwdK {
                                        //     ref:params/networks/blocks/attentionblock.py:43-47: the gated tensor is never materialised)
   const float *mean, *invstd, *gamma, *scale, *shift, *alpha, *mean_dz, *mean_dzx;
   float inv_keep;
-  // XBN: x is the raw output of the unit's preceding convolution; its BatchNorm -> Dropout -> PReLU block is applied on load (bn_bwd.h bn_fwd_act8: the activated
-  // tensor the forward's marching launch also formed on load and never wrote, csrc/mconv.hip BIN)
-  const float *x_sc, *x_sh, *x_alpha;
-  const unsigned char* x_keep;         // keep-mask bytes [voxel][CX / 8] of that block, or nullptr
-  float x_inv_keep;
   const char* wpack;                   // packed weights of the data gradient (K = 9 * CY -> N = CX)
   const char* dr;                      // RES: gradient of the residual convolution's output (CY channels); == da for RES 1
   const char* wpack_r;                 // RES: packed weights of the residual convolution's data gradient (K = CY -> N = CX, one tap)
@@ -67,9 +62,8 @@ constexpr int mb_lds_bytes(int CY, int CX, int TZ, int MT, int RES) {
 }
 
 // (one workgroup per CU where the LDS footprint allows no second one anyway: the register budget is then 512 per lane instead of 256)
-template <int CY, int CX, int TZ, int MT, bool UNITSPLIT, int RES, bool XG = false, bool XBN = false>
+template <int CY, int CX, int TZ, int MT, bool UNITSPLIT, int RES, bool XG = false>
 __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 ? 1 : 2) void mbwd_kernel(const MbwdK k) {
-  static_assert(!XBN || (!XG && RES == 0 && 256 % (TZ * (CX / 8)) == 0), "XBN: a thread's pieces of an x plane share one channel group");
   constexpr int GH = CY / 8, GP = CX / 8, RSH = TZ * GH, RSP = TZ * GP, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int NTH = CY / 16, NTP = CX / 16;
   constexpr int HSLOTS = ROWS * RSH, PSLOTS = TYB * RSP;
@@ -127,9 +121,8 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
     vrel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) hok |= 1u << u;
   }
-  int prel[PINST], pgrel[(XG || XBN) ? PINST : 1];
+  int prel[PINST], pgrel[XG ? PINST : 1];
   unsigned pok = 0, p1m = 0;
-  int pcx0 = 0;  // XBN: the 8-channel group of this thread's pieces of x
 #pragma unroll
   for (int u = 0; u < PINST; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
@@ -137,8 +130,7 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
     const int pcx = (pp - 2 * (r * RSP / 16)) & (GP - 1);
     const bool ok = j < PSLOTS;
     prel[u] = ok ? (r * Z + z) * k.x_vox_bytes + pcx * 16 : 0;
-    if constexpr (XG || XBN) pgrel[u] = ok ? r * Z + z : 0;
-    if (u == 0) pcx0 = pcx;
+    if constexpr (XG) pgrel[u] = ok ? r * Z + z : 0;
     if (ok) pok |= 1u << u;
     if (ok && pcx >= k.x_csplit_pc) p1m |= 1u << u;
   }
@@ -156,14 +148,6 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
   const char* porg1 = k.x1 + col0 * k.x_vox_bytes;
   const float* pgcol = XG ? k.x_gate + col0 : nullptr;
   float pg[XG ? PINST : 1];
-  float xsc[XBN ? 8 : 1], xsh[XBN ? 8 : 1], xalpha = 0.f;
-  if constexpr (XBN) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { xsc[j] = k.x_sc[pcx0 * 8 + j]; xsh[j] = k.x_sh[pcx0 * 8 + j]; }
-    xalpha = *k.x_alpha;
-  }
-  const unsigned char* xkcol = (XBN && k.x_keep) ? k.x_keep + col0 * GP + pcx0 : nullptr;
-  unsigned xk[XBN ? PINST : 1];
 
   // raw pieces of one dy plane in flight (registers): y, dA (16 bytes each) and the keep-mask byte
   uint4 ry[HINST], rd[HINST], rr2[RES == 2 ? HINST : 1];
@@ -216,10 +200,6 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
 #pragma unroll
       for (int u = 0; u < PINST; ++u) pg[u] = pgcol[pv + pgrel[u]];
     }
-    if constexpr (XBN) {
-#pragma unroll
-      for (int u = 0; u < PINST; ++u) xk[u] = xkcol ? (unsigned)xkcol[(pv + pgrel[u]) * GP] : 0xffu;
-    }
     const char* q = porg + pv * k.x_vox_bytes;
     const char* q1 = porg1 + pv * k.x_vox_bytes;
     char* dst = Pl + (i & 1) * PPLANE;
@@ -242,17 +222,6 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
         o.z = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.z << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.z & 0xffff0000u), gg));
         o.w = f2bf2(vsseg_mul_unpacked(__uint_as_float(qv.w << 16), gg), vsseg_mul_unpacked(__uint_as_float(qv.w & 0xffff0000u), gg));
         *p = o;
-      }
-    }
-    if constexpr (XBN) {  // the preceding block applied to the pieces of x plane i this thread fetched (planes of x are always inside the image)
-      char* dst = Pl + (i & 1) * PPLANE + lane * 16;
-#pragma unroll
-      for (int u = 0; u < PINST; ++u) {
-        if (!((pok >> u) & 1u)) continue;
-        uint4* p = reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024);
-        f8 a;
-        bn_fwd_act8(bf16x8_to_f8(*p), xk[u], xalpha, k.x_inv_keep, xsc, xsh, a);
-        *p = f8_to_bf16x8(a);
       }
     }
   };
@@ -462,26 +431,7 @@ template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch_xg(const
   VSSEG_LAUNCH_CHECK("vsseg_conv_bwd_fused");
   return VSSEG_OK;
 }
-template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch_xbn(const MbwdK& k, int grid, hipStream_t s) {  // x = raw output of the preceding convolution, its block applied on load
-  static bool init = false;
-  const int lds = mb_lds<CY, CX, TZ, MT, 0>();
-  if (lds > 160 * 1024) { vsseg_set_error("vsseg_conv_bwd_fused: %d bytes of LDS", lds); return VSSEG_EINVAL; }
-  if (!init) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&mbwd_kernel<CY, CX, TZ, MT, US, 0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    init = true;
-  }
-  hipLaunchKernelGGL((mbwd_kernel<CY, CX, TZ, MT, US, 0, false, true>), dim3((unsigned)grid), dim3(256), lds, s, k);
-  VSSEG_LAUNCH_CHECK("vsseg_conv_bwd_fused");
-  return VSSEG_OK;
-}
 template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch(const MbwdK& k, int grid, hipStream_t s) {
-  if (k.x_sc) {
-    if constexpr (CY == CX) {
-      if (!k.x_gate && !k.dr) return mb_launch_xbn<CY, CX, TZ, MT, US>(k, grid, s);
-    }
-    vsseg_set_error("vsseg_conv_bwd_fused: the input block (x_bn_*) is instantiated for 16 -> 16 and 32 -> 32 channels without residual convolution / gate");
-    return VSSEG_EINVAL;
-  }
   if (k.x_gate) {
     if constexpr (CX == 64) {
       if (k.dr == k.da && k.dr_vox_bytes == k.da_vox_bytes) return mb_launch_xg<CY, CX, TZ, MT, US>(k, grid, s);
@@ -559,10 +509,6 @@ extern "C" int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream) 
   k.x_gate = d->x_gate;
   k.mean = d->mean; k.invstd = d->invstd; k.gamma = d->gamma; k.scale = d->scale; k.shift = d->shift; k.alpha = d->alpha; k.mean_dz = d->mean_dz; k.mean_dzx = d->mean_dzx;
   k.inv_keep = 1.f / (1.f - d->p_drop);
-  VSSEG_CHECK(!d->x_bn_scale || (d->x_bn_shift && d->x_bn_alpha && !d->x.ptr2 && d->x_bn_p >= 0.f && d->x_bn_p < 1.f && (d->x_bn_p == 0.f || d->x_bn_keep)),
-              "vsseg_conv_bwd_fused: the input block needs scale / shift / alpha (and the keep-mask bytes when p > 0) of a one-part x");
-  k.x_sc = d->x_bn_scale; k.x_sh = d->x_bn_shift; k.x_alpha = d->x_bn_alpha; k.x_keep = d->x_bn_p > 0.f ? d->x_bn_keep : nullptr;
-  k.x_inv_keep = 1.f / (1.f - d->x_bn_p);
   k.wpack = reinterpret_cast<const char*>(d->wpack);
   k.dr = reinterpret_cast<const char*>(d->dres.ptr); k.dr_vox_bytes = d->dres.pitch * 2; k.wpack_r = reinterpret_cast<const char*>(d->wpack_res);
   k.y_vox_bytes = d->y.pitch * 2; k.da_vox_bytes = d->dout.pitch * 2; k.x_vox_bytes = d->x.pitch * 2; k.dx_vox_bytes = d->dx.pitch * 2;

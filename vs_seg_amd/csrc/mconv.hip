@@ -50,18 +50,6 @@ struct MconvK {
   int ps;                 // host side only: a pixel-shuffle launch (template PS)
   // NR > 0: NR more 16-channel tiles of a 1x1x1 convolution of the SAME input ride along (the ResidualUnit's residual convolution,
   // ref:params/networks/blocks/convolutions.py:241-255): only the K-steps of the centre tap, weights in registers, the operand reads shared with the main tiles
-  // BIN (MODE 5): the input is the raw OUTPUT y of the preceding convolution of the same ResidualUnit; its BatchNorm -> Dropout -> PReLU block
-  // (ref:params/networks/blocks/convolutions.py:148-156) is applied on load, in LDS, by the thread that fetched the piece (bn_bwd.h bn_fwd_act8: bit-identical to
-  // vsseg_bn_act_fwd, whose output tensor is then never written or read)
-  const float *in_sc, *in_sh, *in_alpha;  // folded scale / shift [CIN] and PReLU slope of that block
-  const unsigned char* in_keep;           // its keep-mask bytes [voxel][CIN / 8], or nullptr (no dropout)
-  float in_inv_keep;
-  // keep_out: this launch also draws the dropout keep-mask bytes [voxel][cout / 8] of ITS OWN output's block (the bytes vsseg_bn_act_fwd would have stored: same
-  // counter, seed and salt), for the convolution / backward launches that apply that block on load
-  unsigned char* keep_out;
-  uint64_t keep_seed;
-  uint32_t keep_salt;
-  float keep_p;
   const char* wpack_r;   // [KHI - KLO][NR][64 lanes][8]
   const float* bias_r;
   char* res_out;         // its output tensor (bf16), or nullptr: added to the main tiles behind their activation (eval: out = act(bn(conv(x))) + residual(x))
@@ -94,9 +82,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   static_assert(CC == 0 || CIN == 8, "compact inputs are one zero-extended channel group");
   static_assert(!PS || (NT == 4 * TPC && NR == 0 && CC == 0 && (MODE == 0 || MODE == 1 || MODE == 2)), "pixel-shuffle launches: four classes of TPC tiles; plain / statistics / accumulating epilogue");
   constexpr bool C1 = CC != 0;
-  constexpr bool STATS = MODE == 1 || MODE == 4 || MODE == 5, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
-  constexpr bool BIN = MODE == 5;  // statistics + the preceding BatchNorm -> Dropout -> PReLU block applied to the input on load
-  static_assert(!BIN || (!C1 && NR == 0), "BIN reads an ordinary bf16 tensor");
+  constexpr bool STATS = MODE == 1 || MODE == 4, AUXM = MODE == 2, GIN = MODE == 3 || MODE == 4;  // (4: statistics + input gate: the level-1 decoder unit's first convolution)
   constexpr int KLO = CIN / 8, KHI = (5 * (CIN / 8) + 3) / 4, KR = NR ? KHI - KLO : 0;  // K-steps that hold the centre tap's channel groups [4G, 5G)
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
@@ -153,9 +139,8 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   }
 
   // ---- this thread's DMA pieces: LDS slot j = (u*4 + wave)*64 + lane of a plane holds (row j / RS, piece' (j % RS) / TZ, z j % TZ)
-  int rel[NINST], grel[(GIN || BIN) ? NINST : 1];
+  int rel[NINST], grel[GIN ? NINST : 1];
   unsigned okmask = 0, p1mask = 0;
-  int pcb = 0;  // BIN: the 8-channel group of this thread's pieces (256 % RS == 0: the same for all of them)
 #pragma unroll
   for (int u = 0; u < NINST; ++u) {
     const int j = (u * 4 + wave) * 64 + lane;
@@ -164,8 +149,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     const int gy = y0 + r - 1;
     const bool ok = j < PLANE_SLOTS && (unsigned)gy < (unsigned)Y;
     rel[u] = ok ? ((r - 1) * Z + z) * k.in_vox_bytes + (C1 ? 0 : pc * 16) : 0;
-    if constexpr (GIN || BIN) grel[u] = ok ? (r - 1) * Z + z : 0;
-    if (u == 0) pcb = pc;
+    if constexpr (GIN) grel[u] = ok ? (r - 1) * Z + z : 0;
     if (ok) okmask |= 1u << u;
     if (ok && pc >= k.in_csplit_pc) p1mask |= 1u << u;
   }
@@ -238,54 +222,6 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     }
   };
 
-  // BIN: the keep-mask bytes of this thread's pieces of plane i (ordinary loads, in FRONT of the plane's DMAs), and the block applied in place.  Pieces outside the
-  // image stay zero: the convolution pads the ACTIVATED tensor.
-  static_assert(!BIN || 256 % RS == 0, "a thread's pieces of a plane must share one channel group");
-  float bsc[BIN ? 8 : 1], bsh[BIN ? 8 : 1], balpha = 0.f;
-  if constexpr (BIN) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { bsc[j] = k.in_sc[pcb * 8 + j]; bsh[j] = k.in_sh[pcb * 8 + j]; }
-    balpha = *k.in_alpha;
-  }
-  const unsigned char* kcol = (BIN && k.in_keep) ? k.in_keep + col0 * G + pcb : nullptr;
-  auto load_keep = [&](int i, unsigned (&kv)[BIN ? NINST : 1]) {
-    if constexpr (BIN) {
-      const int x = xb - 1 + i;
-      const bool inside = (unsigned)x < (unsigned)X;
-      const int64_t pv = (int64_t)(inside ? x : 0) * Y * Z;
-#pragma unroll
-      for (int u = 0; u < NINST; ++u) kv[u] = kcol ? (unsigned)kcol[(pv + grel[u]) * G] : 0xffu;  // pieces outside the image read a valid byte of the column and are never used
-    }
-  };
-  auto apply_bn = [&](int i, const unsigned (&kv)[BIN ? NINST : 1]) {
-    if constexpr (BIN) {
-      if ((unsigned)(xb - 1 + i) >= (unsigned)X) return;  // a plane outside the image: zeros stay zeros
-      char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES + lane * 16;
-#pragma unroll
-      for (int u = 0; u < NINST; ++u) {
-        if (!((okmask >> u) & 1u)) continue;
-        uint4* p = reinterpret_cast<uint4*>(dst + (u * 4 + wave) * 1024);
-        f8 a;
-        bn_fwd_act8(bf16x8_to_f8(*p), kv[u], balpha, k.in_inv_keep, bsc, bsh, a);
-        *p = f8_to_bf16x8(a);
-      }
-    }
-  };
-
-  // keep_out: the keep-mask bytes of this workgroup's OUTPUT plane i (one Philox call per (voxel, 8-channel group), distributed over the 256 threads)
-  uint64_t kseed = k.keep_seed;
-  uint32_t ksalt = k.keep_salt;
-  if (STATS && k.keep_out) dropout_resolve_seed(kseed, ksalt);
-  auto draw_keep = [&](int i) {
-    const int cgs = cout >> 3, items = TYB * TZ * cgs;
-    const int64_t v0 = col0 + (int64_t)(xb - 1 + i) * Y * Z;
-    for (int it = tid; it < items; it += 256) {
-      const int cg = it % cgs, vz = (it / cgs) % TZ, row = it / (cgs * TZ);
-      const int64_t i8 = (v0 + row * Z + vz) * cgs + cg;
-      k.keep_out[i8] = (unsigned char)dropout_keep8(kseed, ksalt, (uint64_t)i8, k.keep_p);
-    }
-  };
-
   // ---- MFMA operand addressing: K-group p = ks*4 + g -> (tap p / G, piece p % G); lane column l15 -> voxel (row l15 / TZ, z l15 % TZ) of the M-tile
   const int rr = l15 / TZ, zz = l15 % TZ;
   int koff[KSTEPS], dxk[KSTEPS];
@@ -350,10 +286,6 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   load_gate(0, gin0);
   load_gate(1, gin1);
   load_gate(2, gin);
-  unsigned kb0[BIN ? NINST : 1], kb1[BIN ? NINST : 1], kb[BIN ? NINST : 1];
-  load_keep(0, kb0);
-  load_keep(1, kb1);
-  load_keep(2, kb);
   unsigned cv0[C1 ? NINST : 1], cv1[C1 ? NINST : 1], cvn[C1 ? NINST : 1];
   if constexpr (C1) {
     loadc(0, cv0);
@@ -373,21 +305,11 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     apply_gate(1, gin1);
     apply_gate(2, gin);
   }
-  if constexpr (BIN) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    apply_bn(0, kb0);
-    apply_bn(1, kb1);
-    apply_bn(2, kb);
-  }
 
   for (int i = 1; i <= steps; ++i) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of plane i+1 have landed (and the previous step's stores have left)
     if constexpr (GIN) {
       if (i > 1) apply_gate(i + 1, gin);                 // ... and are gated by the thread that fetched them
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if constexpr (BIN) {
-      if (i > 1) apply_bn(i + 1, kb);                    // ... (BIN) or turned into the activated tensor by it
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if constexpr (C1) {
@@ -398,10 +320,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     if (i < steps) load_aux(i + 1, auxn, gaten);         // next step's auxiliary operand, in front of the DMAs
     if (i + 2 <= steps + 1) {
       if constexpr (C1) loadc(i + 2, cvn);
-      else { load_gate(i + 2, gin); load_keep(i + 2, kb); issue(i + 2); }
-    }
-    if constexpr (STATS) {
-      if (k.keep_out) draw_keep(i);
+      else { load_gate(i + 2, gin); issue(i + 2); }
     }
     const int sm1 = ((i - 1) & (MC_NR - 1)) * PLANE_BYTES, s0 = (i & (MC_NR - 1)) * PLANE_BYTES, sp1 = ((i + 1) & (MC_NR - 1)) * PLANE_BYTES;
 
@@ -682,13 +601,6 @@ template <int CIN, int NT, int TZ, int MT> static int mc_launch_psonly(const Mco
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch(const MconvK& k, int grid, hipStream_t s) {
   if (k.ps) return mc_launch_ps<CIN, NT, TZ, MT, WREG>(k, grid, s);
-  if (k.in_sc) {  // the preceding BatchNorm -> Dropout -> PReLU block applied on load: the second convolutions of the level-0 / level-1 encoder units
-    if constexpr ((CIN == 16 && NT == 1) || (CIN == 32 && NT == 2)) {
-      if (k.stats && !k.in_gate && !k.aux_mode) return mc_launch_mode<CIN, NT, TZ, MT, 5, WREG>(k, grid, s);
-    }
-    vsseg_set_error("vsseg_igemm: the input block (in_bn_*) is instantiated for 16 -> 16 and 32 -> 32 channels with the statistics epilogue only");
-    return VSSEG_EINVAL;
-  }
   if (k.in_gate) {
     if constexpr (CIN == 32 && NT == 1) return mc_launch_mode<CIN, NT, TZ, MT, 3, WREG>(k, grid, s);  // the level-0 decoder convolution behind the attention gate
     else { vsseg_set_error("vsseg_igemm: no marching-kernel instantiation with the input gate for this shape"); return VSSEG_EINVAL; }
@@ -730,7 +642,7 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
       if (d->tap_off[t][0] != (t >> 1) || d->tap_off[t][1] != (t & 1) || d->tap_off[t][2] != 0) return no("taps are not the 2x2x1 neighbourhood in (x, y) order");
     if (d->out.c != 16 * tpc || d->cout_mod != 16 * tpc || d->out.ptr2 || d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || d->in.ptr2 || d->in.c != d->ck || d->in.pitch % 8 || ((uintptr_t)d->in.ptr & 15))
       return no("pixel-shuffle launches need a one-part 32 / 48-channel input and a one-part 16 / 32-channel bf16 output (cout_mod = channels)");
-    if (d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || d->in_bn_scale || d->keep_out || (d->accumulate && d->stats)) return no("pixel-shuffle launches support the plain, the statistics and the accumulating epilogue only");
+    if (d->res_mode != VSSEG_RES_NONE || d->in_gate || d->res_tiles || (d->accumulate && d->stats)) return no("pixel-shuffle launches support the plain, the statistics and the accumulating epilogue only");
     const int tz = d->tile[2], tyb = d->tile[1], mt = d->mtw;
     if ((tz != 2 && tz != 4 && tz != 8) || tyb != 64 * mt / tz || d->tile[0] < 1) return no("tile must be (x steps per workgroup, 64 * mtw / tz rows, tz in {2, 4, 8})");
     if (d->q[1] % tyb || d->q[2] % tz) return no("extent is not a multiple of the column block");
@@ -765,9 +677,6 @@ static const McEntry* mc_find(const vsseg_igemm_desc* d, const char** why) {
                        (d->res_out.ptr && (d->res_out.dtype != VSSEG_BF16 || d->res_out.ptr2 || (d->res_out.c & 3) || d->res_out.c > d->res_tiles * 16 || (d->res_out.pitch & 3)))))
     return no("residual tiles need their packed weights, a plain or statistics epilogue and a one-part bf16 output");
   if (d->res_tiles && !d->res_out.ptr && (d->out.dtype != VSSEG_BF16 || (d->out.c & 3))) return no("residual tiles added in the epilogue need a bf16 output");
-  if (d->in_bn_scale && (!d->in_bn_shift || !d->in_bn_alpha || c1 || d->res_tiles || d->in.ptr2 || d->in_bn_p < 0.f || d->in_bn_p >= 1.f || (d->in_bn_p > 0.f && !d->in_bn_keep)))
-    return no("the input block needs scale / shift / alpha (and the keep-mask bytes when p > 0) of a one-part input without residual tiles");
-  if (d->keep_out && (!d->stats || (d->out.c & 7) || d->keep_p <= 0.f || d->keep_p >= 1.f)) return no("keep_out needs the statistics epilogue, output channels in groups of 8 and 0 < keep_p < 1");
   for (const McEntry& e : mc_table)
     if (e.cin == d->ck && e.nt == d->nt && e.tz == tz && e.mt == mt && e.nr == d->res_tiles) {
       if (c1 && !e.fn_c1) return no("no compact-input instantiation for this shape");
@@ -830,9 +739,6 @@ int vsseg_mconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
   k.lx = d->tile[0] > k.X ? k.X : d->tile[0];
   k.nxs = (k.X + k.lx - 1) / k.lx; k.nyb = k.Y / d->tile[1]; k.nzb = k.Z / d->tile[2];
-  k.in_sc = d->in_bn_scale; k.in_sh = d->in_bn_shift; k.in_alpha = d->in_bn_alpha; k.in_keep = d->in_bn_p > 0.f ? d->in_bn_keep : nullptr;
-  k.in_inv_keep = 1.f / (1.f - d->in_bn_p);
-  k.keep_out = d->keep_out; k.keep_seed = d->keep_seed; k.keep_salt = d->keep_salt; k.keep_p = d->keep_p;
   k.wpack_r = reinterpret_cast<const char*>(d->wpack_res); k.bias_r = d->bias_res;
   k.res_out = reinterpret_cast<char*>(d->res_out.ptr); k.res_vox_bytes = d->res_out.pitch * 2;
   k.res_cout = d->res_tiles ? (d->res_out.ptr ? d->res_out.c : d->out.c) : 0;

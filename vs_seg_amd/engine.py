@@ -376,7 +376,7 @@ class Plan:
         key = (f"{p0.kind}|f{ch.fold}|w{ch.wshape}|is{p0.cls.is_}os{p0.cls.os}oo{p0.cls.oo}|q{p0.q}|n{self.n}|es{self.eng.es}|kc{p0.kc}|acc{int(d.accumulate)}|res{int(d.res_mode)}"
                f"|st{int(bool(d.stats))}|two{int(bool(d.inp.ptr2))}{int(bool(d.out.ptr2))}" + ("|gin" if bool(d.in_gate) else "") + ("|cs" if p0.classes is not None else "")
                + (f"|rn{p0.res_tiles}{int(bool(d.res_out.ptr))}" if p0.res_tiles else "") + ("|c1" if (d.inp.c == 1 and p0.kc == 8) else ("|c2" if (d.inp.c == 2 and d.inp.pitch == 2 and p0.kc == 8) else ""))
-               + ("|bin" if bool(d.in_bn_scale) else "") + ("|ko" if bool(d.keep_out) else ""))
+)
         cache = _tune_cache()
         hit = cache.get(key)
         # VSSEG_RETUNE_DEPTHS="-6": launches with a candidate plan of one of these depths are measured again although a choice is cached (how the plans of a
@@ -508,7 +508,7 @@ class Plan:
 
     def _igemm(self, lst, ch: _Choice, inp: L.Tensor, out: L.Tensor, *, bias=0, bias2=0, scale=0, shift=0, alpha=0, act=L.ACT_NONE, res: Optional[L.Tensor] = None,
                res_mode=L.RES_NONE, accumulate=0, stats=0, stats_stride=0, ncls=1, gate=0, nb: Optional[int] = None, in_gate=0, probe=False, res_out: Optional[L.Tensor] = None, bias_res=0,
-               in1=None, in_bn=None, keep=None):
+               in1=None):
         """probe: build the launch (plan chosen / measured as usual) WITHOUT making it part of the step — no packed-weight registration, the descriptor
         is only referenced by `lst` (Plan._use_class_split times two alternative lowerings of an op this way; ch.probe_plan = the plan it used)."""
         nb = self.n if nb is None else nb
@@ -529,10 +529,6 @@ class Plan:
             d.in1, d.in1_w, d.in1_b = in1
         if res_out is not None:
             d.res_out = res_out
-        if in_bn is not None:  # (scale, shift, alpha, keep-mask bytes or None, p) of the BatchNorm -> Dropout -> PReLU block applied to the input on load
-            d.in_bn_scale, d.in_bn_shift, d.in_bn_alpha, d.in_bn_keep, d.in_bn_p = in_bn
-        if keep is not None:   # (bytes, p, seed, salt): the launch draws the keep-mask bytes of the block behind its output
-            d.keep_out, d.keep_p, d.keep_seed, d.keep_salt = keep
         if ch.chosen is not None:  # a further launch of the same lattice class (another sample): same plan, same packed weights
             pl = ch.chosen
         else:
@@ -712,35 +708,6 @@ class Plan:
                     continue
                 self.gate_onload[g.out.name] = g
 
-        # The BatchNorm -> Dropout -> PReLU block BETWEEN the two convolutions of an encoder ResidualUnit of levels 0 / 1 applied ON LOAD (training;
-        # ref:params/networks/blocks/convolutions.py:148-156, 223-236): where the block's output has ONE reader — the unit's second stride-1 3x3x1 convolution, 16 -> 16 or
-        # 32 -> 32 on the marching kernel, whose backward is the fused launch — that convolution (csrc/mconv.hip MODE 5) and its backward (csrc/mbwd.hip XBN) read the RAW
-        # convolution output and apply the block in LDS; the first convolution's launch draws the block's keep-mask bytes (keep_out).  vsseg_bn_act_fwd is not launched
-        # for the block and its output tensor is neither written nor read (forward and backward).
-        self.bn_onload: Dict[str, ConvBnAct] = {}  # name of the never-materialised block output -> the ConvBnAct op that owns the block
-        if self.train and eng.bn_onload and eng.es == 2 and eng.fused_bwd == "1" and (p_drop == 0.0 or eng.keepmask):
-            for a in ops:
-                if not isinstance(a, ConvBnAct) or a.res is not None or a.out.kind != "act" or a.out.base is not None or a.out.name in (prog.logits.name,):
-                    continue
-                readers = [o for o in ops if (isinstance(o, (ConvBnAct, ConvPlain)) and (o.x is a.out or (o.x.parts is not None and a.out in o.x.parts) or o.res is a.out))
-                           or (isinstance(o, AttGate) and (o.x is a.out or (o.x.parts is not None and a.out in o.x.parts)))]
-                if len(readers) != 1 or not isinstance(readers[0], ConvBnAct) or readers[0].x is not a.out or any(t is a.out for t in prog.att_maps):
-                    continue
-                b = readers[0]
-                Lb, cpb, La, cpa = b.layer, self.cplans[b.layer.prefix], a.layer, self.cplans[a.layer.prefix]
-                if (Lb.transposed or tuple(Lb.stride) != (1, 1, 1) or Lb.kernel != (3, 3, 1) or (Lb.cin, Lb.cout) not in ((16, 16), (32, 32)) or len(cpb.fwd) != 1 or cpb.fold_fwd
-                        or Lb.prefix in self.resn or a.out.c != Lb.cin or self.lv[Lb.level] != self.lv[La.out_level]):
-                    continue
-                if not self._march_cands(cpb.fwd[0], Lb) or not P.fused_bwd_tiles(Lb.cout, Lb.cin, self.lv[Lb.level], self.n, eng.fused_scratch().numel(), res=False):
-                    continue
-                if p_drop > 0.0:  # the block's keep-mask bytes are drawn by the first convolution's launch: it has to be a marching one
-                    a_compact = len(cpa.fwd) == 1 and a.x.root.name == prog.input.name and La.prefix not in self.resn and self._compact_choice(cpa.fwd[0], La) is not None
-                    if La.transposed or tuple(La.stride) != (1, 1, 1) or La.kernel != (3, 3, 1) or len(cpa.fwd) != 1 or cpa.fold_fwd or La.cout % 8:
-                        continue
-                    if not (a_compact or La.prefix in self.resn or self._march_cands(cpa.fwd[0], La)):
-                        continue
-                self.bn_onload[a.out.name] = a
-
         # ---- forward
         F = self.fwd
         grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
@@ -751,15 +718,8 @@ class Plan:
                 cc1 = self._compact_choice(cp.fwd[0], Lr) if (len(cp.fwd) == 1 and op.x.root.name == prog.input.name and pre not in self.resn) else None
                 if cc1 is not None:  # the network input as a compact one-channel tensor (marching plans only)
                     cp.fwd[0] = cc1
-                bol = self.bn_onload.get(op.x.name) if self.train else None  # the block in front of this convolution is applied on load: read the raw output of the unit's first convolution
-                own_onload = self.train and op.out.name in self.bn_onload    # this block is applied on load by its reader: no pass of its own, its output tensor does not exist
-                if bol is not None:
-                    xin = self._tdesc(self.bufs["y:" + bol.layer.prefix], Lr.level)
-                    ch0 = cp.fwd[0]
-                    cp.fwd[0] = _Choice([pl for pl in self._march_cands(ch0, Lr)], ch0.woff, wshape=ch0.wshape)  # (marching plans only)
-                else:
-                    xin = self._desc(glu.x) if glu is not None else self._xdesc(op.x, cp.fold_fwd or cc1 is not None)
-                out = None if own_onload else self._desc(op.out)
+                xin = self._desc(glu.x) if glu is not None else self._xdesc(op.x, cp.fold_fwd or cc1 is not None)
+                out = self._desc(op.out)
                 fused_res = plain_by_out[op.res.name] if (op.res is not None and op.res.name in plain_by_out and plain_by_out[op.res.name].layer.prefix in res1_fused) else None
                 res = self._desc(op.res) if (op.res is not None and fused_res is None) else None
                 gam, bet, alp = self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._pp(pre + ".act.weight")
@@ -773,20 +733,10 @@ class Plan:
                     rkw["res_out"] = self._desc(rcv.out)
                 if self.train:
                     yd = self._tdesc(self._raw("y:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
-                    if bol is not None:
-                        bp = bol.layer.prefix
-                        rkw["in_bn"] = (vptr(2, bp), vptr(3, bp), self._pp(bp + ".act.weight"), keep_ptr(bol.layer), p_drop)
-                    if own_onload and p_drop > 0.0:
-                        rkw["keep"] = (keep_ptr(Lr), p_drop, SEED, salt[pre])
-                        if cc1 is None and pre not in self.resn and not all(P.is_march(pl) for pl in cp.fwd[0].cands):
-                            ch0 = cp.fwd[0]
-                            cp.fwd[0] = _Choice(self._march_cands(ch0, Lr), ch0.woff, wshape=ch0.wshape)
                     self._igemm_classes(F, cp.fwd, xin, yd, bias=self._pp(Lr.bkey), stats=sptr(0, pre), stats_stride=cpad[pre], ncls=len(cp.fwd), **rkw)
                     F.append([lib.vsseg_bn_finalize, [sptr(0, pre), cpad[pre], Lr.cout, float(self._vox(Lr.out_level)), gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                                       self._cp(pre + ".norm.num_batches_tracked"), vptr(0, pre), vptr(1, pre), vptr(2, pre), vptr(3, pre)]])
-                    if own_onload:
-                        assert fused_res is None and res is None
-                    elif fused_res is not None:
+                    if fused_res is not None:
                         x1 = self._xdesc(fused_res.x, True)  # compact 1-channel copy of the network input
                         F.append([lib.vsseg_bn_act_fwd_res1, [yd, vptr(2, pre), vptr(3, pre), alp, p_drop, SEED, salt[pre], x1.ptr, self._pp(fused_res.layer.wkey), self._pp(fused_res.layer.bkey), out, keep_ptr(Lr)],
                                   self._ew_meta("bn_act_fwd", Lr.out_level, 2 * Lr.cout + 1)])
@@ -1069,7 +1019,6 @@ class Plan:
             mps = P.march_plans("conv_dgrad", Lr.wshape, cls, self.lv[Lr.level], eng.es, Lr.cout, Lr.cin, Lr.cout, self.n)  # (the packed-weight layout of the data gradient)
             if not tiles or not mps or written.get(x.root.name) or (glx is not None and dres is None):
                 assert glx is None, "a unit behind an attention gate applied on load must run the fused backward with its residual convolution"
-                assert x.name not in self.bn_onload, "a convolution behind a block applied on load must run the fused backward"
                 return False
             assert contribution(x) == 0
             mp = mps[0]
@@ -1077,14 +1026,7 @@ class Plan:
             ch = _Choice([mp], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape))
             self._register(ch, mp)
             d = L.ConvBwdDesc()
-            bol = self.bn_onload.get(x.name)  # x was never materialised: the raw output of the unit's first convolution, its block applied on load
-            if bol is not None:
-                assert glx is None and dres is None
-                bp = bol.layer.prefix
-                d.y, d.dout, d.x, d.dx = yd, dA, self._tdesc(self.bufs["y:" + bp], Lr.level), gdesc(x)
-                d.x_bn_scale, d.x_bn_shift, d.x_bn_alpha, d.x_bn_keep, d.x_bn_p = vptr(2, bp), vptr(3, bp), self._pp(bp + ".act.weight"), keep_ptr(bol.layer), p_drop
-            else:
-                d.y, d.dout, d.x, d.dx = yd, dA, self._desc(glx.x if glx is not None else x), gdesc(x)
+            d.y, d.dout, d.x, d.dx = yd, dA, self._desc(glx.x if glx is not None else x), gdesc(x)
             if glx is not None:
                 d.x_gate = self._alloc(glx.att, self.bufs).data_ptr()
             d.mean, d.invstd, d.gamma, d.scale, d.shift, d.alpha = vptr(0, pre), vptr(1, pre), self._pp(pre + ".norm.weight"), vptr(2, pre), vptr(3, pre), self._pp(pre + ".act.weight")
@@ -1104,7 +1046,7 @@ class Plan:
                 res_tag = f" +res[{'dA' if sink is op else 'unit dA'}]"
             tile, tuned = tiles[0], ""
             if self.tune and len(tiles) > 1:
-                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}" + ("|res" if res_tag else "") + ("|xg" if glx is not None else "") + ("|xbn" if bol is not None else "")
+                key = f"fbwd|w{tuple(Lr.wshape)}|q{self.lv[Lr.level]}|n{self.n}" + ("|res" if res_tag else "") + ("|xg" if glx is not None else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     tile, tuned = tuple(cache[key]), " tuned[cache]"
@@ -1390,11 +1332,6 @@ class Engine:
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
         self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
-        # The block between the two convolutions of the level-0 / level-1 encoder units applied on load (csrc/mconv.hip MODE 5, csrc/mbwd.hip XBN).  OFF by default: measured at the
-        # benchmark shape it removes 0.35 ms of vsseg_bn_act_fwd and adds 0.68 ms to the five launches that take the work over (Philox in the first convolutions +0.17 / +0.15,
-        # the block in the second convolutions' loaders +0.15 / +0.07, in their backward +0.08 / +0.06: all VALU / latency bound), the wall clock of the step is unchanged
-        # (28.79 against 28.87 ms, four alternating pairs on one box) — DESIGN.md §3.9.
-        self.bn_onload = os.environ.get("VSSEG_BN_ONLOAD", "0") == "1" and not dry_run
         # the deep-level kernel (csrc/dconv.hip, plans with depth -7) on the small launches of levels 3-5: "1" = a candidate the tuner measures, "0" = off, "force" = every launch
         # it is offered for runs on it (the untuned lowering then too: how the tests send a whole network through it)
         self.deep = os.environ.get("VSSEG_DEEP", "1")
