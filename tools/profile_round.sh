@@ -16,10 +16,32 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/sfetch -- python $R/tools/profile_eval.py 2 >
 rocprofv3 --pmc WRITE_SIZE -d $OUT/swrite -- python $R/tools/profile_eval.py 2 > $OUT/swrite.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS -d $OUT/sq1 -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq2 -- python $R/bench.py --steps 2 --warmup 1 $TRAIN > $OUT/sq2.log 2>&1
+# the product's DEFAULT schedule (two streams, hipGraph replay of the forward) traced once more for the host-side question: how long is the GPU idle inside a step
+# (tools/trace_gaps.py), and the true start / end of every kernel of one step (tools/step_timeline.py)
+rocprofv3 --kernel-trace -d $OUT/ktd -- python $R/tools/time_step.py 8 > $OUT/ktd.log 2>&1
 cd $R
+python tools/trace_gaps.py $OUT/ktd/*/*.db > $OUT/gaps.txt 2>&1
+python tools/step_timeline.py $OUT/ktd/*/*.db > $OUT/step_timeline.txt 2> /dev/null
+python - "$OUT" <<'PYEOF'
+import json, re, sys
+out = sys.argv[1]
+line = open(out + "/bench.json").read().strip().splitlines()[-1]
+d = json.loads(line)
+m = re.search(r"wall ([\d.]+) ms per step, GPU busy ([\d.]+) ms, idle ([\d.]+) ms in (\d+) gaps", open(out + "/gaps.txt").read())
+if m:
+    d["gpu_idle_in_step"] = dict(wall_ms=float(m.group(1)), busy_ms=float(m.group(2)), idle_ms=float(m.group(3)), idle_share=float(m.group(3)) / float(m.group(1)), gaps_per_step=int(m.group(4)),
+                                 source="rocprofv3 --kernel-trace of tools/time_step.py under the default schedule (two streams, eager backward), union of the kernel intervals: tools/trace_gaps.py")
+open(out + "/bench.json", "w").write(json.dumps(d) + "\n")
+PYEOF
+rm -rf $OUT/ktd
+# BASELINE config 5 at its full case count, once per round (the default bench line carries 8 cases)
+python bench.py --steps 2 --warmup 1 --swi-volumes 0 --fp32-steps 0 --no-cpu-baseline --no-parity --swi-cases 242 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['sharded_cases']))" > $OUT/sharded_242.json
+# what a dependent stage boundary costs (launch / hipGraph node / in-kernel grid barrier) and the deep-level kernel against the other plans, launch by launch
+(tools/probes/chain_probe > $OUT/chain_probe.txt 2>&1 || true)
+(timeout 600 python tools/bench_dconv.py 4 > $OUT/dconv_bench.txt 2>&1 || true)
 python tools/rocprof_summary.py kernel $OUT/kt/*/*.db > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py kernel $OUT/kts/*/*.db > $OUT/swi_kernel_stats.txt
 python tools/rocprof_summary.py pmc $OUT/sfetch/*/*.db $OUT/swrite/*/*.db > $OUT/swi_pmc_hbm.txt
 python tools/rocprof_summary.py sq $OUT/sq1/*/*.db $OUT/sq2/*/*.db > $OUT/pmc_sq.txt
 rm -rf $OUT/kt $OUT/kts $OUT/fetch $OUT/write $OUT/sfetch $OUT/swrite $OUT/sq1 $OUT/sq2
-tail -1 $OUT/bench.json | cut -c1-300; head -14 $OUT/kernel_stats.txt; head -8 $OUT/swi_kernel_stats.txt; head -8 $OUT/pmc_hbm.txt; head -16 $OUT/pmc_sq.txt
+tail -1 $OUT/bench.json | cut -c1-300; head -14 $OUT/kernel_stats.txt; head -8 $OUT/swi_kernel_stats.txt; head -8 $OUT/pmc_hbm.txt; head -16 $OUT/pmc_sq.txt; head -3 $OUT/gaps.txt; cat $OUT/chain_probe.txt; tail -1 $OUT/dconv_bench.txt; cut -c1-300 $OUT/sharded_242.json

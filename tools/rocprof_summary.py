@@ -43,6 +43,9 @@ def bench_name(short_name):
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
     if short_name.startswith("wgrad_narrow_kernel"):
         return "wgrad_narrow"
+    m = re.match(r"dconv_kernel<(\d+), (\d+)>", short_name)  # deep-level kernel: (M-tiles per workgroup, channel tiles per workgroup)
+    if m:
+        return f"dconv<bf16,{m.group(1)},{m.group(2)}>"
     m = re.match(r"(bn_act_fwd|bn_act_bwd_reduce|bn_act_bwd_apply|att_apply_fwd|att_apply_bwd)_kernel<", short_name)  # streaming kernels: bench.py's group names
     if m:
         return m.group(1)
