@@ -247,9 +247,18 @@ class DataParallelTrainer:
         """Returns the loss tensor (device scalar).  `sync` is accepted for symmetry with the reference loop, which reads
         `loss.item()` every step (ref:params/VSparams.py:463); nothing here forces a host read either way."""
         self.opt.zero_grad()
-        outputs = self.model(inputs)
-        loss = self.loss_fn(outputs, labels)
-        loss.backward()
+        # logits and attention maps never leave this function: the loss reads them and its backward has run before the next forward overwrites the plan's buffers, so the
+        # forward may hand out views of them instead of clones (7 device copies, 0.15 ms of a 28 ms step at the benchmark shape)
+        keep = getattr(self.model, "reuse_output_buffers", None)
+        if keep is not None:
+            self.model.reuse_output_buffers = True
+        try:
+            outputs = self.model(inputs)
+            loss = self.loss_fn(outputs, labels)
+            loss.backward()
+        finally:
+            if keep is not None:
+                self.model.reuse_output_buffers = keep
         _, gflat = self.model.flat_parameters()
         allreduce_gradients(gflat)
         if self.world > 1 and not self.fused_mean:
