@@ -108,3 +108,44 @@ def test_window_sharded_inference_matches_single_process(two_rank_results):
 def test_scores_gathered_in_case_order(two_rank_results):
     for r in (0, 1):
         assert two_rank_results[r]["scores"] == [0.0, 10.0, 20.0, 30.0, 40.0, 50.0, 60.0]
+
+
+def _lower_worker(rank, world, port, out, fail, modes):
+    """Engine._lower_rank0_first with a stand-in Plan (no GPU here): what the other ranks do when rank 0 fails while lowering, or runs another VSSEG_AUTOTUNE mode."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), VSSEG_AUTOTUNE=modes[rank])
+    DP.init_distributed("gloo")
+    from vs_seg_amd import engine as E
+
+    class FakePlan:
+        def __init__(self, eng, n, dims, train):
+            if fail and dist.get_rank() == 0:
+                raise MemoryError("out of memory while measuring plans")
+            self.key = (n, tuple(dims), train)
+
+    real = E.Plan
+    E.Plan = FakePlan
+    eng = E.Engine.__new__(E.Engine)
+    eng.dry_run = False
+    try:
+        pl = eng._lower_rank0_first((2, (64, 64, 32), True, 0))
+        out[rank] = ("ok", pl.key)
+    except BaseException as e:  # noqa: BLE001
+        out[rank] = (type(e).__name__, str(e))
+    finally:
+        E.Plan = real
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail,modes", [(True, ("1", "1")), (False, ("1", "0")), (False, ("1", "1"))])
+def test_rank0_lowering_failure_reaches_every_rank(fail, modes):
+    """rank 0 lowers the training plan first and broadcasts its plan choices — if it fails (or the ranks disagree on VSSEG_AUTOTUNE) every rank must
+    raise at once instead of blocking in the broadcast until the collective times out."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_lower_worker, args=(world, port, out, fail, modes), nprocs=world, join=True)
+    if fail:
+        assert out[0][0] == "MemoryError" and out[1][0] == "RuntimeError" and "rank 0 failed while lowering" in out[1][1] and "out of memory" in out[1][1]
+    elif modes[0] != modes[1]:
+        assert out[0][0] == "ok" and out[1][0] == "RuntimeError" and "VSSEG_AUTOTUNE differs" in out[1][1]
+    else:
+        assert out[0] == out[1] == ("ok", (2, (64, 64, 32), True))
