@@ -36,6 +36,10 @@ for arg in sys.argv[1:]:
         vol = torch.randn(1, 1, patch[0] + 64, patch[1] + 64, patch[2] + 16, device=dev)
         for _ in range(3):
             V.sliding_window_inference(vol, tuple(patch), 1, lambda w: model(w)[0], overlap=0.5, mode="gaussian")
+        pred = model.segmentation_predictor()
+        for swb in (2, 4):  # the eval plans of 2 / 4 windows per predictor call (bench.py: sliding_window.sw_batch_size_2 / _4), on both lanes
+            for _ in range(3):
+                V.sliding_window_inference(vol, tuple(patch), swb, pred, overlap=0.5, mode="gaussian")
         for _ in range(4):  # the caller's stream has its own eval plan: lowered and captured before the timed forwards
             model(x)
         torch.cuda.synchronize()

@@ -388,8 +388,9 @@ class Plan:
                     ch.cached = True
                     return pl
         pl = self._autotune(ch, d)
-        cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth]
-        _tune_cache.dirty = True
+        if self.eng.deep == "1":  # (VSSEG_DEEP=0 / force are experiment modes: their restricted candidate lists must not overwrite the measured choices of the full list)
+            cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth]
+            _tune_cache.dirty = True
         return pl
 
     def _autotune(self, ch: _Choice, d: L.IgemmDesc) -> P.IgemmPlan:
@@ -501,8 +502,9 @@ class Plan:
                 best = min(best, e0.elapsed_time(e1))
             times.append(best)
         use = times[1] < times[0]
-        cache[key] = int(use)
-        _tune_cache.dirty = True
+        if self.eng.deep == "1":
+            cache[key] = int(use)
+            _tune_cache.dirty = True
         self.class_split_ms = getattr(self, "class_split_ms", []) + [(key, times)]
         return use
 

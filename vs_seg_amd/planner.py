@@ -557,7 +557,7 @@ def _deep_ok(tile, mt, nt):
     return all(t & (t - 1) == 0 and t <= 128 for t in tile) and tile[0] * tile[1] * tile[2] == 16 * mt and mt * nt <= 40
 
 
-def deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1, in_split=0, limit=6) -> List["IgemmPlan"]:
+def deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1, in_split=0, limit=12) -> List["IgemmPlan"]:
     """The depth -7 candidates: the deep-level kernel (csrc/dconv.hip) on the small bf16 launches — workgroups of 16 * mt lattice voxels x nt channel tiles whose
     four waves split the K-steps, weight fragments straight from L2.  Any lattice class (stride-1, strided, one parity class of a transposed convolution)."""
     nvox = n * q[0] * q[1] * q[2]
@@ -586,7 +586,7 @@ def deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1, in_split=0, limi
                 out.append((tiles * nsplit, pl))
                 got += 1
                 break  # the largest chunk that fits: fewest passes over the K loop
-            if got >= 2:
+            if got >= (4 if tiles < 96 else 2):  # a launch of a few dozen tiles (level 5, an eval window's level 4): also the finer output-channel splits — more workgroups, each streaming a smaller slice of the weights
                 break
     # prefer launches that fill the GPU once (256 CUs), then the larger tiles
     out.sort(key=lambda r: (abs(np.log2(max(r[0], 1) / 256.0)) > 1.5, -r[1].mtw, r[1].nsplit))
