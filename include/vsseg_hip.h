@@ -175,8 +175,37 @@ typedef struct {
 } vsseg_conv_bwd_desc;
 int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
 
+/* Two consecutive stride-1 3x3x1 convolutions of an INFERENCE forward as one launch (csrc/chain.hip; bf16):
+ *   h   = act_a(scale_a * (conv_a(in) + bias_a) + shift_a)                         conv + eval-mode BatchNorm (folded) + PReLU, ref:params/networks/blocks/convolutions.py:114-146
+ *   out = act_b(scale_b * (conv_b(h) + bias_b) + shift_b) [+ in * in1_w + in1_b]
+ * h (cmid channels) lives in LDS only.  The pairs of the sliding-window predictor (ref:params/VSparams.py:553-567): the first ResidualUnit of the encoder, 1 -> 16 -> 16 with the
+ * 1x1x1 residual convolution of the one-channel input added behind the second activation (ref:params/networks/blocks/convolutions.py:241-255), and the attention block of the
+ * finest decoder level, 32 -> 16 -> 1 + sigmoid (ref:params/networks/blocks/attentionblock.py:20-41).  Results are bit-identical to the two vsseg_igemm marching launches
+ * (depth -5) with the same packed weights.  Not applicable in training (the BatchNorm between the two needs the statistics of all of h first). */
+typedef struct {
+  vsseg_tensor in;         /* bf16: a multiple of 8 channels (16-byte aligned voxel rows; may be two-part) or a COMPACT one-channel tensor (c = pitch = 1) standing for one zero-extended group */
+  vsseg_tensor out;        /* same extent; bf16 with a multiple of 4 channels (<= 16), or 1..3 channels bf16 / fp32 (the attention map: c = 1, fp32) */
+  int32_t cmid;            /* channels of h (16) */
+  const void* wpack_a;     /* [K-steps of 9 taps x in channels][cmid / 16][64 lanes][8] bf16: the packed weights of conv_a's marching plan (planner.pack_map, nt = cmid / 16) */
+  const float *bias_a, *scale_a, *shift_a; /* [cmid]; scale_a / shift_a NULL: 1 / 0 */
+  const float* alpha_a;    /* device pointer to the PReLU slope of stage A */
+  int32_t act_a;           /* VSSEG_ACT_NONE | VSSEG_ACT_PRELU | VSSEG_ACT_RELU */
+  const void* wpack_b;     /* [K-steps of 9 taps x cmid][1][64 lanes][8] bf16 */
+  const float *bias_b, *scale_b, *shift_b; /* [out.c] or NULL */
+  const float* alpha_b;
+  int32_t act_b;           /* VSSEG_ACT_* */
+  const float *in1_w, *in1_b; /* [out.c] each or both NULL: + in[voxel] * in1_w[c] + in1_b[c] behind act_b (compact one-channel input only) */
+  int32_t tz;              /* plan: z voxels per workgroup column (1, 2, 4 or 8; in.z a multiple) */
+  int32_t mtw;             /* ... 16-voxel M-tiles per wave: a workgroup owns ALL rows, in.y == waves * mtw * 16 / tz */
+  int32_t lx;              /* ... x positions per workgroup (a segment re-fetches 4 input planes and recomputes 2 planes of h) */
+  int32_t waves;           /* ... waves per workgroup: 4 or 8 */
+  int32_t lead;            /* ... iterations between the fetch of an input plane and its use: 1 (several small workgroups per CU) or 3 (one large one; always 3 for a compact input) */
+} vsseg_chain_desc;
+int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
+int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
+
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------

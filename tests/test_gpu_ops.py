@@ -1027,6 +1027,135 @@ def test_attention_gate_on_load_equals_materialised_gate(dims, split, shape, lx)
     assert torch.equal(dw_gate, dw_mat), float((dw_gate - dw_mat).abs().max())
 
 
+CHAIN_CASES = [
+    # input channels, output channels of the second convolution, dims (Y = waves * mtw * 16 / tz), input split, (tz, mtw), x steps per workgroup, waves, fetch distance
+    (1, 16, (7, 64, 8), 0, (4, 2), 3, 8, 3),      # first ResidualUnit: compact one-channel input, three x segments (3 + 3 + 1)
+    (1, 16, (5, 128, 4), 0, (4, 4), 5, 8, 3),     # ... full benchmark height, one segment
+    (1, 16, (6, 64, 4), 0, (2, 1), 2, 8, 3),
+    (1, 16, (4, 128, 12), 0, (2, 2), 4, 8, 3),    # six z blocks
+    (1, 16, (5, 128, 4), 0, (2, 4), 2, 4, 3),     # four waves
+    (1, 16, (6, 64, 8), 0, (4, 4), 3, 4, 3),
+    (32, 1, (7, 128, 4), 16, (2, 2), 3, 8, 3),    # attention block of the level-0 decoder: two-part (concat) input, fp32 one-channel sigmoid output; one large workgroup per CU
+    (32, 1, (6, 64, 8), 16, (4, 2), 6, 8, 3),
+    (32, 1, (9, 64, 4), 0, (2, 1), 4, 8, 3),      # one-part input, three segments (4 + 4 + 1)
+    (32, 1, (7, 128, 4), 16, (1, 1), 3, 8, 1),    # ... several small workgroups per CU (fetch distance 1): one-voxel columns
+    (32, 1, (5, 128, 4), 16, (1, 2), 5, 4, 1),
+    (32, 1, (6, 128, 4), 0, (2, 4), 2, 4, 1),
+    (32, 1, (6, 128, 4), 16, (2, 2), 6, 8, 1),
+    (32, 1, (8, 64, 4), 16, (1, 1), 4, 4, 1),
+    (32, 1, (5, 64, 4), 0, (2, 2), 5, 4, 1),
+    (32, 1, (5, 64, 8), 0, (2, 1), 3, 8, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,split,shape,lx,waves,lead", CHAIN_CASES)
+def test_chained_marching_convolution_equals_the_two_launches(cin, cout, dims, split, shape, lx, waves, lead):
+    """vsseg_conv_chain (csrc/chain.hip): conv + folded BatchNorm + PReLU -> conv + epilogue as ONE launch with the 16-channel tensor between them in LDS.  Same packed
+    weights, K order, MFMA order and epilogue arithmetic as the two marching launches (depth -5) it replaces: the output must be IDENTICAL bit for bit — across x segments
+    (the halo planes of h are recomputed), z blocks, the image borders (h is zero outside the image, not conv_a of a padded x) — and equal the torch fp64 definition."""
+    lib = L.lib()
+    dt, k, cm = "bf16", (3, 3, 1), 16
+    tz, mtw = shape
+    assert dims[1] == waves * mtw * 16 // tz
+    torch.manual_seed(21)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    wa = _round(torch.randn(cm, cin, *k) / (cin * 9) ** 0.5, dt)
+    wb = _round(torch.randn(cout, cm, *k) / (cm * 9) ** 0.5, dt)
+    ba, bb = torch.randn(cm), torch.randn(cout)
+    res1 = cin == 1
+    sca, sha = (torch.rand(cm) + 0.5, torch.randn(cm) * 0.3) if res1 else (None, None)  # (the attention block's first convolution has no BatchNorm: bias + ReLU)
+    act_a = L.ACT_PRELU if res1 else L.ACT_RELU
+    scb, shb = (torch.rand(cout) + 0.5, torch.randn(cout) * 0.3) if res1 else (None, None)
+    w1, b1 = torch.randn(cout), torch.randn(cout)
+    alpha_a, alpha_b = torch.tensor([0.25], device="cuda"), torch.tensor([0.1], device="cuda")
+    dev = lambda t: t.cuda() if t is not None else None
+    ba_d, bb_d, sca_d, sha_d, scb_d, shb_d, w1_d, b1_d = map(dev, (ba, bb, sca, sha, scb, shb, w1, b1))
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    act_b = L.ACT_PRELU if res1 else L.ACT_SIGMOID
+
+    # torch fp64 definition (h rounded to bf16 like the stored tensor)
+    h = F.conv3d(x.double(), wa.double(), ba.double(), padding=P.same_pad(k))
+    if res1:
+        h = h * sca.double().view(1, -1, 1, 1, 1) + sha.double().view(1, -1, 1, 1, 1)
+    h = torch.where(h > 0, h, (0.25 if res1 else 0.0) * h).float().to(torch.bfloat16).double()
+    y = F.conv3d(h, wb.double(), bb.double(), padding=P.same_pad(k))
+    if res1:
+        y = y * scb.double().view(1, -1, 1, 1, 1) + shb.double().view(1, -1, 1, 1, 1)
+        y = torch.where(y > 0, y, 0.1 * y) + x.double() * w1.double().view(1, -1, 1, 1, 1) + b1.double().view(1, -1, 1, 1, 1)
+    else:
+        y = torch.sigmoid(y)
+
+    # the two marching launches
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+    x_cl = H.to_cl(x, H.DT[dt], cpad=P.round_up(cin, 8))
+    compact = x_cl[..., :1].contiguous() if res1 else None
+    parts = H._split_cl(x_cl, split) if split else None
+    xin = H.tdesc(compact) if res1 else (H.two_part(*parts) if parts else H.tdesc(x_cl))
+
+    def march(w, kc, n_t):
+        kreal, nreal = P.gemm_dims("conv_fwd", tuple(w.shape))
+        got = [pl for pl in P.march_plans("conv_fwd", tuple(w.shape), cls, dims, 2, kc, nreal, kreal, n=2) if pl.depth == -5 and pl.nt == n_t]
+        assert got, "no marching plan"
+        pl = got[0]
+        pl.pack_map = P.pack_map(pl, tuple(w.shape))
+        return pl, H.pack(pl, w, H.DT[dt])
+
+    pa, wpa = march(wa, x_cl.shape[-1], 1)
+    pb, wpb = march(wb, cm, 1)
+    h_cl = torch.zeros(2, *dims, cm, dtype=H.DT[dt], device="cuda")
+    odt = H.DT[dt] if res1 else torch.float32
+    want = torch.zeros(2, *dims, cout, dtype=odt, device="cuda")
+    d1 = H.igemm_desc(pa, wpa, xin, H.tdesc(h_cl), bias=ptr(ba_d), scale=ptr(sca_d), shift=ptr(sha_d), act=act_a, alpha=alpha_a.data_ptr())
+    L.check(lib.vsseg_igemm(C.byref(d1), H.stream()), "igemm A")
+    kw = dict(bias=ptr(bb_d), act=act_b, alpha=alpha_b.data_ptr())
+    if res1:
+        kw.update(scale=ptr(scb_d), shift=ptr(shb_d), res_mode=L.RES_IN1, in1=compact.data_ptr(), in1_w=ptr(w1_d), in1_b=ptr(b1_d))
+    d2 = H.igemm_desc(pb, wpb, H.tdesc(h_cl), H.tdesc(want), **kw)
+    L.check(lib.vsseg_igemm(C.byref(d2), H.stream()), "igemm B")
+
+    # ... and the chain
+    got = torch.full((2, *dims, cout), float("nan"), dtype=odt, device="cuda")
+    d = L.ChainDesc()
+    d.inp, d.out, d.cmid = xin, H.tdesc(got), cm
+    d.wpack_a, d.bias_a, d.scale_a, d.shift_a, d.alpha_a, d.act_a = wpa.data_ptr(), ptr(ba_d), ptr(sca_d), ptr(sha_d), alpha_a.data_ptr(), act_a
+    d.wpack_b, d.bias_b, d.scale_b, d.shift_b, d.alpha_b, d.act_b = wpb.data_ptr(), ptr(bb_d), ptr(scb_d), ptr(shb_d), alpha_b.data_ptr(), act_b
+    if res1:
+        d.in1_w, d.in1_b = ptr(w1_d), ptr(b1_d)
+    d.tz, d.mtw, d.lx, d.waves, d.lead = tz, mtw, lx, waves, lead
+    assert lib.vsseg_conv_chain_lds_bytes(C.byref(d)) > 0, lib.vsseg_last_error()
+    L.check(lib.vsseg_conv_chain(C.byref(d), H.stream()), "conv_chain")
+    torch.cuda.synchronize()
+    assert not torch.isnan(got.float()).any()
+    assert torch.equal(got, want), f"chain differs from the two launches (max {float((got.float() - want.float()).abs().max())})"
+    np.testing.assert_allclose(H.from_cl(got).numpy(), y.float().numpy(), atol=_tol(dt, y) if res1 else 2e-3)
+    got2 = torch.full_like(got, float("nan"))
+    d.out = H.tdesc(got2)
+    L.check(lib.vsseg_conv_chain(C.byref(d), H.stream()), "conv_chain")
+    torch.cuda.synchronize()
+    assert torch.equal(got, got2)  # run-to-run
+
+
+def test_chained_marching_convolution_rejects_what_it_does_not_cover():
+    lib = L.lib()
+    x = torch.zeros(1, 4, 64, 4, 32, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 4, 64, 4, 1, dtype=torch.float32, device="cuda")
+    w = torch.zeros(16 * 1024, dtype=torch.bfloat16, device="cuda")
+
+    def desc(**kw):
+        d = L.ChainDesc()
+        d.inp, d.out, d.cmid, d.wpack_a, d.wpack_b, d.act_b, d.tz, d.mtw, d.lx, d.waves, d.lead = H.tdesc(x), H.tdesc(out), 16, w.data_ptr(), w.data_ptr(), L.ACT_SIGMOID, 2, 1, 4, 8, 3
+        for k_, v in kw.items():
+            setattr(d, k_, v)
+        return d
+
+    assert lib.vsseg_conv_chain_lds_bytes(C.byref(desc())) > 0
+    for bad in (dict(tz=4), dict(mtw=2), dict(cmid=32), dict(lx=0), dict(waves=6), dict(lead=2), dict(wpack_b=None), dict(in1_w=w.data_ptr()), dict(scale_b=w.data_ptr()), dict(act_b=7), dict(act_a=L.ACT_SIGMOID)):
+        assert lib.vsseg_conv_chain(C.byref(desc(**bad)), H.stream()) == L.EINVAL, bad
+        assert b"vsseg_conv_chain" in lib.vsseg_last_error()
+    f32_in = torch.zeros(1, 4, 64, 4, 32, dtype=torch.float32, device="cuda")
+    assert lib.vsseg_conv_chain(C.byref(desc(inp=H.tdesc(f32_in))), H.stream()) == L.EINVAL
+
+
 COMPUTE_CASES = [
     # kind, cin, cout, dims, input split
     ("conv_fwd", 32, 48, (8, 16, 32), 0),     # every tile touches the border

@@ -43,6 +43,9 @@ def bench_name(short_name):
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
     if short_name.startswith("wgrad_narrow_kernel"):
         return "wgrad_narrow"
+    m = re.match(r"chain_kernel<(\d+),", short_name)  # chained marching convolution (inference): input channels of its first stage
+    if m:
+        return f"chain<bf16,{m.group(1)}>"
     m = re.match(r"dconv_kernel<(\d+), (\d+)>", short_name)  # deep-level kernel: (M-tiles per workgroup, channel tiles per workgroup)
     if m:
         return f"dconv<bf16,{m.group(1)},{m.group(2)}>"

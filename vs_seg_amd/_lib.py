@@ -139,9 +139,36 @@ class ConvBwdDesc(C.Structure):
     ]
 
 
+class ChainDesc(C.Structure):  # vsseg_chain_desc
+    _fields_ = [
+        ("inp", Tensor),
+        ("out", Tensor),
+        ("cmid", C.c_int32),
+        ("wpack_a", C.c_void_p),
+        ("bias_a", C.c_void_p),
+        ("scale_a", C.c_void_p),
+        ("shift_a", C.c_void_p),
+        ("alpha_a", C.c_void_p),
+        ("act_a", C.c_int32),
+        ("wpack_b", C.c_void_p),
+        ("bias_b", C.c_void_p),
+        ("scale_b", C.c_void_p),
+        ("shift_b", C.c_void_p),
+        ("alpha_b", C.c_void_p),
+        ("act_b", C.c_int32),
+        ("in1_w", C.c_void_p),
+        ("in1_b", C.c_void_p),
+        ("tz", C.c_int32),
+        ("mtw", C.c_int32),
+        ("lx", C.c_int32),
+        ("waves", C.c_int32),
+        ("lead", C.c_int32),
+    ]
+
+
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_wgrad", "vsseg_conv_bwd_fused", "vsseg_wgrad_narrow", "vsseg_wgrad_narrow_bn", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_conv_chain", "vsseg_conv_chain_lds_bytes", "vsseg_wgrad", "vsseg_conv_bwd_fused", "vsseg_wgrad_narrow", "vsseg_wgrad_narrow_bn", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -173,6 +200,8 @@ def lib():
         L.vsseg_normalize_intensity.argtypes = [vp, vp, i64, vp, vp]
         L.vsseg_igemm.argtypes = [C.POINTER(IgemmDesc), vp]
         L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
+        L.vsseg_conv_chain.argtypes = [C.POINTER(ChainDesc), vp]
+        L.vsseg_conv_chain_lds_bytes.argtypes = [C.POINTER(ChainDesc)]
         L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
         L.vsseg_conv_bwd_fused.argtypes = [C.POINTER(ConvBwdDesc), vp]
         L.vsseg_wgrad_narrow.argtypes = [Tensor, vp, i32, i32, vp, C.c_int64, vp, vp, C.c_int64, vp]

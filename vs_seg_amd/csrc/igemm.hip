@@ -5,6 +5,7 @@
 #include "cconv.h"
 #include "mconv.h"
 #include "dconv.h"
+#include "chain.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
   const vsseg_igemm_desc& d = k.d;
@@ -92,6 +93,8 @@ static const void* zero_page() {
   }
   return z;
 }
+
+const void* vsseg_zero_page() { return zero_page(); }  // (chain.hip)
 
 static int igemm_prepare(const vsseg_igemm_desc* d, IgemmK& k) {
   VSSEG_CHECK(d && d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");

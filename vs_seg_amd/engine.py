@@ -210,6 +210,7 @@ class Plan:
         self._map_len = 0
         self._wpack_fixups: list = []  # (descriptor, element offset): wpack is allocated after every launch chose its plan
         self._res_fixups: list = []  # ... the same for the `wpack_res` field of the fused backward launches
+        self._chain_fixups: list = []  # ... (descriptor, field, element offset) of the chained launches' two packed-weight pointers
         # Autotune (default on a GPU): every launch measures its candidate plans on the real buffers at lowering time and keeps
         # the fastest.  VSSEG_AUTOTUNE=0 keeps the heuristic plan (deterministic; what the CPU dry-run lowering always uses).
         self.tune = (not eng.dry_run) and os.environ.get("VSSEG_AUTOTUNE", "1") != "0"
@@ -348,7 +349,9 @@ class Plan:
             d.wpack = self.wpack.data_ptr() + eng.es * off
         for d, off in self._res_fixups:
             d.wpack_res = self.wpack.data_ptr() + eng.es * off
-        del self._maps, self._maps2, self._wpack_fixups, self._res_fixups
+        for d, attr, off in self._chain_fixups:
+            setattr(d, attr, self.wpack.data_ptr() + eng.es * off)
+        del self._maps, self._maps2, self._wpack_fixups, self._res_fixups, self._chain_fixups
         self._tune_gflat = None
         _tune_cache_save()
 
@@ -710,10 +713,85 @@ class Plan:
                     continue
                 self.gate_onload[g.out.name] = g
 
+        # Chained marching convolutions (csrc/chain.hip, vsseg_conv_chain; inference only): two consecutive stride-1 3x3x1 convolutions whose intermediate 16-channel tensor has
+        # no other reader run as ONE launch with that tensor in LDS — the first ResidualUnit of the encoder (1 -> 16 -> 16 with the residual convolution of the network input in
+        # the second epilogue) and the attention block of the finest decoder level (32 -> 16 + ReLU -> 1 + sigmoid).  201 MB per patch are neither written nor read back, per pair.
+        self.chain_first: Dict[str, tuple] = {}  # prefix of the first convolution -> (first op, second op, plan)
+        self.chain_second: set = set()           # prefixes of the second convolutions: emitted with the first
+        if not self.train and eng.chain and eng.es == 2 and not eng.dry_run:
+            def march3(Lr):
+                return not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1)
+            for a in ops:
+                if not isinstance(a, (ConvBnAct, ConvPlain)) or not march3(a.layer) or a.layer.cout != 16 or a.res is not None or a.x.base is not None or a.out.base is not None:
+                    continue
+                pa_ = a.layer.prefix
+                if pa_ in self.resn or pa_ in self.merged or pa_ in self.absorbs or pa_ in self.resn_of or a.x.name in self.gate_onload:
+                    continue
+                readers = [o for o in ops if o is not a and ((getattr(o, "x", None) is a.out) or (getattr(getattr(o, "x", None), "parts", None) is not None and a.out in o.x.parts)
+                                                             or getattr(o, "res", None) is a.out or getattr(o, "att", None) is a.out)]
+                if len(readers) != 1 or not isinstance(readers[0], type(a)) or readers[0].x is not a.out:
+                    continue
+                b = readers[0]
+                pb_ = b.layer.prefix
+                if not march3(b.layer) or b.layer.cin != 16 or pb_ in self.resn or pb_ in self.merged or pb_ in self.absorbs or b.out.base is not None or a.out in (prog.logits, *prog.att_maps):
+                    continue
+                if isinstance(a, ConvBnAct):  # the first ResidualUnit: compact network input, the unit's residual convolution already folded into the second epilogue (eval_in1)
+                    ok = a.x.root.name == prog.input.name and a.x.real == 1 and eng.compact_c1 and b.layer.cout == 16 and pb_ in self.eval_in1 and b.res is not None
+                    compact, cin = True, 8
+                else:  # the attention block: conv + ReLU -> conv + sigmoid -> the fp32 attention map
+                    ok = a.act == "relu" and b.act == "sigmoid" and b.layer.cout == 1 and b.res is None and b.out.kind == "f32" and a.layer.cin == 32 and (a.x.parts is None or a.x.parts[0].c % 16 == 0)
+                    compact, cin = False, a.layer.cin
+                plan_c = P.chain_plan(cin, compact, self.lv[a.layer.level], self.n) if ok else None
+                if plan_c is None:
+                    continue
+                self.chain_first[pa_] = (a, b, plan_c)
+                self.chain_second.add(pb_)
+
+        def chain_launch(a, b, plan_c):
+            La, Lb = a.layer, b.layer
+            q = self.lv[La.level]
+            d = L.ChainDesc()
+            compact = isinstance(a, ConvBnAct)
+            d.inp, d.out, d.cmid = (self._xdesc(a.x, True) if compact else self._desc(a.x)), self._desc(b.out), 16
+            d.bias_a, d.bias_b = self._pp(La.bkey), self._pp(Lb.bkey)
+            if compact:
+                for Lr in (La, Lb):
+                    pre = Lr.prefix
+                    self.fwd_pre.append([lib.vsseg_bn_fold_eval, [self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var"), BN_EPS,
+                                                                  vptr(2, pre), vptr(3, pre), Lr.cout]])
+                d.scale_a, d.shift_a, d.alpha_a, d.act_a = vptr(2, La.prefix), vptr(3, La.prefix), self._pp(La.prefix + ".act.weight"), L.ACT_PRELU
+                d.scale_b, d.shift_b, d.alpha_b, d.act_b = vptr(2, Lb.prefix), vptr(3, Lb.prefix), self._pp(Lb.prefix + ".act.weight"), L.ACT_PRELU
+                pr1 = self.eval_in1[Lb.prefix]
+                d.in1_w, d.in1_b = self._pp(pr1.layer.wkey), self._pp(pr1.layer.bkey)
+            else:
+                d.act_a, d.act_b = L.ACT_RELU, L.ACT_SIGMOID
+            d.tz, d.mtw, d.lx, d.waves, d.lead = plan_c["tz"], plan_c["mtw"], plan_c["lx"], plan_c["waves"], plan_c["lead"]
+            for attr, Lr, kc in (("wpack_a", La, 8 if compact else La.cin), ("wpack_b", Lb, 16)):
+                pl = P.chain_pack_plan(tuple(Lr.wshape), q, eng.es, kc, self.n)
+                assert pl is not None, "no marching pack layout for a chained convolution"
+                ch = _Choice([pl], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape))
+                self._register(ch, pl)
+                self._chain_fixups.append((d, attr, ch.map_off))
+            dummy = torch.zeros(16, dtype=eng.tdtype, device=dev)
+            d.wpack_a = d.wpack_b = dummy.data_ptr()  # (placeholders for the domain check; the real pointers are set once the packed-weight buffer exists)
+            if lib.vsseg_conv_chain_lds_bytes(C.byref(d)) < 0:
+                raise RuntimeError("vsseg_conv_chain rejected a launch the planner offered: " + lib.vsseg_last_error().decode())
+            self.keep.append(d)
+            nvox = float(self.n) * q[0] * q[1] * q[2]
+            cin_r = a.x.real
+            F.append([lib.vsseg_conv_chain, [C.byref(d)], dict(tag=f"chain q={q} K={cin_r}x9 -> 16x9 -> N={Lb.cout} tz={plan_c['tz']} waves={plan_c['waves']} mtw={plan_c['mtw']} lead={plan_c['lead']} lx={plan_c['lx']}",
+                                                               name=f"chain<bf16,{8 if compact else La.cin}>", kind="mfma", flops=2.0 * nvox * 9 * (cin_r * 16 + 16 * Lb.cout),
+                                                               bytes=nvox * (cin_r * eng.es + Lb.cout * (4 if b.out.kind == "f32" else eng.es)))])
+
         # ---- forward
         F = self.fwd
         grad_alias: Dict[str, TensorSpec] = {}  # residual-conv output -> the tensor it is added into (shares its gradient)
         for op in ops:
+            if isinstance(op, (ConvBnAct, ConvPlain)) and op.layer.prefix in self.chain_second:
+                continue
+            if isinstance(op, (ConvBnAct, ConvPlain)) and op.layer.prefix in self.chain_first:
+                chain_launch(*self.chain_first[op.layer.prefix])
+                continue
             if isinstance(op, ConvBnAct):
                 Lr, cp, pre = op.layer, self.cplans[op.layer.prefix], op.layer.prefix
                 glu = self.gate_onload.get(op.x.name)  # the attention gate in front of the unit is applied on load: read x (the concat) and the attention map
@@ -1332,6 +1410,7 @@ class Engine:
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
+        self.chain = os.environ.get("VSSEG_CHAIN", "1") != "0"  # inference: pairs of 3x3x1 convolutions as one launch, the tensor between them in LDS (csrc/chain.hip)
         self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
         # the deep-level kernel (csrc/dconv.hip, plans with depth -7) on the small launches of levels 3-5: "1" = a candidate the tuner measures, "0" = off, "force" = every launch
