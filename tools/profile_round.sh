@@ -39,6 +39,7 @@ python bench.py --steps 2 --warmup 1 --swi-volumes 0 --fp32-steps 0 --no-cpu-bas
 # what a dependent stage boundary costs (launch / hipGraph node / in-kernel grid barrier) and the deep-level kernel against the other plans, launch by launch
 (tools/probes/chain_probe > $OUT/chain_probe.txt 2>&1 || true)
 (timeout 600 python tools/bench_dconv.py 4 > $OUT/dconv_bench.txt 2>&1 || true)
+(timeout 300 python tools/bench_chain.py 1 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt || true)
 python tools/rocprof_summary.py kernel $OUT/kt/*/*.db > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py kernel $OUT/kts/*/*.db > $OUT/swi_kernel_stats.txt
 python tools/rocprof_summary.py pmc $OUT/sfetch/*/*.db $OUT/swrite/*/*.db > $OUT/swi_pmc_hbm.txt
