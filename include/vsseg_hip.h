@@ -184,17 +184,21 @@ int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
  * (depth -5) with the same packed weights.  Not applicable in training (the BatchNorm between the two needs the statistics of all of h first). */
 typedef struct {
   vsseg_tensor in;         /* bf16: a multiple of 8 channels (16-byte aligned voxel rows; may be two-part) or a COMPACT one-channel tensor (c = pitch = 1) standing for one zero-extended group */
-  vsseg_tensor out;        /* same extent; bf16 with a multiple of 4 channels (<= 16), or 1..3 channels bf16 / fp32 (the attention map: c = 1, fp32) */
-  int32_t cmid;            /* channels of h (16) */
+  vsseg_tensor out;        /* same extent; bf16 with a multiple of 4 channels (<= 32), or 1..3 channels bf16 / fp32 (the attention map: c = 1, fp32) */
+  int32_t cmid;            /* channels of h (16 or 32) */
   const void* wpack_a;     /* [K-steps of 9 taps x in channels][cmid / 16][64 lanes][8] bf16: the packed weights of conv_a's marching plan (planner.pack_map, nt = cmid / 16) */
   const float *bias_a, *scale_a, *shift_a; /* [cmid]; scale_a / shift_a NULL: 1 / 0 */
   const float* alpha_a;    /* device pointer to the PReLU slope of stage A */
   int32_t act_a;           /* VSSEG_ACT_NONE | VSSEG_ACT_PRELU | VSSEG_ACT_RELU */
-  const void* wpack_b;     /* [K-steps of 9 taps x cmid][1][64 lanes][8] bf16 */
+  const void* wpack_b;     /* [K-steps of 9 taps x cmid][ceil(out.c / 16)][64 lanes][8] bf16 */
   const float *bias_b, *scale_b, *shift_b; /* [out.c] or NULL */
   const float* alpha_b;
   int32_t act_b;           /* VSSEG_ACT_* */
   const float *in1_w, *in1_b; /* [out.c] each or both NULL: + in[voxel] * in1_w[c] + in1_b[c] behind act_b (compact one-channel input only) */
+  int32_t res_tiles;       /* 0, or ceil(out.c / 16): + bf16(residual(in) + bias_res) behind act_b, residual = a 1x1x1 convolution of `in` (the ResidualUnit's residual convolution,
+                            * ref:params/networks/blocks/convolutions.py:241-255; ordinary multi-channel input only) */
+  const void* wpack_res;   /* [K-steps of conv_a's centre tap][res_tiles][64 lanes][8] bf16 (planner.residual_tile_pack_map) */
+  const float* bias_res;   /* [out.c] or NULL */
   int32_t tz;              /* plan: z voxels per workgroup column (1, 2, 4 or 8; in.z a multiple) */
   int32_t mtw;             /* ... 16-voxel M-tiles per wave: a workgroup owns ALL rows, in.y == waves * mtw * 16 / tz */
   int32_t lx;              /* ... x positions per workgroup (a segment re-fetches 4 input planes and recomputes 2 planes of h) */

@@ -1135,6 +1135,65 @@ def test_chained_marching_convolution_equals_the_two_launches(cin, cout, dims, s
     assert torch.equal(got, got2)  # run-to-run
 
 
+@pytest.mark.parametrize("dims,shape,lx", [((7, 64, 8), (2, 1), 3), ((6, 64, 8), (4, 2), 6), ((5, 128, 4), (2, 2), 2)])
+def test_chained_marching_convolution_with_residual_tiles(dims, shape, lx):
+    """The two-sub-unit ResidualUnit of level 1 in inference (ref:params/networks/blocks/convolutions.py:241-255): 16 -> 32 (folded BatchNorm + PReLU) -> 32 (the same) + the
+    1x1x1 residual convolution 16 -> 32 of the unit's input, as ONE vsseg_conv_chain launch: stage B multiplies the centre-tap K-step of the input plane it is about to overwrite
+    with the residual weights and adds the bf16-rounded result behind its activation.  Bit-identical to the three launches (convolution, residual convolution, convolution + add)."""
+    lib = L.lib()
+    dt, k, cin, cm, cout = "bf16", (3, 3, 1), 16, 32, 32
+    tz, mtw = shape
+    assert dims[1] == 8 * mtw * 16 // tz
+    torch.manual_seed(33)
+    x = _round(torch.randn(2, cin, *dims), dt)
+    wa = _round(torch.randn(cm, cin, *k) / (cin * 9) ** 0.5, dt)
+    wb = _round(torch.randn(cout, cm, *k) / (cm * 9) ** 0.5, dt)
+    wr = _round(torch.randn(cout, cin, 1, 1, 1) / cin ** 0.5, dt)
+    vec = lambda n_, s_=1.0: (torch.randn(n_) * s_).cuda()
+    ba, bb, br, sha, shb = vec(cm), vec(cout), vec(cout), vec(cm, 0.3), vec(cout, 0.3)
+    sca, scb = (torch.rand(cm) + 0.5).cuda(), (torch.rand(cout) + 0.5).cuda()
+    al_a, al_b = torch.tensor([0.25], device="cuda"), torch.tensor([0.1], device="cuda")
+    x_cl = H.to_cl(x, H.DT[dt])
+    cls = P.lattice_classes("conv_fwd", k, (1, 1, 1))[0]
+
+    def march(w, kc, nt):
+        kreal, nreal = P.gemm_dims("conv_fwd", tuple(w.shape))
+        pl = [p_ for p_ in P.march_plans("conv_fwd", tuple(w.shape), cls, dims, 2, kc, nreal, kreal, n=2) if p_.depth == -5 and p_.nt == nt][0]
+        pl.pack_map = P.pack_map(pl, tuple(w.shape))
+        return pl, H.pack(pl, w, H.DT[dt])
+
+    pa, wpa = march(wa, cin, 2)
+    pb, wpb = march(wb, cm, 2)
+    h_cl = torch.zeros(2, *dims, cm, dtype=H.DT[dt], device="cuda")
+    r_cl = torch.zeros(2, *dims, cout, dtype=H.DT[dt], device="cuda")
+    want = torch.zeros(2, *dims, cout, dtype=H.DT[dt], device="cuda")
+    L.check(lib.vsseg_igemm(C.byref(H.igemm_desc(pa, wpa, H.tdesc(x_cl), H.tdesc(h_cl), bias=ba.data_ptr(), scale=sca.data_ptr(), shift=sha.data_ptr(), act=L.ACT_PRELU, alpha=al_a.data_ptr())), H.stream()), "A")
+    H.run_lattice_op("conv_fwd", wr, x_cl, r_cl, (1, 1, 1), bias=br.data_ptr())
+    L.check(lib.vsseg_igemm(C.byref(H.igemm_desc(pb, wpb, H.tdesc(h_cl), H.tdesc(want), bias=bb.data_ptr(), scale=scb.data_ptr(), shift=shb.data_ptr(), act=L.ACT_PRELU, alpha=al_b.data_ptr(),
+                                                  res=H.tdesc(r_cl), res_mode=L.RES_ADD)), H.stream()), "B")
+    rmap = torch.from_numpy(P.residual_tile_pack_map(cin, 2, tuple(wr.shape))).cuda()
+    wflat = wr.reshape(-1).to(H.DT[dt]).cuda()
+    wpr = torch.where(rmap >= 0, wflat[rmap.clamp(min=0).long()], torch.zeros((), dtype=H.DT[dt], device="cuda"))
+    got = torch.full((2, *dims, cout), float("nan"), dtype=H.DT[dt], device="cuda")
+    d = L.ChainDesc()
+    d.inp, d.out, d.cmid = H.tdesc(x_cl), H.tdesc(got), cm
+    d.wpack_a, d.bias_a, d.scale_a, d.shift_a, d.alpha_a, d.act_a = wpa.data_ptr(), ba.data_ptr(), sca.data_ptr(), sha.data_ptr(), al_a.data_ptr(), L.ACT_PRELU
+    d.wpack_b, d.bias_b, d.scale_b, d.shift_b, d.alpha_b, d.act_b = wpb.data_ptr(), bb.data_ptr(), scb.data_ptr(), shb.data_ptr(), al_b.data_ptr(), L.ACT_PRELU
+    d.res_tiles, d.wpack_res, d.bias_res = 2, wpr.data_ptr(), br.data_ptr()
+    d.tz, d.mtw, d.lx, d.waves, d.lead = tz, mtw, lx, 8, 1
+    assert lib.vsseg_conv_chain_lds_bytes(C.byref(d)) > 0, lib.vsseg_last_error()
+    L.check(lib.vsseg_conv_chain(C.byref(d), H.stream()), "conv_chain")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want), f"chain differs from the three launches (max {float((got.float() - want.float()).abs().max())})"
+    # the definition in fp64 (h and the residual rounded to bf16 like the stored tensors)
+    pre = lambda v: v.double().cpu().view(1, -1, 1, 1, 1)
+    h = F.conv3d(x.double(), wa.double(), ba.double().cpu(), padding=P.same_pad(k)) * pre(sca) + pre(sha)
+    h = torch.where(h > 0, h, 0.25 * h).float().to(torch.bfloat16).double()
+    y = F.conv3d(h, wb.double(), bb.double().cpu(), padding=P.same_pad(k)) * pre(scb) + pre(shb)
+    y = torch.where(y > 0, y, 0.1 * y) + F.conv3d(x.double(), wr.double(), br.double().cpu()).float().to(torch.bfloat16).double()
+    np.testing.assert_allclose(H.from_cl(got).numpy(), y.float().numpy(), atol=_tol(dt, y))
+
+
 def test_chained_marching_convolution_rejects_what_it_does_not_cover():
     lib = L.lib()
     x = torch.zeros(1, 4, 64, 4, 32, dtype=torch.bfloat16, device="cuda")

@@ -158,6 +158,9 @@ class ChainDesc(C.Structure):  # vsseg_chain_desc
         ("act_b", C.c_int32),
         ("in1_w", C.c_void_p),
         ("in1_b", C.c_void_p),
+        ("res_tiles", C.c_int32),
+        ("wpack_res", C.c_void_p),
+        ("bias_res", C.c_void_p),
         ("tz", C.c_int32),
         ("mtw", C.c_int32),
         ("lx", C.c_int32),

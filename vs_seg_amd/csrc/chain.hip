@@ -31,6 +31,8 @@ struct ChainK {
   const float *bias_b, *scale_b, *shift_b, *alpha_b;
   int act_a, act_b;
   const float *in1_w, *in1_b;
+  const char* wres;      // NR > 0: packed weights [K-steps of the centre tap][NR][64][8] of a 1x1x1 convolution of the INPUT (the ResidualUnit's residual convolution) ...
+  const float* bias_r;   // ... and its bias: out += bf16(residual(in) + bias_r) behind stage B's activation
   const void* zeros;
   int X, Y, Z, lx, nxs, nzb;
 };
@@ -44,8 +46,10 @@ template <int G> __device__ __forceinline__ int ch_mod(int v) {
 // TZ: z voxels per column, CH_NW waves per workgroup with MT 16-voxel M-tiles each: Y = CH_NW * MT * 16 / TZ rows; LEAD: iterations between the fetch of an input plane and
 // its first use (1: the next plane is in flight while this one is multiplied, as in mconv.hip — several small workgroups per CU cover the latency for each other;
 // 3: one large workgroup per CU covers it with the depth of its own ring)
-template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int CH_NW, int LEAD>
+template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int CH_NW, int LEAD, int NR>
 __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
+  constexpr bool RES = NR > 0;
+  static_assert(!RES || (CC == 0 && NR == NTB), "residual tiles: one per output tile of stage B, ordinary input");
   constexpr int CH_THREADS = CH_NW * 64;
   constexpr bool C1 = CC != 0;
   static_assert(LEAD == 1 || LEAD == 3, "fetch distance");
@@ -58,8 +62,9 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
   constexpr int NIA = (WIA + CH_NW - 1) / CH_NW;  // ... per wave: NIA for waves < WFULL, NIA - 1 for the others
   constexpr int WFULL = WIA - (NIA - 1) * CH_NW;
   constexpr int PA_BYTES = WIA * 1024, PB_BYTES = (SLOTS_B * 16 + 255) / 256 * 256;
-  constexpr int RING = C1 ? 5 : 3 + LEAD;         // input planes s-3 (compact: the residual operand of output plane s-3) / s-2 .. s in LDS, (DMA) s+1 .. s+LEAD in flight / being issued
+  constexpr int RING = C1 ? 5 : 3 + LEAD + (RES ? 1 : 0);         // input planes s-3 (compact: the residual operand of output plane s-3) / s-2 .. s in LDS, (DMA) s+1 .. s+LEAD in flight / being issued
   constexpr int KSA = (9 * GA + 3) / 4, KSB = (9 * GB + 3) / 4;
+  constexpr int KLO = GA, KHI = (5 * GA + 3) / 4, KR = RES ? KHI - KLO : 0;  // K-steps of stage A's K order that hold the centre tap's channel groups [4G, 5G)
   constexpr int MTA_BYTES = RPM * RSA * 16, MTB_BYTES = RPM * RSB * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Rin = smem;
@@ -82,6 +87,21 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
   for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
     for (int t = 0; t < NTB; ++t) wb[ks][t] = *reinterpret_cast<const bf16x8*>(k.wb + ((ks * NTB + t) * 64 + lane) * 16);
+  bf16x8 wres[RES ? KR : 1][RES ? NR : 1];
+  float rb[RES ? NR : 1][4];
+  if constexpr (RES) {
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+      for (int t = 0; t < NR; ++t) wres[ks][t] = *reinterpret_cast<const bf16x8*>(k.wres + ((ks * NR + t) * 64 + lane) * 16);
+#pragma unroll
+    for (int t = 0; t < NR; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + g * 4 + r;
+        rb[t][r] = (k.bias_r && c < cout) ? k.bias_r[c] : 0.f;
+      }
+  }
   for (int i = tid; i < CH_HR * PB_BYTES / 16; i += CH_THREADS) reinterpret_cast<uint4*>(Hl)[i] = make_uint4(0u, 0u, 0u, 0u);  // rows -1 and Y of h stay zero
   for (int i = tid; i < CM; i += CH_THREADS) {
     epi[i] = k.bias_a ? k.bias_a[i] : 0.f;
@@ -203,6 +223,12 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
   for (int ks = 0; ks < KSB; ++ks)
 #pragma unroll
     for (int t = 0; t < NTB; ++t) asm volatile("" : "+v"(wb[ks][t]));
+  if constexpr (RES) {
+#pragma unroll
+    for (int ks = 0; ks < KR; ++ks)
+#pragma unroll
+      for (int t = 0; t < NR; ++t) asm volatile("" : "+v"(wres[ks][t]));
+  }
 
   auto iter = [&](int s, unsigned (&cv)[NIA]) __attribute__((always_inline)) {
     if constexpr (C1) {
@@ -221,7 +247,13 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
     const bool a_on = s <= steps + 1, a_in = (unsigned)(xb + s - 1) < (unsigned)X, b_on = s >= 3;
     // ---- the MFMAs of both stages first (A: h plane s-1 from input planes s-2, s-1, s; B: output plane s-3 from h planes s-4, s-3, s-2 = H slots (s+1) & 3, (s+2) & 3,
     //      (s+3) & 3, all written in earlier iterations): eight independent accumulator chains, no LDS write between their operand reads
-    f32x4 acca[MT][NTA], accb[MT][NTB];
+    f32x4 acca[MT][NTA], accb[MT][NTB], racc[RES ? MT : 1][RES ? NR : 1];
+    if constexpr (RES) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NR; ++t) racc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -252,6 +284,19 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
           const bf16x8 av = *reinterpret_cast<const bf16x8*>(hb + m * MTB_BYTES);
 #pragma unroll
           for (int t = 0; t < NTB; ++t) accb[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[ks][t], av, accb[m][t], 0, 0, 0);
+        }
+      }
+      if constexpr (RES) {  // the 1x1x1 residual convolution of the input at output plane s-3: the centre-tap K-steps on input plane s-3 (ring slot (s-1) % RING)
+        const int sr = ((s - 1) % RING) * PA_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks) {
+          const char* hb = Rin + koffA[KLO + ks] + sr;
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(hb + m * MTA_BYTES);
+#pragma unroll
+            for (int t = 0; t < NR; ++t) racc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[ks][t], av, racc[m][t], 0, 0, 0);
+          }
         }
       }
     }
@@ -324,6 +369,10 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
               val[0] += x1 * w1.x + b1.x; val[1] += x1 * w1.y + b1.y; val[2] += x1 * w1.z + b1.z; val[3] += x1 * w1.w + b1.w;
             }
           }
+          if constexpr (RES) {  // + the residual convolution, rounded to bf16 like the tensor the separate launch stores
+            const unsigned r01 = f2bf2(racc[m][t][0] + rb[t][0], racc[m][t][1] + rb[t][1]), r23 = f2bf2(racc[m][t][2] + rb[t][2], racc[m][t][3] + rb[t][3]);
+            val[0] += __uint_as_float(r01 << 16); val[1] += __uint_as_float(r01 & 0xffff0000u); val[2] += __uint_as_float(r23 << 16); val[3] += __uint_as_float(r23 & 0xffff0000u);
+          }
           char* op = k.out + ovox * k.out_vox_bytes + c * (int)out_es;
           if (vec_store) {
             st4(reinterpret_cast<bf16_t*>(op), make_float4(val[0], val[1], val[2], val[3]));
@@ -349,25 +398,26 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD> static int ch_lds() {
+template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD, int NR> static int ch_lds() {
   constexpr int GA = CIN / 8, GB = CM / 8, RPM = 16 / TZ, ROWS = NW * MT * RPM + 2;
   constexpr int WIA = (ROWS * TZ * GA + 63) / 64, PB = (ROWS * TZ * GB * 16 + 255) / 256 * 256;
-  return (CC ? 5 : 3 + LEAD) * WIA * 1024 + CH_HR * PB + (3 * CM + 5 * NTB * 16) * 4 + 16;
+  return (CC ? 5 : 3 + LEAD + (NR ? 1 : 0)) * WIA * 1024 + CH_HR * PB + (3 * CM + 5 * NTB * 16) * 4 + 16;
 }
-template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD> static int ch_launch(const ChainK& k, int grid, hipStream_t s) {
+template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD, int NR> static int ch_launch(const ChainK& k, int grid, hipStream_t s) {
   static bool init = false;
-  const int lds = ch_lds<CIN, CM, NTB, TZ, MT, CC, NW, LEAD>();
+  const int lds = ch_lds<CIN, CM, NTB, TZ, MT, CC, NW, LEAD, NR>();
   if (!init) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<CIN, CM, NTB, TZ, MT, CC, NW, LEAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<CIN, CM, NTB, TZ, MT, CC, NW, LEAD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     init = true;
   }
-  hipLaunchKernelGGL((chain_kernel<CIN, CM, NTB, TZ, MT, CC, NW, LEAD>), dim3((unsigned)grid), dim3(NW * 64), lds, s, k);
+  hipLaunchKernelGGL((chain_kernel<CIN, CM, NTB, TZ, MT, CC, NW, LEAD, NR>), dim3((unsigned)grid), dim3(NW * 64), lds, s, k);
   VSSEG_LAUNCH_CHECK("vsseg_conv_chain");
   return VSSEG_OK;
 }
 typedef int (*ch_fn_t)(const ChainK&, int, hipStream_t);
-struct ChEntry { int cin, cm, ntb, tz, mt, cc, nw, lead; ch_fn_t fn; int (*lds)(); };
-#define CH_E(CI, CMID, NB, Z, M, C, W, LD) {CI, CMID, NB, Z, M, C, W, LD, ch_launch<CI, CMID, NB, Z, M, C, W, LD>, ch_lds<CI, CMID, NB, Z, M, C, W, LD>}
+struct ChEntry { int cin, cm, ntb, tz, mt, cc, nw, lead, nr; ch_fn_t fn; int (*lds)(); };
+#define CH_E(CI, CMID, NB, Z, M, C, W, LD) {CI, CMID, NB, Z, M, C, W, LD, 0, ch_launch<CI, CMID, NB, Z, M, C, W, LD, 0>, ch_lds<CI, CMID, NB, Z, M, C, W, LD, 0>}
+#define CH_R(CI, CMID, NB, Z, M, W, LD) {CI, CMID, NB, Z, M, 0, W, LD, NB, ch_launch<CI, CMID, NB, Z, M, 0, W, LD, NB>, ch_lds<CI, CMID, NB, Z, M, 0, W, LD, NB>}  // + the residual convolution of the input
 // (input channels of A, channels between the stages, output tiles of B, tz, M-tiles per wave, compact input, waves, fetch distance): rows Y = waves * mt * 16 / tz
 static const ChEntry ch_table[] = {
     // 1 -> 16 -> 16 (+ residual of the input)
@@ -377,7 +427,9 @@ static const ChEntry ch_table[] = {
     CH_E(32, 16, 1, 2, 2, 0, 8, 3), CH_E(32, 16, 1, 4, 2, 0, 8, 3), CH_E(32, 16, 1, 2, 1, 0, 8, 3),                               // one workgroup per CU: Y = 128 / 64 / 64
     CH_E(32, 16, 1, 1, 1, 0, 8, 1), CH_E(32, 16, 1, 1, 2, 0, 4, 1), CH_E(32, 16, 1, 2, 4, 0, 4, 1), CH_E(32, 16, 1, 2, 2, 0, 8, 1),  // several per CU: Y = 128
     CH_E(32, 16, 1, 1, 1, 0, 4, 1), CH_E(32, 16, 1, 2, 2, 0, 4, 1), CH_E(32, 16, 1, 2, 1, 0, 8, 1),                               // ... Y = 64
-    CH_E(32, 16, 1, 2, 1, 0, 16, 1), CH_E(32, 16, 1, 2, 1, 0, 16, 3), CH_E(32, 16, 1, 4, 2, 0, 16, 1), CH_E(8, 16, 1, 2, 1, 1, 16, 3), CH_E(8, 16, 1, 4, 2, 1, 16, 3)};  // sixteen waves: Y = 128
+    CH_E(32, 16, 1, 2, 1, 0, 16, 1), CH_E(32, 16, 1, 2, 1, 0, 16, 3), CH_E(32, 16, 1, 4, 2, 0, 16, 1), CH_E(8, 16, 1, 2, 1, 1, 16, 3), CH_E(8, 16, 1, 4, 2, 1, 16, 3),  // sixteen waves: Y = 128
+    // 16 -> 32 -> 32 + the 1x1x1 residual convolution 16 -> 32 of the input (the two-sub-unit ResidualUnit of level 1)
+    CH_R(16, 32, 2, 2, 1, 8, 1), CH_R(16, 32, 2, 4, 2, 8, 1), CH_R(16, 32, 2, 2, 2, 8, 1)};  // Y = 64 / 64 / 128
 
 static const ChEntry* ch_find(const vsseg_chain_desc* d, const char** why) {
   *why = nullptr;
@@ -390,7 +442,9 @@ static const ChEntry* ch_find(const vsseg_chain_desc* d, const char** why) {
   if (c1 && ((uintptr_t)d->in.ptr & 1)) return no("unaligned compact input");
   if (d->in.n != d->out.n || d->in.x != d->out.x || d->in.y != d->out.y || d->in.z != d->out.z || d->out.ptr2) return no("input and output extents differ / two-part output");
   if (d->out.dtype != VSSEG_BF16 && d->out.dtype != VSSEG_F32) return no("output dtype");
-  if (d->out.c < 1 || d->out.c > 16 || d->out.pitch < d->out.c) return no("output channels");
+  if (d->out.c < 1 || d->out.c > 32 || d->out.pitch < d->out.c) return no("output channels");
+  const int ntb = (d->out.c + 15) / 16;
+  if (d->res_tiles && (d->res_tiles != ntb || c1 || !d->wpack_res || (d->out.c & 3) || d->in1_w)) return no("residual tiles: one per output tile, packed weights, an ordinary input, a bf16 output");
   if ((d->out.c & 3) == 0 && (d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || ((uintptr_t)d->out.ptr & 7))) return no("a 4k-channel output is bf16 with 8-byte aligned rows");
   if ((d->in1_w || d->in1_b) && (!c1 || !d->in1_w || !d->in1_b || (d->out.c & 3))) return no("the residual of the input needs a compact one-channel input, weights and bias, and a bf16 output");
   if ((d->scale_a == nullptr) != (d->shift_a == nullptr) || (d->scale_b == nullptr) != (d->shift_b == nullptr)) return no("scale without shift");
@@ -399,7 +453,7 @@ static const ChEntry* ch_find(const vsseg_chain_desc* d, const char** why) {
   if ((d->tz != 1 && d->tz != 2 && d->tz != 4 && d->tz != 8) || d->mtw < 1 || (d->waves != 4 && d->waves != 8 && d->waves != 16) || d->in.y != d->waves * d->mtw * 16 / d->tz || d->in.z % d->tz || d->lx < 1)
     return no("plan: 4 or 8 waves, y must be waves * mtw * 16 / tz rows, z a multiple of tz, lx >= 1");
   for (const ChEntry& e : ch_table)
-    if (e.cin == cin && e.cm == d->cmid && e.ntb == 1 && e.tz == d->tz && e.mt == d->mtw && e.cc == (c1 ? 1 : 0) && e.nw == d->waves && e.lead == d->lead) return e.lds() <= 160 * 1024 ? &e : no("more than 160 KB of LDS");
+    if (e.cin == cin && e.cm == d->cmid && e.ntb == ntb && e.nr == d->res_tiles && e.tz == d->tz && e.mt == d->mtw && e.cc == (c1 ? 1 : 0) && e.nw == d->waves && e.lead == d->lead) return e.lds() <= 160 * 1024 ? &e : no("more than 160 KB of LDS");
   return no("no instantiation for this (channels, tz, mtw, waves, lead)");
 }
 
@@ -431,6 +485,7 @@ extern "C" int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream) {
   k.bias_b = d->bias_b; k.scale_b = d->scale_b; k.shift_b = d->shift_b; k.alpha_b = d->alpha_b;
   k.act_a = d->act_a; k.act_b = d->act_b;
   k.in1_w = d->in1_w; k.in1_b = d->in1_b;
+  k.wres = reinterpret_cast<const char*>(d->wpack_res); k.bias_r = d->bias_res;
   k.zeros = vsseg_zero_page();
   VSSEG_CHECK(k.zeros, "vsseg_conv_chain: could not allocate the zero page");
   k.X = d->in.x; k.Y = d->in.y; k.Z = d->in.z;

@@ -9,6 +9,7 @@ torch tensors are used only as device-memory containers.  There is no CPU/eager 
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -718,14 +719,15 @@ class Plan:
         # the second epilogue) and the attention block of the finest decoder level (32 -> 16 + ReLU -> 1 + sigmoid).  201 MB per patch are neither written nor read back, per pair.
         self.chain_first: Dict[str, tuple] = {}  # prefix of the first convolution -> (first op, second op, plan)
         self.chain_second: set = set()           # prefixes of the second convolutions: emitted with the first
-        if not self.train and eng.chain and eng.es == 2 and not eng.dry_run:
+        if not self.train and eng.chain != "0" and eng.es == 2 and not eng.dry_run:
             def march3(Lr):
                 return not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1)
             for a in ops:
-                if not isinstance(a, (ConvBnAct, ConvPlain)) or not march3(a.layer) or a.layer.cout != 16 or a.res is not None or a.x.base is not None or a.out.base is not None:
+                if not isinstance(a, (ConvBnAct, ConvPlain)) or not march3(a.layer) or a.layer.cout not in (16, 32) or a.res is not None or a.x.base is not None or a.out.base is not None:
                     continue
                 pa_ = a.layer.prefix
-                if pa_ in self.resn or pa_ in self.merged or pa_ in self.absorbs or pa_ in self.resn_of or a.x.name in self.gate_onload:
+                unit = eng.chain != "l0" and pa_ in self.resn and (a.layer.cin, a.layer.cout) == (16, 32) and a.x.parts is None  # a two-sub-unit ResidualUnit whose residual convolution rides along
+                if (pa_ in self.resn) != unit or (a.layer.cout == 32) != unit or pa_ in self.merged or pa_ in self.absorbs or pa_ in self.resn_of or a.x.name in self.gate_onload:
                     continue
                 readers = [o for o in ops if o is not a and ((getattr(o, "x", None) is a.out) or (getattr(getattr(o, "x", None), "parts", None) is not None and a.out in o.x.parts)
                                                              or getattr(o, "res", None) is a.out or getattr(o, "att", None) is a.out)]
@@ -733,15 +735,20 @@ class Plan:
                     continue
                 b = readers[0]
                 pb_ = b.layer.prefix
-                if not march3(b.layer) or b.layer.cin != 16 or pb_ in self.resn or pb_ in self.merged or pb_ in self.absorbs or b.out.base is not None or a.out in (prog.logits, *prog.att_maps):
+                if not march3(b.layer) or b.layer.cin != a.layer.cout or pb_ in self.resn or pb_ in self.merged or pb_ in self.absorbs or b.out.base is not None or a.out in (prog.logits, *prog.att_maps):
                     continue
-                if isinstance(a, ConvBnAct):  # the first ResidualUnit: compact network input, the unit's residual convolution already folded into the second epilogue (eval_in1)
+                if unit:  # 16 -> 32 -> 32 + the residual convolution's output (which then never exists): the residual tensor's only reader must be the second sub-unit
+                    rcv = self.resn[pa_]
+                    ok = (isinstance(b, ConvBnAct) and b.layer.cout == 32 and b.res is rcv.out
+                          and sum(1 for o in ops if getattr(o, "res", None) is rcv.out or getattr(o, "x", None) is rcv.out) == 1)
+                    compact, cin = False, 16
+                elif isinstance(a, ConvBnAct):  # the first ResidualUnit: compact network input, the unit's residual convolution already folded into the second epilogue (eval_in1)
                     ok = a.x.root.name == prog.input.name and a.x.real == 1 and eng.compact_c1 and b.layer.cout == 16 and pb_ in self.eval_in1 and b.res is not None
                     compact, cin = True, 8
                 else:  # the attention block: conv + ReLU -> conv + sigmoid -> the fp32 attention map
                     ok = a.act == "relu" and b.act == "sigmoid" and b.layer.cout == 1 and b.res is None and b.out.kind == "f32" and a.layer.cin == 32 and (a.x.parts is None or a.x.parts[0].c % 16 == 0)
                     compact, cin = False, a.layer.cin
-                plan_c = P.chain_plan(cin, compact, self.lv[a.layer.level], self.n) if ok else None
+                plan_c = P.chain_plan(cin, compact, self.lv[a.layer.level], self.n, a.layer.cout) if ok else None
                 if plan_c is None:
                     continue
                 self.chain_first[pa_] = (a, b, plan_c)
@@ -751,36 +758,48 @@ class Plan:
             La, Lb = a.layer, b.layer
             q = self.lv[La.level]
             d = L.ChainDesc()
-            compact = isinstance(a, ConvBnAct)
-            d.inp, d.out, d.cmid = (self._xdesc(a.x, True) if compact else self._desc(a.x)), self._desc(b.out), 16
+            bn = isinstance(a, ConvBnAct)
+            rcv = self.resn.get(La.prefix)
+            compact = bn and rcv is None
+            d.inp, d.out, d.cmid = (self._xdesc(a.x, True) if compact else self._desc(a.x)), self._desc(b.out), La.cout
             d.bias_a, d.bias_b = self._pp(La.bkey), self._pp(Lb.bkey)
-            if compact:
+            if bn:
                 for Lr in (La, Lb):
                     pre = Lr.prefix
                     self.fwd_pre.append([lib.vsseg_bn_fold_eval, [self._pp(pre + ".norm.weight"), self._pp(pre + ".norm.bias"), self._bp(pre + ".norm.running_mean"), self._bp(pre + ".norm.running_var"), BN_EPS,
                                                                   vptr(2, pre), vptr(3, pre), Lr.cout]])
                 d.scale_a, d.shift_a, d.alpha_a, d.act_a = vptr(2, La.prefix), vptr(3, La.prefix), self._pp(La.prefix + ".act.weight"), L.ACT_PRELU
                 d.scale_b, d.shift_b, d.alpha_b, d.act_b = vptr(2, Lb.prefix), vptr(3, Lb.prefix), self._pp(Lb.prefix + ".act.weight"), L.ACT_PRELU
-                pr1 = self.eval_in1[Lb.prefix]
-                d.in1_w, d.in1_b = self._pp(pr1.layer.wkey), self._pp(pr1.layer.bkey)
+                if compact:
+                    pr1 = self.eval_in1[Lb.prefix]
+                    d.in1_w, d.in1_b = self._pp(pr1.layer.wkey), self._pp(pr1.layer.bkey)
+                else:
+                    d.res_tiles, d.bias_res = 2, self._pp(rcv.layer.bkey)
             else:
                 d.act_a, d.act_b = L.ACT_RELU, L.ACT_SIGMOID
             d.tz, d.mtw, d.lx, d.waves, d.lead = plan_c["tz"], plan_c["mtw"], plan_c["lx"], plan_c["waves"], plan_c["lead"]
-            for attr, Lr, kc in (("wpack_a", La, 8 if compact else La.cin), ("wpack_b", Lb, 16)):
+            for attr, Lr, kc in (("wpack_a", La, 8 if compact else La.cin), ("wpack_b", Lb, La.cout)):
                 pl = P.chain_pack_plan(tuple(Lr.wshape), q, eng.es, kc, self.n)
                 assert pl is not None, "no marching pack layout for a chained convolution"
                 ch = _Choice([pl], eng.layout.param_off[Lr.wkey][0], wshape=tuple(Lr.wshape))
+                if attr == "wpack_a" and rcv is not None:  # + the residual convolution's centre-tap tiles behind the first convolution's weights
+                    pl = dataclasses.replace(pl, res_tiles=2)
+                    pl.pack_map_res = P.residual_tile_pack_map(kc, 2, tuple(rcv.layer.wshape))
+                    ch.woff_res = eng.layout.param_off[rcv.layer.wkey][0]
                 self._register(ch, pl)
                 self._chain_fixups.append((d, attr, ch.map_off))
+                if pl.res_tiles:
+                    self._chain_fixups.append((d, "wpack_res", ch.map_off_res))
             dummy = torch.zeros(16, dtype=eng.tdtype, device=dev)
-            d.wpack_a = d.wpack_b = dummy.data_ptr()  # (placeholders for the domain check; the real pointers are set once the packed-weight buffer exists)
+            d.wpack_a = d.wpack_b = dummy.data_ptr()
+            d.wpack_res = dummy.data_ptr() if rcv is not None else None  # (placeholders for the domain check; the real pointers are set once the packed-weight buffer exists)
             if lib.vsseg_conv_chain_lds_bytes(C.byref(d)) < 0:
                 raise RuntimeError("vsseg_conv_chain rejected a launch the planner offered: " + lib.vsseg_last_error().decode())
             self.keep.append(d)
             nvox = float(self.n) * q[0] * q[1] * q[2]
             cin_r = a.x.real
-            F.append([lib.vsseg_conv_chain, [C.byref(d)], dict(tag=f"chain q={q} K={cin_r}x9 -> 16x9 -> N={Lb.cout} tz={plan_c['tz']} waves={plan_c['waves']} mtw={plan_c['mtw']} lead={plan_c['lead']} lx={plan_c['lx']}",
-                                                               name=f"chain<bf16,{8 if compact else La.cin}>", kind="mfma", flops=2.0 * nvox * 9 * (cin_r * 16 + 16 * Lb.cout),
+            F.append([lib.vsseg_conv_chain, [C.byref(d)], dict(tag=f"chain q={q} K={cin_r}x9 -> {La.cout}x9 -> N={Lb.cout}{'+res' if rcv is not None else ''} tz={plan_c['tz']} waves={plan_c['waves']} mtw={plan_c['mtw']} lead={plan_c['lead']} lx={plan_c['lx']}",
+                                                               name=f"chain<bf16,{8 if compact else La.cin}>", kind="mfma", flops=2.0 * nvox * (9 * (cin_r * La.cout + La.cout * Lb.cout) + (cin_r * Lb.cout if rcv is not None else 0)),
                                                                bytes=nvox * (cin_r * eng.es + Lb.cout * (4 if b.out.kind == "f32" else eng.es)))])
 
         # ---- forward
@@ -1410,7 +1429,7 @@ class Engine:
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
-        self.chain = os.environ.get("VSSEG_CHAIN", "1") != "0"  # inference: pairs of 3x3x1 convolutions as one launch, the tensor between them in LDS (csrc/chain.hip)
+        self.chain = os.environ.get("VSSEG_CHAIN", "1")  # inference: pairs of 3x3x1 convolutions as one launch, the tensor between them in LDS (csrc/chain.hip); "0": off, "l0": level 0 only
         self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
         # the deep-level kernel (csrc/dconv.hip, plans with depth -7) on the small launches of levels 3-5: "1" = a candidate the tuner measures, "0" = off, "force" = every launch

@@ -242,15 +242,19 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
     return out
 
 
-def chain_plan(cin: int, compact: bool, q, n: int = 1) -> Optional[dict]:
-    """Plan of a chained marching launch (csrc/chain.hip: two stride-1 3x3x1 convolutions with the 16-channel tensor between them in LDS; inference only) for the two pairs it is
-    instantiated and measured for — the compact one-channel network input (1 -> 16 -> 16) and a 32-channel input (32 -> 16 -> 1) on columns of 128 rows — or None.
-    A workgroup of 16 waves owns all rows of `tz` slices; x is cut into segments so that the launch has about one workgroup per CU (tools/bench_chain.py)."""
+def chain_plan(cin: int, compact: bool, q, n: int = 1, cmid: int = 16) -> Optional[dict]:
+    """Plan of a chained marching launch (csrc/chain.hip: two stride-1 3x3x1 convolutions with the tensor between them in LDS; inference only) for the pairs it is
+    instantiated and measured for (tools/bench_chain.py) — the compact one-channel network input (1 -> 16 -> 16) and a 32-channel input (32 -> 16 -> 1) on columns of 128 rows,
+    16 -> 32 -> 32 with the residual convolution of the input on columns of 64 rows — or None.  A workgroup owns all rows of `tz` slices; x is cut into segments so that the
+    launch has about one workgroup per CU."""
     X, Y, Z = q
-    if Y != 128 or X < 32 or cin != (8 if compact else 32):
+    if cmid == 16 and Y == 128 and cin == (8 if compact else 32):
+        tz, waves, mtw, lead = (4, 16, 2, 3) if compact else (2, 16, 1, 1)
+    elif cmid == 32 and Y == 64 and cin == 16 and not compact:
+        tz, waves, mtw, lead = 4, 8, 2, 1
+    else:
         return None
-    tz, waves, mtw, lead = (4, 16, 2, 3) if compact else (2, 16, 1, 1)
-    if Z % tz:
+    if X < 32 or Z % tz:
         return None
     cols = n * (Z // tz)
     nxs = max(1, min(X // 16, int(round(256.0 / cols))))
@@ -258,11 +262,11 @@ def chain_plan(cin: int, compact: bool, q, n: int = 1) -> Optional[dict]:
 
 
 def chain_pack_plan(wshape, q, es, kc, n=1) -> Optional["IgemmPlan"]:
-    """The packed-weight layout a chained launch reads for one of its two convolutions: that of a marching plan (depth -5) with ONE 16-channel output tile."""
+    """The packed-weight layout a chained launch reads for one of its two convolutions: that of a marching plan (depth -5) holding all output tiles."""
     cls = lattice_classes("conv_fwd", tuple(wshape[2:]), (1, 1, 1))[0]
     kreal, nreal = gemm_dims("conv_fwd", wshape)
     for pl in march_plans("conv_fwd", wshape, cls, q, es, kc, nreal, kreal, n):
-        if pl.depth == -5 and pl.nt == 1:
+        if pl.depth == -5 and pl.nt == (nreal + 15) // 16:
             pl.pack_map = pack_map(pl, wshape)
             return pl
     return None
