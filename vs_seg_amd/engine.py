@@ -719,10 +719,12 @@ class Plan:
         # the second epilogue) and the attention block of the finest decoder level (32 -> 16 + ReLU -> 1 + sigmoid).  201 MB per patch are neither written nor read back, per pair.
         self.chain_first: Dict[str, tuple] = {}  # prefix of the first convolution -> (first op, second op, plan)
         self.chain_second: set = set()           # prefixes of the second convolutions: emitted with the first
-        if not self.train and eng.chain != "0" and eng.es == 2 and not eng.dry_run:
+        if eng.chain != "0" and eng.es == 2 and not eng.dry_run:
             def march3(Lr):
                 return not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1)
             for a in ops:
+                if self.train and not (isinstance(a, ConvPlain) and eng.chain_train):  # training: only pairs without a BatchNorm between them (the attention block), h stored as well
+                    continue
                 if not isinstance(a, (ConvBnAct, ConvPlain)) or not march3(a.layer) or a.layer.cout not in (16, 32) or a.res is not None or a.x.base is not None or a.out.base is not None:
                     continue
                 pa_ = a.layer.prefix
@@ -777,6 +779,8 @@ class Plan:
                     d.res_tiles, d.bias_res = 2, self._pp(rcv.layer.bkey)
             else:
                 d.act_a, d.act_b = L.ACT_RELU, L.ACT_SIGMOID
+                if self.train:  # the backward pass reads h (ReLU mask, weight gradient of the second convolution)
+                    d.h_out = self._desc(a.out)
             d.tz, d.mtw, d.lx, d.waves, d.lead = plan_c["tz"], plan_c["mtw"], plan_c["lx"], plan_c["waves"], plan_c["lead"]
             for attr, Lr, kc in (("wpack_a", La, 8 if compact else La.cin), ("wpack_b", Lb, La.cout)):
                 pl = P.chain_pack_plan(tuple(Lr.wshape), q, eng.es, kc, self.n)
@@ -800,7 +804,7 @@ class Plan:
             cin_r = a.x.real
             F.append([lib.vsseg_conv_chain, [C.byref(d)], dict(tag=f"chain q={q} K={cin_r}x9 -> {La.cout}x9 -> N={Lb.cout}{'+res' if rcv is not None else ''} tz={plan_c['tz']} waves={plan_c['waves']} mtw={plan_c['mtw']} lead={plan_c['lead']} lx={plan_c['lx']}",
                                                                name=f"chain<bf16,{8 if compact else La.cin}>", kind="mfma", flops=2.0 * nvox * (9 * (cin_r * La.cout + La.cout * Lb.cout) + (cin_r * Lb.cout if rcv is not None else 0)),
-                                                               bytes=nvox * (cin_r * eng.es + Lb.cout * (4 if b.out.kind == "f32" else eng.es)))])
+                                                               bytes=nvox * (cin_r * eng.es + Lb.cout * (4 if b.out.kind == "f32" else eng.es) + (La.cout * eng.es if (self.train and not bn) else 0)))])
 
         # ---- forward
         F = self.fwd
@@ -1429,6 +1433,9 @@ class Engine:
         # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
         self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
         self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
+        # ... and (VSSEG_CHAIN_TRAIN=1, off by default) the level-0 attention block of the TRAINING forward: no BatchNorm between its convolutions, h is stored as well (h_out).  Bit-identical,
+        # one launch less — and no faster: 27.93 against 27.92 ms per step over three alternating same-box pairs (the chain moves 2.5 GB at ~3.5 TB/s where the two launches move 3.2 GB at 4.6 / 2.5)
+        self.chain_train = os.environ.get("VSSEG_CHAIN_TRAIN", "0") == "1"
         self.chain = os.environ.get("VSSEG_CHAIN", "1")  # inference: pairs of 3x3x1 convolutions as one launch, the tensor between them in LDS (csrc/chain.hip); "0": off, "l0": level 0 only
         self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
         self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
