@@ -1463,7 +1463,9 @@ class Engine:
 
     def side_stream(self) -> "torch.cuda.Stream":
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            from ._streams import side_stream  # the process-wide pool: the sliding-window lanes reuse this stream instead of adding a fifth one (see _streams.py)
+
+            self._side = side_stream(self.device, 0)
         return self._side
 
     def wgrad_scratch(self) -> torch.Tensor:

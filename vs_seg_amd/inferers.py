@@ -112,7 +112,6 @@ def crop_all_windows(vol: torch.Tensor, b_and_starts, roi, pad_before) -> torch.
     return out
 
 
-_SIDE_STREAMS: Dict[tuple, "torch.cuda.Stream"] = {}
 _CNT_CACHE: Dict[tuple, torch.Tensor] = {}  # (device, padded extents, roi, window starts, importance map) -> sum of the window weights per voxel
 
 
@@ -134,10 +133,9 @@ def _weight_sum(lib, device, padded, roi, starts, imap: torch.Tensor, stream, mo
 
 
 def _side_stream(device, i: int) -> "torch.cuda.Stream":
-    key = (str(device), i)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
+    from ._streams import side_stream  # one pool for the whole process (the training step's weight-gradient stream is its lane 0): see _streams.py
+
+    return side_stream(device, i)
 
 
 def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int, predictor: Callable, overlap: float = 0.25, mode: str = "constant", padding_mode: str = "constant",
@@ -148,7 +146,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
 
     The default is 1 for an arbitrary `predictor` — a callable that reuses buffers between calls, or returns views of them, would race on two
     streams — and 2 for a predictor that declares itself `stream_safe` (`UNet2d5_spvPA.segmentation_predictor()`: one set of eval activation
-    buffers, packed weights and hipGraph per stream, i.e. twice the eval memory and lowering time of the serial schedule)."""
+    buffers, packed weights and hipGraph per stream, i.e. twice the eval memory and lowering time of the serial schedule).  Three groups (round 5, with the shorter launch
+    list): 42.7 against 41.8 volumes/s in an inference-only process, 38.6-41.0 against 40.8-42.9 in a process that has also trained (bench.py) — not the default."""
     if concurrent_groups is None:
         concurrent_groups = 2 if getattr(predictor, "stream_safe", False) else 1
     if not inputs.is_cuda:
