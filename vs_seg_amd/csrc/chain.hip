@@ -1,21 +1,25 @@
-// Chained marching convolution (vsseg_conv_chain; eval only): TWO consecutive stride-1 3x3x1 bf16 convolutions of the two finest levels of the 2.5D U-Net as ONE launch,
+// Chained marching convolution (vsseg_conv_chain; the inference forward): TWO consecutive stride-1 3x3x1 bf16 convolutions of the two finest levels of the 2.5D U-Net as ONE launch,
 //   h = act_a(scale_a * (conv_a(x) + bias_a) + shift_a)          (conv + eval-mode BatchNorm + PReLU: ref:params/networks/blocks/convolutions.py:114-146; or conv + ReLU)
-//   y = act_b(scale_b * (conv_b(h) + bias_b) + shift_b) [+ x * in1_w + in1_b]
-// with the tensor between them (16 channels at 384x128x128: 201 MB written and read back per sliding-window patch) kept in LDS.  Users: the first ResidualUnit of the
-// encoder (1 -> 16 -> 16 with its 1x1x1 residual convolution of the network input, ref:params/networks/nets/unet2d5_spvPA.py:52-77, blocks/convolutions.py:241-255) and the
-// attention block of the level-0 decoder (32 -> 16 -> 1 + sigmoid, ref:params/networks/blocks/attentionblock.py:20-41).  In TRAINING the BatchNorm between the two needs the
-// statistics of the whole tensor before any element of h exists, so this is an inference-only launch (the sliding-window predictor, ref:params/VSparams.py:553-567).
+//   y = act_b(scale_b * (conv_b(h) + bias_b) + shift_b) [+ x * in1_w + in1_b] [+ bf16(residual(x) + bias_r)]
+// with the tensor between them (16 channels at 384x128x128: 201 MB written and read back per sliding-window patch) kept in LDS.  Users (engine.py, Plan._lower): the first
+// ResidualUnit of the encoder (1 -> 16 -> 16 with its 1x1x1 residual convolution of the network input, ref:params/networks/nets/unet2d5_spvPA.py:52-77,
+// blocks/convolutions.py:241-255), the attention block of the level-0 decoder (32 -> 16 -> 1 + sigmoid, ref:params/networks/blocks/attentionblock.py:20-41) and the
+// two-sub-unit ResidualUnit of level 1 (16 -> 32 -> 32 with its residual convolution as residual tiles of stage B).  In TRAINING the BatchNorm between two sub-units needs the
+// statistics of the whole tensor before any element of h exists, so the units are inference-only launches (the sliding-window predictor, ref:params/VSparams.py:553-567); the
+// attention block has no BatchNorm and can also run in the training forward with h stored as well (h_out) — measured: no faster than its two launches.
 //
 // Structure = mconv.hip's (a workgroup owns a column: sample n, ALL rows, slices [z0, z0 + TZ), and marches along x; a plane = one x position of the column, LDS layout
 // [row][piece'][z] with the same bank swizzle) with a second ring: iteration s
-//   * waits for input plane s (fetched three iterations ahead: one workgroup of 8 waves per CU, so the latency is covered by the depth of the ring, not by neighbours),
-//   * stage A multiplies input planes s-2, s-1, s into h plane s-1, applies its epilogue and writes the bf16 result into the H ring in stage B's operand layout
-//     (a lane of the 16x16 MFMA result holds 4 consecutive channels of one voxel = half a 16-byte piece: one ds_write_b64), zeros where the plane lies outside the image
-//     (stage B's zero padding is a padding of h, not h of a padded x),
-//   * stage B multiplies h planes s-4, s-3, s-2 (written in EARLIER iterations: one barrier per iteration, the two MFMA streams are independent) into output plane s-3.
-// Rows -1 and Y of both rings are the zero padding (all rows in one workgroup: no halo in y); an x segment re-fetches 4 input planes and recomputes 2 h planes.
-// Same packed weights ([K-steps][tiles][64 lanes][8], K order (tap, channel group)), MFMA operand order and epilogue arithmetic as the two mconv launches it replaces:
-// the results are bit-identical to them (tests/test_gpu_ops.py::test_chained_marching_convolution_*).
+//   * waits for input plane s (LDS-DMA, fetched LEAD = 1 or 3 iterations ahead; the compact one-channel input travels through registers, three planes ahead),
+//   * issues the MFMAs of BOTH stages — stage A: input planes s-2, s-1, s -> h plane s-1; stage B: h planes s-4, s-3, s-2, all written in EARLIER iterations -> output plane
+//     s-3 — before either epilogue: one barrier per iteration, the accumulator chains of the two stages are independent,
+//   * stage A's epilogue writes the bf16 result into the H ring in stage B's operand layout (a lane of the 16x16 MFMA result holds 4 consecutive channels of one voxel = half
+//     a 16-byte piece: one ds_write_b64), zeros where the plane lies outside the image (stage B's zero padding is a padding of h, not h of a padded x),
+//   * stage B's epilogue stores output plane s-3; residual tiles (NR): the centre-tap K-steps of input plane s-3, which the ring keeps one iteration longer.
+// Rows -1 and Y of both rings are the zero padding (all rows in one workgroup: no halo in y); an x segment re-fetches 4 input planes and recomputes 2 h planes.  One large
+// workgroup (8 or 16 waves) per CU: its own waves are its latency cover, and the packed weights of both stages stay in registers (tools/bench_chain.py: 16 waves beat 8 beat 4).
+// Same packed weights ([K-steps][tiles][64 lanes][8], K order (tap, channel group)), MFMA operand order and epilogue arithmetic as the mconv launches it replaces: the results
+// are bit-identical to them (tests/test_gpu_ops.py::test_chained_marching_convolution_*).
 #include "common.h"
 #include "chain.h"
 
