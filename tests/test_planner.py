@@ -241,3 +241,30 @@ def test_march_plans_cover_the_benchmark_layers_and_mirror_the_kernel_lds():
     # outside the domain: strided, 3x3x3, fp32
     assert P.march_plans("conv_fwd", (16, 16, 3, 3, 1), P.lattice_classes("conv_fwd", (3, 3, 1), (2, 2, 1))[0], (192, 64, 128), 2, 16, 16, 16) == []
     assert P.march_plans("conv_fwd", (16, 16, 3, 3, 1), cls, (384, 128, 128), 4, 16, 16, 16) == []
+
+
+def test_chained_launch_plans_cover_the_benchmark_window_and_nothing_else():
+    """planner.chain_plan / chain_pack_plan (csrc/chain.hip, inference): the three pairs of the 384x128x128 window get a plan whose workgroup owns ALL rows
+    (y == waves * mtw * 16 / tz), about one workgroup per CU, and packed weights in the marching layout [K-steps][tiles][64][8]; every other shape gets None."""
+    for cin, compact, cmid, dims in [(8, True, 16, (384, 128, 128)), (32, False, 16, (384, 128, 128)), (16, False, 32, (192, 64, 128))]:
+        for n in (1, 2, 4):
+            pc = P.chain_plan(cin, compact, dims, n, cmid)
+            assert pc is not None, (cin, cmid, n)
+            assert dims[1] == pc["waves"] * pc["mtw"] * 16 // pc["tz"] and dims[2] % pc["tz"] == 0 and 1 <= pc["lx"] <= dims[0]
+            assert pc["waves"] in (8, 16) and pc["lead"] in (1, 3) and (pc["lead"] == 3 or not compact)
+            wgs = n * -(-dims[0] // pc["lx"]) * (dims[2] // pc["tz"])
+            assert 128 <= wgs <= 512, (cin, n, wgs)
+    assert P.chain_plan(32, False, (384, 384, 64), 1) is None      # 384 rows do not fit one workgroup's rings
+    assert P.chain_plan(8, True, (192, 64, 128), 1) is None        # the compact pair is instantiated for 128 rows
+    assert P.chain_plan(16, False, (384, 128, 128), 1, 32) is None  # the level-1 unit for 64 rows
+    assert P.chain_plan(32, False, (16, 128, 128), 1) is None      # too short to march
+    assert P.chain_plan(64, False, (192, 64, 128), 1, 32) is None  # the level-1 attention block is not instantiated
+    for wshape, kc in [((16, 1, 3, 3, 1), 8), ((16, 16, 3, 3, 1), 16), ((1, 16, 3, 3, 1), 16), ((32, 16, 3, 3, 1), 16), ((32, 32, 3, 3, 1), 32)]:
+        dims = (384, 128, 128) if wshape[0] <= 16 else (192, 64, 128)
+        pl = P.chain_pack_plan(wshape, dims, 2, kc, 1)
+        assert pl is not None and pl.depth == -5 and pl.nt == (wshape[0] + 15) // 16
+        assert pl.pack_map.size == ((9 * (kc // 8) + 3) // 4) * pl.nt * 64 * 8
+        real = pl.pack_map[pl.pack_map >= 0]
+        assert real.size == int(np.prod(wshape)) and len(set(real.tolist())) == real.size  # every weight element exactly once
+    rm = P.residual_tile_pack_map(16, 2, (32, 16, 1, 1, 1))
+    assert rm.size == 1 * 2 * 64 * 8 and (rm >= 0).sum() == 32 * 16
