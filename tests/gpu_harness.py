@@ -110,7 +110,7 @@ def run_lattice_op(kind, w, x_cl, out_cl, stride, **epi):
     return keep
 
 
-def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid, hgroup=0, single_buffer=0, march_tile=None, dbias=None, h_gate=None):
+def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid, hgroup=0, single_buffer=0, march_tile=None, dbias=None, h_gate=None, compute=0, blocks=None):
     lib = L.lib()
     es = p_cl.element_size()
     wp = P.plan_wgrad(transposed, wshape, kernel, stride, tuple(p_cl.shape[1:4]), es)
@@ -128,11 +128,15 @@ def run_wgrad(transposed, wshape, kernel, stride, p_cl, h_cl, cp_valid, ch_valid
     d.hgroup, d.single_buffer = hgroup, single_buffer
     if march_tile is not None:  # the marching kernel (csrc/mwgrad.hip): tile = (x steps per workgroup, rows, z slices)
         d.march, d.tile = 1, L.i3(march_tile)
+    if compute:  # the compute kernel (csrc/cwgrad.hip): hgroup = 16-channel H chunks per workgroup (1 or 2)
+        d.march, d.hgroup = 2, compute
+    if blocks is not None:
+        d.persistent_blocks = blocks
     if dbias is not None:
         d.dbias_p = dbias.data_ptr()
     if h_gate is not None:
         d.h_gate = h_gate.data_ptr()
-    scr = torch.zeros(8 * 1024 * 1024, dtype=torch.float32, device="cuda")
+    scr = torch.zeros((48 if compute else 8) * 1024 * 1024, dtype=torch.float32, device="cuda")
     d.scratch, d.scratch_elems = scr.data_ptr(), scr.numel()
     L.check(lib.vsseg_wgrad(C.byref(d), stream()), "wgrad")
     torch.cuda.synchronize()

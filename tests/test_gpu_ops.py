@@ -182,6 +182,68 @@ def test_marching_weight_gradient(cin, cout, dims, split, tile):
         assert torch.equal(a, b) and not torch.equal(a, dw)
 
 
+COMPUTE_WGRAD_CASES = [
+    # cin (H), cout (P), dims, batch, H split, H chunks per workgroup, bias gradient, workgroups per class (None: one per CU)
+    (32, 48, (4, 8, 64), 2, 0, 2, False, None),    # level-2 encoder unit0: one chunk class, two K-step shares
+    (32, 48, (4, 8, 64), 2, 0, 1, False, None),    # two classes x four K-step shares
+    (48, 48, (6, 4, 32), 2, 0, 1, False, None),    # three classes (odd: class = workgroup % 3)
+    (96, 48, (4, 8, 64), 2, 48, 2, True, None),    # level-2 attention conv1: the concat as a two-part H, bias gradient on the side
+    (96, 48, (2, 12, 32), 3, 0, 2, False, 5),      # few workgroups per class: several tiles per workgroup, ragged (XCD, class) groups
+    (96, 48, (8, 8, 32), 1, 0, 1, False, 4),       # six classes
+    (48, 64, (4, 8, 64), 2, 0, 1, False, None),    # level 3: 64 P channels, P tiles split over two waves
+    (64, 64, (6, 4, 32), 2, 0, 1, True, 8),
+    (128, 64, (4, 4, 64), 1, 64, 1, True, None),   # level-3 concat, eight classes
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,batch,split,cg,bias,blocks", COMPUTE_WGRAD_CASES)
+def test_compute_weight_gradient(cin, cout, dims, batch, split, cg, bias, blocks):
+    """march = 2 selects the compute weight-gradient kernel of the stride-1 3x3x3 layers (csrc/cwgrad.hip: the three z-taps of a voxel row share one H
+    fragment, all 27 taps of a 16-channel chunk of H accumulate in one wave's registers).  Against the fp64 autograd of F.conv3d on the same bf16 operands
+    and against the tile kernel, over volume borders in all three axes, several tiles per workgroup, every wave-role split, a two-part H and the bias
+    gradient; run twice: the slab sums are in a fixed order, the result is bit-identical."""
+    dt, k = "bf16", (3, 3, 3)
+    torch.manual_seed(21)
+    x = _round(torch.randn(batch, cin, *dims), dt)
+    w = torch.randn(cout, cin, *k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, padding=P.same_pad(k))
+    gy = _round(torch.randn(*y.shape), dt)
+    y.backward(gy.double())
+    xcl, gcl = H.to_cl(x, H.DT[dt]), H.to_cl(gy, H.DT[dt])
+    h = H._split_cl(xcl, split) if split else xcl
+    db = torch.zeros(cout, dtype=torch.float32, device="cuda") if bias else None
+    dw = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin, compute=cg, dbias=db, blocks=blocks)
+    ref = w.grad.float()
+    np.testing.assert_allclose(dw.numpy(), ref.numpy(), atol=1e-4 * float(ref.abs().max()))
+    gen = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin)  # the tile kernel on the same operands
+    np.testing.assert_allclose(dw.numpy(), gen.numpy(), atol=1e-4 * float(ref.abs().max()))
+    if bias:
+        want = gy.double().sum((0, 2, 3, 4)).float()
+        np.testing.assert_allclose(db.cpu().numpy(), want.numpy(), atol=1e-4 * float(want.abs().max()) + 1e-3)
+    again = H.run_wgrad(False, tuple(w.shape), k, (1, 1, 1), gcl, h, cout, cin, compute=cg, blocks=blocks)
+    assert torch.equal(again, dw)
+
+
+def test_compute_weight_gradient_rejects_what_it_does_not_cover():
+    """Outside its domain the compute weight-gradient kernel is an error, never another kernel."""
+    lib = L.lib()
+    k = (3, 3, 3)
+
+    def attempt(cin, cout, dims, kernel=k, cg=1):
+        p = torch.zeros(1, *dims, cout, device="cuda", dtype=torch.bfloat16)
+        h = torch.zeros(1, *dims, cin, device="cuda", dtype=torch.bfloat16)
+        with pytest.raises(RuntimeError, match="compute kernel"):
+            H.run_wgrad(False, (cout, cin, *kernel), kernel, (1, 1, 1), p, h, cout, cin, compute=cg)
+
+    attempt(32, 48, (4, 8, 48))            # z extent not a multiple of 32
+    attempt(32, 48, (3, 8, 32))            # x extent odd
+    attempt(32, 32, (4, 8, 32))            # 32 P channels
+    attempt(40, 48, (4, 8, 32))            # H channels not a multiple of 16
+    attempt(48, 48, (4, 8, 32), cg=2)      # 3 chunks, 2 per workgroup
+    attempt(64, 64, (4, 8, 32), cg=2)      # 64 P channels with two chunks per workgroup
+    attempt(32, 48, (4, 8, 32), kernel=(3, 3, 1))
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 @pytest.mark.parametrize("k,cin,cout,dims", [((3, 3, 1), 1, 16, (12, 16, 8)), ((1, 1, 1), 1, 16, (6, 8, 4)), ((3, 3, 1), 16, 1, (12, 16, 8)), ((3, 3, 1), 32, 1, (5, 8, 12)), ((3, 3, 1), 1, 8, (3, 4, 2))])
 def test_wgrad_narrow(k, cin, cout, dims, dt):

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--tile", type=int, nargs=3, default=None)
     ap.add_argument("--blocks", type=int, nargs="*", default=[0])
+    ap.add_argument("--compute-only", action="store_true")
     a = ap.parse_args()
     dt = H.DT[a.dtype]
     es = 2 if a.dtype == "bf16" else 4
@@ -59,6 +60,24 @@ def main():
     flops = 2.0 * nq * len(wp.taps) * a.cin * a.cout
     S = H.stream()
     print(f"wgrad {a.cin}->{a.cout} k={k} dims={a.dims} tile={tile} ntp={wp.ntp} hch={hch} tiles={tiles}  alg {byts / 1e9:.2f} GB")
+    if k == (3, 3, 3):  # the compute kernel (csrc/cwgrad.hip, march = 2): hgroup = H chunks per workgroup
+        for cg in (1, 2):
+            d.march, d.hgroup, d.persistent_blocks = 2, cg, 0
+            if lib.vsseg_wgrad(C.byref(d), S):
+                print(f"  compute cg={cg}: rejected ({lib.vsseg_last_error().decode()})")
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.reps):
+                lib.vsseg_wgrad(C.byref(d), S)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.reps
+            print(f"  compute cg={cg}: {ms:7.3f} ms  {flops / ms / 1e9:7.1f} TF  {byts / ms / 1e6:6.0f} GB/s(alg)")
+        d.march = 0
+        if a.compute_only:
+            return
     for hg in [g for g in (1, 2, 3, 4) if hch % g == 0]:
         for sb in (0, 1):
             for blocks in a.blocks:

@@ -424,14 +424,15 @@ int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, 
 }
 
 int vsseg_mwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_t s);  // mwgrad.hip
+int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_t s);  // cwgrad.hip
 
 extern "C" int vsseg_wgrad(const vsseg_wgrad_desc* d, void* stream) {
   VSSEG_CHECK(d && d->p.ptr && d->h.ptr && d->dw, "vsseg_wgrad: null pointer");
-  if (d->march) {  // marching kernel (mwgrad.hip): fails loudly outside its domain, never falls back
+  if (d->march) {  // 1: marching kernel (mwgrad.hip), 2: compute kernel (cwgrad.hip): they fail loudly outside their domains, never fall back
     static void* z = nullptr;
     if (!z && (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess)) z = nullptr;
     VSSEG_CHECK(z, "vsseg_wgrad: could not allocate the zero page");
-    return vsseg_mwgrad_launch(d, z, as_stream(stream));
+    return d->march == 2 ? vsseg_cwgrad_launch(d, z, as_stream(stream)) : vsseg_mwgrad_launch(d, z, as_stream(stream));
   }
   VSSEG_CHECK(!d->h_gate, "vsseg_wgrad: the gated H operand (h_gate) needs the marching kernel (march = 1)");
   VSSEG_CHECK(d->p.dtype == d->h.dtype, "vsseg_wgrad: dtype mismatch");
