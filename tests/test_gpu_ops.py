@@ -184,15 +184,15 @@ def test_marching_weight_gradient(cin, cout, dims, split, tile):
 
 COMPUTE_WGRAD_CASES = [
     # cin (H), cout (P), dims, batch, H split, H chunks per workgroup, bias gradient, workgroups per class (None: one per CU)
-    (32, 48, (4, 8, 64), 2, 0, 2, False, None),    # level-2 encoder unit0: one chunk class, two K-step shares
-    (32, 48, (4, 8, 64), 2, 0, 1, False, None),    # two classes x four K-step shares
-    (48, 48, (6, 4, 32), 2, 0, 1, False, None),    # three classes (odd: class = workgroup % 3)
+    (32, 48, (5, 8, 64), 2, 0, 2, False, None),    # level-2 encoder unit0: one chunk class, two K-step shares; runs of a single x step
+    (32, 48, (4, 16, 32), 2, 0, 1, False, 8),      # two classes x four K-step shares; runs that cross strips
+    (48, 48, (6, 8, 32), 2, 0, 1, False, None),    # three classes (odd: class = workgroup % 3)
     (96, 48, (4, 8, 64), 2, 48, 2, True, None),    # level-2 attention conv1: the concat as a two-part H, bias gradient on the side
-    (96, 48, (2, 12, 32), 3, 0, 2, False, 5),      # few workgroups per class: several tiles per workgroup, ragged (XCD, class) groups
-    (96, 48, (8, 8, 32), 1, 0, 1, False, 4),       # six classes
+    (96, 48, (7, 24, 32), 1, 0, 2, False, 2),      # two workgroups per class: long runs over several strips, ragged (XCD, class) groups
+    (96, 48, (9, 8, 32), 1, 0, 1, False, 4),       # six classes
     (48, 64, (4, 8, 64), 2, 0, 1, False, None),    # level 3: 64 P channels, P tiles split over two waves
-    (64, 64, (6, 4, 32), 2, 0, 1, True, 8),
-    (128, 64, (4, 4, 64), 1, 64, 1, True, None),   # level-3 concat, eight classes
+    (64, 64, (6, 16, 32), 2, 0, 1, True, 8),
+    (128, 64, (3, 8, 64), 1, 64, 1, True, None),   # level-3 concat, eight classes
 ]
 
 
@@ -236,7 +236,7 @@ def test_compute_weight_gradient_rejects_what_it_does_not_cover():
             H.run_wgrad(False, (cout, cin, *kernel), kernel, (1, 1, 1), p, h, cout, cin, compute=cg)
 
     attempt(32, 48, (4, 8, 48))            # z extent not a multiple of 32
-    attempt(32, 48, (3, 8, 32))            # x extent odd
+    attempt(32, 48, (4, 12, 32))           # y extent not a multiple of 8
     attempt(32, 32, (4, 8, 32))            # 32 P channels
     attempt(40, 48, (4, 8, 32))            # H channels not a multiple of 16
     attempt(48, 48, (4, 8, 32), cg=2)      # 3 chunks, 2 per workgroup

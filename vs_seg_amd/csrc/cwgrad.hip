@@ -4,37 +4,40 @@
 //
 //   dW[(dx, dy, dz)][cP][cH] = sum_q P[q][cP] * H[q + (dx, dy, dz)][cH]          P = dY (48 or 64 channels), H = X (a multiple of 16 channels; may be two-part)
 //
-// What held wgrad_kernel (wgrad.hip) at 0.19-0.28 of the bf16 MFMA peak on these layers: every H fragment it read from LDS fed only NTP MFMAs (10 fragment
-// reads per 21 MFMAs), 256-voxel tiles with a load -> wait -> multiply round each and 2-3 small workgroups per CU taking turns.  Here:
+// What held wgrad_kernel (wgrad.hip) at 0.19-0.28 of the bf16 MFMA peak on these layers in the training step: every H fragment it read from LDS fed only NTP
+// MFMAs (10 fragment reads per 21 MFMAs), 256-voxel tiles with a load -> wait -> multiply round each, a (4+2)x(8+2)x(8+2) halo per 4x8x8 tile (2.3x the
+// tile's voxels through the LDS-DMA path, which delivers ~5 TB/s chip-wide whatever the L2 hit rate).  Here:
 //
 //   * THE THREE z-TAPS OF A VOXEL ROW SHARE ONE H FRAGMENT.  The reduction axis (voxels) runs along z, 32 voxels per MFMA K-step.  Shifting the P operand
 //     instead of the H operand —  dW[dz] = sum_z' P[z' - dz] * H[z'] — one H fragment (32 voxels x 16 channels at column (x + dx, y + dy)) is multiplied
 //     with the three z-shifted P fragments of every P tile, and the shifted P fragments (3 x NTP, held in registers) serve all nine (dx, dy) taps of the
-//     K-step: 9 + 9 fragment reads for 81 MFMAs (NTP = 3).  Tiles therefore partition H along z (no z halo in H) and P along x, y; P carries a z halo of
-//     one voxel (zero outside the volume), H an (x, y) halo
-//   * one wave per SIMD owns ALL 27 taps of its 16-channel chunk of H: 27 x NPW accumulator tiles (324 / 216 registers) live in registers over every
-//     tile of the persistent workgroup, the fragment reads of tap t + 1 are issued in front of the MFMAs of tap t, the P fragments of the next K-step
-//     during the last three taps of the current one; nothing inside a stage waits on memory
-//   * tile = 2 x 4 columns x 32 z-voxels: each H column of a 16-channel chunk is exactly one 1 KiB LDS-DMA row ([z][32 bytes]: the transpose reads
-//     ds_read_b64_tr_b16 of 8 consecutive voxels hit 8 different 32-byte bank groups), P rows are 96 bytes (48 channels) or padded to 160 (64 channels):
-//     an odd number of 32-byte groups, conflict-free for every z shift.  Both operands of a tile arrive by LDS-DMA in one of two buffers while the other
-//     is multiplied (one `s_waitcnt vmcnt(0)` + one s_barrier per tile)
+//     K-step: 9 + 9 fragment reads for 81 MFMAs (NTP = 3).  Work items therefore partition H along z (no z halo in H) and P along x, y; P carries a z
+//     halo of one voxel (zero outside the volume)
+//   * one wave per SIMD owns ALL 27 taps of its 16-channel chunk of H: 27 x NPW accumulator tiles (324 / 216 registers) live in registers over the whole
+//     launch, the fragment reads of tap t + 2 are issued in front of the MFMAs of tap t, the P fragments of the next K-step during the last three taps of
+//     the current one; nothing inside a step waits on memory
+//   * MARCH ALONG x: a workgroup owns a strip (8 rows of y x 32 voxels of z) and walks x.  A plane of H — (8 + 2) columns of 32 voxels x 16 channels =
+//     10 KiB per chunk, each column exactly one 1 KiB LDS-DMA row ([z][32 bytes]: the transpose reads ds_read_b64_tr_b16 of 8 consecutive voxels hit 8
+//     different 32-byte bank groups) — is fetched ONCE into a ring of four planes and multiplied in three consecutive steps (dx = +1, 0, -1); the plane
+//     of P (8 columns x 34 rows of 96 bytes, or 160 for 64 channels: an odd number of 32-byte groups, conflict-free for every z shift) is double
+//     buffered.  Per step 46 KiB arrive (1.25x the H bytes, 1.06x the P bytes of the step) against 74 KiB for a 2x4x32 tile with its halo (the first
+//     version of this kernel: LDS-DMA bound at 0.44 ms on the 96 -> 48 layer, as fast as wgrad_kernel).  The DMAs of the next step are issued one per
+//     tap inside the MFMA stream; one `s_waitcnt vmcnt(0)` + one s_barrier per step
 //   * the four waves of a workgroup are (P half) x (H chunk) x (K-step share); workgroups of chunk class c own the chunks [c*CG, (c+1)*CG); the classes of
-//     a tile run on the same XCD at about the same time (P comes from that L2), every (XCD, class) group walks a contiguous tile range
+//     a strip run on the same XCD at about the same time (P comes from that L2); every workgroup walks a contiguous run of (strip, x) steps
 //   * partial sums leave as slabs in wgrad_kernel's layout and are summed in a fixed order by its reduce launch (run-to-run bit-identical)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
-constexpr int CW_TX = 2, CW_TY = 4, CW_TZ = 32;
-constexpr int CW_HX = CW_TX + 2, CW_HY = CW_TY + 2;
-constexpr int CW_HCOLS = CW_HX * CW_HY;  // 24 halo columns, 1 KiB each per 16-channel chunk
-constexpr int CW_NCOL = CW_TX * CW_TY;   // 8 columns = 8 K-steps per tile
+constexpr int CW_TY = 8, CW_TZ = 32;
+constexpr int CW_HY = CW_TY + 2;         // halo columns of a plane, 1 KiB each per 16-channel chunk
+constexpr int CW_RING = 4;               // planes x - 1, x, x + 1 of the current step + plane x + 2 in flight
 constexpr int CW_PROWS = CW_TZ + 2;      // P column with its z halo
 constexpr int cw_prow(int ntp) { return (ntp & 1) ? ntp * 32 : ntp * 32 + 32; }  // bytes per P voxel row in LDS: an odd number of 32-byte groups
-constexpr int cw_pdrows(int ntp) { return (CW_NCOL * CW_PROWS * (cw_prow(ntp) / 16) + 63) / 64; }
-constexpr int cw_buf_bytes(int ntp, int cg) { return cg * CW_HCOLS * 1024 + cw_pdrows(ntp) * 1024; }
+constexpr int cw_pdrows(int ntp) { return (CW_TY * CW_PROWS * (cw_prow(ntp) / 16) + 63) / 64; }
+constexpr int cw_lds_bytes(int ntp, int cg) { return CW_RING * cg * CW_HY * 1024 + 2 * cw_pdrows(ntp) * 1024; }
 
 struct CwK {
   const char* p;
@@ -42,15 +45,15 @@ struct CwK {
   const char* h1;       // part 1 of a two-part H, biased by -csplit channels (== h0 for an ordinary tensor)
   int h_split_chunk;    // first 16-channel chunk that lives in part 1
   int p_vox_bytes, h_vox_bytes;
-  int X, Y, Z, ntx, nty, ntz;
-  unsigned mg_ty, mg_tx, mg_tz;
-  int ncls, pow2, gpc;  // chunk classes; class map (see cw_class); workgroups per class
+  int X, Y, Z, nty, ntz;
+  unsigned mg_x, mg_ty, mg_tz;
+  int ncls, pow2;       // chunk classes; class map (see cw_class)
   int hchunks, slab_chunk;
-  const void* zeros;
+  const char* zeros;    // >= 16 KiB of zeros
   float* slab;
   float* bias_slab;
-  int tstart[8][8];     // first tile of the (XCD, class) group
-  int tcnt[8][8];       // its tile count
+  int fstart[8][8];     // first (strip, x) step of the (XCD, class) group
+  int fcnt[8][8];       // its step count
   short gsz[8][8];      // its workgroups
 };
 
@@ -61,10 +64,21 @@ __host__ __device__ inline int cw_class(int L, int ncls, int pow2) { return pow2
 __host__ __device__ inline int cw_widx(int L, int ncls, int pow2) { return pow2 ? ((L >> 3) / ncls) * 8 + (L & 7) : L / ncls; }
 
 typedef __attribute__((address_space(3))) bf16x4 cw_lds_b4;
-__device__ __forceinline__ bf16x8 cw_frag(const char* a, int second) {  // two transpose reads: voxels 4g .. 4g+3 and 16 + 4g .. of the lane's channel
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cw_lds_b4*)(a));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cw_lds_b4*)(a + second));
+__device__ __forceinline__ void cw_dma16_v(const void* gsrc, unsigned lds_wave_base) {  // per-lane 64-bit source (vsseg_dma16 with an integer LDS address)
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory", "m0");
+}
+// LDS addresses are carried as 32-bit integers: a generic pointer that went through a select makes hipcc (ROCm 7.2) emit the generic -> LDS null check as
+// `v_cmp_ne_u32 0, src_shared_base`, which its own verifier rejects ("Operand has incorrect register class")
+__device__ __forceinline__ bf16x8 cw_frag(unsigned a, int second) {  // two transpose reads: voxels 4g .. 4g+3 and 16 + 4g .. of the lane's channel
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cw_lds_b4*)(uintptr_t)(a));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cw_lds_b4*)(uintptr_t)(a + (unsigned)second));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// 16-byte LDS-DMA with a wave-uniform 64-bit base and a 32-bit lane offset (the H columns: no vector arithmetic per instruction)
+__device__ __forceinline__ void cw_dma16_s(const char* sbase, unsigned voff, unsigned lds_wave_base) {
+  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 
 // Compile-time loops: the accumulator index decides the register class of an MFMA below, so it must be a constant expression (not just unrollable).
@@ -88,42 +102,29 @@ template <bool AG, bool PAD> __device__ __forceinline__ void cw_mfma(f32x4& c, c
 __device__ __forceinline__ void cw_mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory"); }
 
 // NPW: 16-channel P tiles per wave; PS: waves a K-step's P tiles are split over; CG: 16-channel H chunks per workgroup (one per wave); the K-steps of a
-// tile are shared by KS = 4 / (PS * CG) waves
+// plane are shared by KS = 4 / (PS * CG) waves
 template <int NPW, int PS, int CG, bool BIAS, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   constexpr int KS = 4 / (PS * CG), NTP = NPW * PS, PROW = cw_prow(NTP), PPR = PROW / 16, PREAL = NTP * 2;
-  constexpr int PCOL = CW_PROWS * PROW, HBYTES = CG * CW_HCOLS * 1024, PSLOTS = CW_NCOL * CW_PROWS * PPR, PDROWS = cw_pdrows(NTP);
-  constexpr int BUF = cw_buf_bytes(NTP, CG), NPD = (PDROWS + 3) / 4, NHD = CG * CW_HCOLS / 4, NK = CW_NCOL / KS;
-  static_assert(KS >= 1 && KS * PS * CG == 4 && CW_TY % KS == 0, "wave roles");
+  constexpr int PCOL = CW_PROWS * PROW, HPLANE = CG * CW_HY * 1024, HBYTES = CW_RING * HPLANE, PSLOTS = CW_TY * CW_PROWS * PPR, PDROWS = cw_pdrows(NTP);
+  constexpr int PBUF = PDROWS * 1024, NPD = (PDROWS + 3) / 4, NHD = (CG * CW_HY + 3) / 4, NK = CW_TY / KS, NDMA = NHD + NPD;
+  static_assert(KS >= 1 && KS * PS * CG == 4 && CW_TY % KS == 0 && NDMA <= NK * 9 && NHD <= 6, "wave roles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned sm0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
   const int ps = wave % PS, cg = (wave / PS) % CG, ks = wave / (PS * CG);
   const int X = k.X, Y = k.Y, Z = k.Z;
 
-  // ---- which tiles: workgroup L runs on XCD L % 8; group (XCD, class) owns a contiguous tile range and its workgroups stride through it ----
+  // ---- which steps: workgroup L runs on XCD L % 8; group (XCD, class) owns a contiguous range of the (strip, x) list, its workgroups contiguous parts ----
   const int L = blockIdx.x, xcd = L & 7, cls = cw_class(L, k.ncls, k.pow2), widx = cw_widx(L, k.ncls, k.pow2);
   int rank = 0;
   for (int l2 = xcd; l2 < L; l2 += 8) rank += cw_class(l2, k.ncls, k.pow2) == cls;
-  const int gsz = k.gsz[xcd][cls], t_first = k.tstart[xcd][cls], t_cnt = k.tcnt[xcd][cls];
-  const int my_tiles = t_cnt > rank ? (t_cnt - 1 - rank) / gsz + 1 : 0;
-  struct Tile { int n, x0, y0, z0; };
-  auto tile_of = [&](int i) {  // tile order (n, z, x, y), y fastest: the tiles in flight on an XCD are (x, y) neighbours, which share halo columns
-    unsigned b = (unsigned)(t_first + rank + i * gsz);
-    Tile t;
-    unsigned q = cw_div(b, k.mg_ty); t.y0 = (int)(b - q * k.nty) * CW_TY; b = q;
-    q = cw_div(b, k.mg_tx); t.x0 = (int)(b - q * k.ntx) * CW_TX; b = q;
-    q = cw_div(b, k.mg_tz); t.z0 = (int)(b - q * k.ntz) * CW_TZ; t.n = (int)q;
-    return t;
-  };
+  const int gsz = k.gsz[xcd][cls];
+  const int64_t gcnt = k.fcnt[xcd][cls];
+  const int f_lo = k.fstart[xcd][cls] + (int)(gcnt * rank / gsz), f_hi = k.fstart[xcd][cls] + (int)(gcnt * (rank + 1) / gsz);
 
-  // ---- LDS-DMA tables.  H: column j = i*4 + wave of the CG x 24 halo columns; lane -> (z = lane >> 1, 16-byte half of the chunk) ----
+  // ---- LDS-DMA tables.  H: column j = i*4 + wave of the CG x 10 plane columns; lane -> (z = lane >> 1, 16-byte half of the chunk) ----
   const unsigned h_lane = (unsigned)(lane >> 1) * (unsigned)k.h_vox_bytes + (unsigned)(lane & 1) * 16u;
-  int hcol[NHD];  // hx | hy << 8 | chunk-in-group << 16 (wave-uniform)
-#pragma unroll
-  for (int i = 0; i < NHD; ++i) {
-    const int j = i * 4 + wave, c = j / CW_HCOLS, hc = j - c * CW_HCOLS;
-    hcol[i] = __builtin_amdgcn_readfirstlane((hc / CW_HY) | ((hc % CW_HY) << 8) | (c << 16));
-  }
   // P: slot j = (u*4 + wave)*64 + lane of [column][row 0..33][PPR 16-byte slots]; padding slots are never written
   int prel[NPD];
   unsigned pflags = 0;  // 2 bits per u: 0 interior row, 1 row z0 - 1, 2 row z0 + 32, 3 no piece
@@ -132,29 +133,55 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
     const int j = (u * 4 + wave) * 64 + lane;
     const int c = j / (CW_PROWS * PPR), rem = j - c * (CW_PROWS * PPR), row = rem / PPR, pc = rem - row * PPR;
     const bool real = j < PSLOTS && pc < PREAL;
-    prel[u] = real ? (((c / CW_TY) * Y + (c % CW_TY)) * Z + row - 1) * k.p_vox_bytes + pc * 16 : 0;
+    prel[u] = real ? (c * Z + row - 1) * k.p_vox_bytes + pc * 16 : 0;
     pflags |= (unsigned)(!real ? 3 : (row == 0 ? 1 : (row == CW_PROWS - 1 ? 2 : 0))) << (2 * u);
   }
 
-  auto issue = [&](const Tile& t, int buf) {
-    char* Hdst = smem + buf * BUF;
-    char* Pdst = Hdst + HBYTES;
+  // ---- LDS-DMA addressing.  Everything wave-uniform lives in scalar registers: per H column one 64-bit scalar add + two selects, no vector arithmetic ----
+  int hconst[NHD];      // byte offset of this wave's column u inside a plane of its H part: hy * Z * vox + chunk * 32
+  unsigned hbits = 0;   // per u: bits [4u, 4u+4) = hy (0..9); bit 24 + u: the column's chunk lives in part 1
+  const int hys = Z * k.h_vox_bytes;
 #pragma unroll
-    for (int i = 0; i < NHD; ++i) {
-      const int hx = hcol[i] & 255, hy = (hcol[i] >> 8) & 255, c = hcol[i] >> 16;
-      const int gx = t.x0 - 1 + hx, gy = t.y0 - 1 + hy, chunk = cls * CG + c;
-      const bool ok = ((unsigned)gx < (unsigned)X) & ((unsigned)gy < (unsigned)Y);  // wave-uniform: the zero padding of the convolution comes from the zero page
-      const char* base = (chunk >= k.h_split_chunk ? k.h1 : k.h0) + ((((int64_t)t.n * X + gx) * Y + gy) * Z + t.z0) * k.h_vox_bytes + chunk * 32;
-      vsseg_dma16(ok ? (const void*)(base + h_lane) : k.zeros, Hdst + (i * 4 + wave) * 1024);
+  for (int u = 0; u < NHD; ++u) {
+    const int q = u * 4 + wave, c = q / CW_HY, hy = q - c * CW_HY, chunk = cls * CG + c;
+    hconst[u] = __builtin_amdgcn_readfirstlane(hy * hys + chunk * 32);
+    hbits |= (unsigned)hy << (4 * u);
+    hbits |= (chunk >= k.h_split_chunk ? 1u : 0u) << (24 + u);
+  }
+  hbits = __builtin_amdgcn_readfirstlane(hbits);
+  const int64_t hxs = (int64_t)Y * hys, pxs = (int64_t)Y * Z * k.p_vox_bytes;  // bytes per x plane of H / P
+  // run state (wave-uniform): plane 0 of the strip, biased to row y0 - 1 (H) / y0 (P) and voxel z0
+  const char *hrun0 = nullptr, *hrun1 = nullptr, *prun = nullptr;
+  unsigned colmask = 0, s_edge = 0;  // valid rows of the halo; z borders of the volume
+  // Operand piece u of plane xx: u < NHD: H column (u*4 + wave), ring slot xx & 3;  else P piece row, buffer xx & 1.  hp0 / hp1 / pp: plane xx of the run's
+  // H parts / of P.  REGISTER PATH: a 16-byte global load per lane now, one ds_write_b128 later (ld / st below).  The first two versions used LDS-DMA
+  // (global_load_lds): each such instruction held its wave for ~85 cycles of a CU-wide serial resource — 48 per step, issued from the MFMA stream,
+  // cost their full 0.12 ms on top of the 0.31 ms of the MFMAs (measured: H only + 0.06, P only + 0.06, neither 0.31) — the MFMA wave IS the loader here,
+  // there is no second wave per SIMD to take the stall.  Ordinary loads pipeline; the data waits in 4 registers per piece.
+  // live = false sends every lane to the zero page (a step without a successor still executes its slots: no branch in the MFMA stream)
+  typedef unsigned cw_u32x4 __attribute__((ext_vector_type(4)));
+  auto ld = [&](auto uc, int xx, const char* hp0, const char* hp1, const char* pp, bool live) -> cw_u32x4 {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u < NHD) {
+      const bool ok = live & ((unsigned)xx < (unsigned)X) & (((colmask >> ((hbits >> (4 * u)) & 15u)) & 1u) != 0) & (CG * CW_HY % 4 == 0 || u * 4 + wave < CG * CW_HY);  // the zero padding of the convolution comes from the zero page
+      const char* base = (((hbits >> (24 + u)) & 1u) ? hp1 : hp0) + hconst[u];
+      return *reinterpret_cast<const cw_u32x4*>((ok ? base : k.zeros) + h_lane);
+    } else {
+      constexpr int v = u - NHD;
+      const unsigned f = (pflags >> (2 * v)) & 3u;
+      return *reinterpret_cast<const cw_u32x4*>((!live || f == 3u || (f & s_edge)) ? k.zeros : pp + prel[v]);
     }
-    const char* origin = k.p + ((((int64_t)t.n * X + t.x0) * Y + t.y0) * Z + t.z0) * k.p_vox_bytes;
-    const unsigned edge = (t.z0 == 0 ? 1u : 0u) | (t.z0 + CW_TZ == Z ? 2u : 0u);
-#pragma unroll
-    for (int u = 0; u < NPD; ++u) {
-      const int row = u * 4 + wave;
-      if (row >= PDROWS) break;  // wave-uniform
-      const unsigned f = (pflags >> (2 * u)) & 3u;
-      if (f != 3u) vsseg_dma16((f & edge) ? k.zeros : (const void*)(origin + prel[u]), Pdst + row * 1024);
+  };
+  typedef __attribute__((address_space(3))) cw_u32x4 cw_lds_u32x4;
+  auto st = [&](auto uc, int xx, const cw_u32x4& val) {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u < NHD) {
+      const int q = u * 4 + wave;
+      if (CG * CW_HY % 4 == 0 || q < CG * CW_HY) *(cw_lds_u32x4*)(uintptr_t)(sm0 + (unsigned)((xx & 3) * HPLANE + q * 1024 + lane * 16)) = val;
+    } else {
+      constexpr int v = u - NHD;
+      const int row = v * 4 + wave;
+      if ((PDROWS % 4 == 0 || row < PDROWS) && ((pflags >> (2 * v)) & 3u) != 3u) *(cw_lds_u32x4*)(uintptr_t)(sm0 + (unsigned)(HBYTES + (xx & 1) * PBUF + row * 1024 + lane * 16)) = val;
     }
   };
 
@@ -172,70 +199,142 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   // operand addressing: lane (g, l15) reads row 4g + (l15 >> 2) of a 4-voxel block, 4-channel group l15 & 3 (ds_read_b64_tr_b16 returns the lane's channel of
   // the four voxels); K-slot g*8 + j holds voxel 4g + j (j < 4) / 16 + 4g + (j - 4) of the K-step for both operands
   const int r4 = g * 4 + (l15 >> 2), qc = (l15 & 3) * 8;
-  const int h_lane_off = (cg * CW_HCOLS + ks) * 1024 + r4 * 32 + qc;
+  const int h_lane_off = (cg * CW_HY + ks) * 1024 + r4 * 32 + qc;
   const int p_lane_off = HBYTES + ks * PCOL + r4 * PROW + ps * NPW * 32 + qc;
-
   int exp_dummy = 0;
-  if (my_tiles > 0) issue(tile_of(0), 0);
-  for (int st = 0; st < my_tiles; ++st) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // tile st has landed for every wave; every wave is done with the other buffer
-    const char* Hs = smem + (st & 1) * BUF + h_lane_off;
-    const char* Ps = smem + (st & 1) * BUF + p_lane_off;
-    bf16x8 pa[2][3][NPW], hb[3];  // P fragments of this / the next K-step; H fragments: a ring, read two taps ahead
+
+  int f = f_lo;
+  while (f < f_hi) {
+    // ---- a run: consecutive x of one strip ----
+    unsigned b = (unsigned)f, qd = cw_div(b, k.mg_x);
+    const int x0 = (int)(b - qd * (unsigned)X);
+    b = qd;
+    qd = cw_div(b, k.mg_ty);
+    const int y0 = (int)(b - qd * k.nty) * CW_TY;
+    b = qd;
+    qd = cw_div(b, k.mg_tz);
+    const int z0 = (int)(b - qd * k.ntz) * CW_TZ, n = (int)qd;
+    s_edge = (z0 == 0 ? 1u : 0u) | (z0 + CW_TZ == Z ? 2u : 0u);
+    colmask = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-      for (int p = 0; p < NPW; ++p) pa[0][s][p] = cw_frag(Ps + s * PROW + p * 32, 16 * PROW);
-    // H fragment of the j-th (K-step, tap) pair of the stage
-    auto h_off = [](int j) { const int i = j / 9, t = j % 9; return ((((i * KS) / CW_TY) + t / 3) * CW_HY + ((i * KS) % CW_TY) + t % 3) * 1024; };
-    hb[0] = cw_frag(Hs + h_off(0), 512);
-    hb[1] = cw_frag(Hs + h_off(1), 512);
-    __builtin_amdgcn_sched_barrier(0);
-    if (st + 1 < my_tiles && (EXP != 1 || st < 1)) issue(tile_of(st + 1), (st + 1) & 1);  // behind the first fragment reads: its address arithmetic covers their latency
-    __builtin_amdgcn_sched_barrier(0);
-    cw_for<NK * 9>([&](auto jc) {
-      constexpr int j = decltype(jc)::value, i = j / 9, t = j % 9;
-      if constexpr (j + 2 < NK * 9 && EXP != 3) hb[(j + 2) % 3] = cw_frag(Hs + h_off(j + 2), 512);
-      if constexpr (i + 1 < NK && t >= 6 && EXP != 3) {  // the P fragments of the next K-step during the last three taps of this one
-#pragma unroll
-        for (int p = 0; p < NPW; ++p) pa[(i + 1) & 1][t - 6][p] = cw_frag(Ps + (i + 1) * KS * PCOL + (t - 6) * PROW + p * 32, 16 * PROW);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (BIAS && t == 4) {  // the centre tap's iteration carries the bias MFMAs (shift 0 = the tile's own voxels, each exactly once)
-#pragma unroll
-        for (int p = 0; p < NPW; ++p) {
-          if constexpr (ASM) cw_mfma<false, true>(accb[p], pa[i & 1][1][p], ones);
-          else accb[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[i & 1][1][p], ones, accb[p], 0, 0, 0);
-        }
-      }
-      cw_for<3 * NPW>([&](auto qc_) {
-        constexpr int q = decltype(qc_)::value, a = t * 3 * NPW + q;
-        const bf16x8& pa_q = pa[i & 1][q / NPW][q % NPW];
-        const bf16x8& hb_j = hb[j % 3];
-        if constexpr (EXP == 2) exp_dummy ^= (int)pa_q[0] ^ (int)hb_j[q & 7];
-        else if constexpr (ASM) cw_mfma<(a < NAG), q == 0>(acc[a], pa_q, hb_j);
-        else acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa_q, hb_j, acc[a], 0, 0, 0);
-      });
-      __builtin_amdgcn_sched_barrier(0);
+    for (int hy = 0; hy < CW_HY; ++hy) colmask |= ((unsigned)(y0 - 1 + hy) < (unsigned)Y ? 1u : 0u) << hy;
+    {
+      const int64_t hoff = ((((int64_t)n * X) * Y + (y0 - 1)) * Z + z0) * k.h_vox_bytes;
+      hrun0 = k.h0 + hoff;
+      hrun1 = k.h1 + hoff;
+      prun = k.p + ((((int64_t)n * X) * Y + y0) * Z + z0) * k.p_vox_bytes;
+    }
+    int nsteps = X - x0;
+    if (nsteps > f_hi - f) nsteps = f_hi - f;
+    f += nsteps;
+    __syncthreads();  // every wave is done with the previous run's planes
+    // prime: H planes x0 - 1, x0, x0 + 1 and P plane x0
+    cw_for<NHD>([&](auto uc) {
+      const cw_u32x4 a0 = ld(uc, x0 - 1, hrun0 + (x0 - 1) * hxs, hrun1 + (x0 - 1) * hxs, nullptr, true);
+      const cw_u32x4 a1 = ld(uc, x0, hrun0 + x0 * hxs, hrun1 + x0 * hxs, nullptr, true);
+      const cw_u32x4 a2 = ld(uc, x0 + 1, hrun0 + (x0 + 1) * hxs, hrun1 + (x0 + 1) * hxs, nullptr, true);
+      st(uc, x0 - 1, a0);
+      st(uc, x0, a1);
+      st(uc, x0 + 1, a2);
     });
+    cw_for<NPD>([&](auto vc) {
+      constexpr auto uc = std::integral_constant<int, NHD + decltype(vc)::value>{};
+      st(uc, x0, ld(uc, x0, nullptr, nullptr, prun + x0 * pxs, true));
+    });
+    for (int sti = 0; sti < nsteps; ++sti) {
+      const int x = x0 + sti;
+      const bool more = sti + 1 < nsteps;
+      const char *hp0 = hrun0 + (x + 2) * hxs, *hp1 = hrun1 + (x + 2) * hxs, *pp = prun + (x + 1) * pxs;  // the next step's planes (scalar)
+      __syncthreads();  // planes x - 1 .. x + 1 of H and plane x of P are in LDS for every wave; every wave is done with step x - 1
+      cw_u32x4 stage[NDMA];  // the next step's pieces on their way through the registers
+      const unsigned Hs[3] = {sm0 + (unsigned)(((x - 1) & 3) * HPLANE + h_lane_off), sm0 + (unsigned)((x & 3) * HPLANE + h_lane_off), sm0 + (unsigned)(((x + 1) & 3) * HPLANE + h_lane_off)};
+      const unsigned Ps = sm0 + (unsigned)((x & 1) * PBUF + p_lane_off);
+      bf16x8 pa[3][NPW], hb[3];  // P fragments of the K-step (refilled for the next one behind their last MFMA); H fragments: a ring, read two taps ahead
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int p = 0; p < NPW; ++p) pa[s][p] = cw_frag(Ps + s * PROW + p * 32, 16 * PROW);
+      // H fragment of the j-th (K-step i, tap t) pair of the step: plane dx = t / 3, column i*KS (+ ks) + dy
+      auto h_frag = [&](auto jc) { constexpr int j = decltype(jc)::value, i = j / 9, t = j % 9; return cw_frag(Hs[t / 3] + (i * KS + t % 3) * 1024, 512); };
+      hb[0] = h_frag(std::integral_constant<int, 0>{});
+      hb[1] = h_frag(std::integral_constant<int, 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      cw_for<NK * 9>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, i = j / 9, t = j % 9;
+        if constexpr (j + 2 < NK * 9 && EXP != 3) hb[(j + 2) % 3] = h_frag(std::integral_constant<int, (j + 2 < NK * 9 ? j + 2 : 0)>{});
+        // the next step's operands, H plane x + 2 and P plane x + 1: one load per tap in the first taps, one LDS store per tap in the last ones
+        if constexpr (j < NDMA && EXP != 1) stage[j < NDMA ? j : 0] = ld(std::integral_constant<int, (j < NDMA ? j : 0)>{}, j < NHD ? x + 2 : x + 1, hp0, hp1, pp, more);
+        if constexpr (j >= NK * 9 - NDMA && EXP != 1) {
+          constexpr int u = j - (NK * 9 - NDMA);
+          st(std::integral_constant<int, u>{}, u < NHD ? x + 2 : x + 1, stage[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BIAS && t == 4) {  // the centre tap's iteration carries the bias MFMAs (shift 0 = the plane's own voxels, each exactly once)
+#pragma unroll
+          for (int p = 0; p < NPW; ++p) {
+            if constexpr (ASM) cw_mfma<false, true>(accb[p], pa[1][p], ones);
+            else accb[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][p], ones, accb[p], 0, 0, 0);
+          }
+        }
+        cw_for<3 * NPW>([&](auto qc_) {
+          constexpr int q = decltype(qc_)::value, a = t * 3 * NPW + q;
+          bf16x8& pa_q = pa[q / NPW][q % NPW];
+          const bf16x8& hb_j = hb[j % 3];
+          if constexpr (EXP == 2) exp_dummy ^= (int)pa_q[0] ^ (int)hb_j[q & 7];
+          else if constexpr (ASM) cw_mfma<(a < NAG), q == 0>(acc[a], pa_q, hb_j);
+          else acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa_q, hb_j, acc[a], 0, 0, 0);
+          if constexpr (t == 8 && i + 1 < NK && EXP != 3) {  // last tap: this P fragment is dead — refill it for the next K-step (used 3 * NPW MFMAs from now)
+            __builtin_amdgcn_sched_barrier(0);
+            pa_q = cw_frag(Ps + (i + 1) * KS * PCOL + (q / NPW) * PROW + (q % NPW) * 32, 16 * PROW);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
   }
   if constexpr (ASM) cw_mfma_drain();
   if (EXP == 2 && exp_dummy == 0x12345) k.slab[0] = 1.f;
 
-  // ---- flush: this wave's accumulators -> its slab [tap][cP][16 channels of its chunk] (wgrad_kernel's layout: slab index = workgroup-of-class * KS + K share) ----
+  // ---- flush.  The KS waves that share a chunk hold partial sums of the same tiles: they meet in LDS first (tile group o goes to the wave with K share o,
+  //      which adds the others' copies in share order), so a workgroup leaves ONE slab, and every tile leaves as one coalesced 1 KiB store (a lane's four
+  //      values = 16 bytes).  The first version stored 4-byte values into wgrad_kernel's [tap][cP][16] layout, one slab per K share: 85 MB per launch of the
+  //      96 -> 48 layer in 64-byte fragments, 0.06 ms of a 0.42 ms launch.
+  constexpr int GT = (NACC + KS - 1) / KS;  // tiles per owner
+  typedef __attribute__((address_space(3))) f32x4 cw_lds_f4;
+  if constexpr (KS > 1) {
+    cw_for<KS>([&](auto oc) {
+      constexpr int o = decltype(oc)::value;
+      __syncthreads();  // the operand planes (first round) / the previous round's copies are no longer read
+      if (ks != o) {
+        const int sender = (ps * CG + cg) * (KS - 1) + (ks < o ? ks : ks - 1);
+        cw_for<GT>([&](auto ic) {
+          constexpr int a = o * GT + decltype(ic)::value;
+          if constexpr (a < NACC) *(cw_lds_f4*)(uintptr_t)(sm0 + (unsigned)(((sender * GT + decltype(ic)::value) * 64 + lane) * 16)) = acc[a];
+        });
+      }
+      __syncthreads();
+      if (ks == o) {
+        cw_for<GT>([&](auto ic) {
+          constexpr int a = o * GT + decltype(ic)::value;
+          if constexpr (a < NACC) {
+#pragma unroll
+            for (int sdr = 0; sdr < KS - 1; ++sdr) acc[a] += *(cw_lds_f4*)(uintptr_t)(sm0 + (unsigned)(((((ps * CG + cg) * (KS - 1) + sdr) * GT + decltype(ic)::value) * 64 + lane) * 16));
+          }
+        });
+      }
+    });
+  }
+  // slab of the workgroup: [chunk][tap][P tile][64 lanes][4]; lane (g, l15), value r = element (cP = tile*16 + g*4 + r, cH = chunk*16 + l15)
   const int chunk = cls * CG + cg;
-  float* slab = k.slab + (((int64_t)widx * KS + ks) * k.hchunks + chunk) * k.slab_chunk;
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int tap = t * 3 + (2 - s);  // P shifted by s - 1 pairs P[z' - dz] with H[z']: dz = 1 - s
-#pragma unroll
-      for (int p = 0; p < NPW; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[((int64_t)tap * (NTP * 16) + (ps * NPW + p) * 16 + g * 4 + r) * 16 + l15] = acc[(t * 3 + s) * NPW + p][r];
+  float* slab = k.slab + ((int64_t)widx * k.hchunks + chunk) * k.slab_chunk + lane * 4;
+  cw_for<NACC>([&](auto ic) {
+    constexpr int a = decltype(ic)::value, t = a / (3 * NPW), sft = (a / NPW) % 3, p = a % NPW;
+    if (KS == 1 || a / GT == ks) {
+      const int tap = t * 3 + (2 - sft);  // P shifted by sft - 1 pairs P[z' - dz] with H[z']: dz = 1 - sft
+      *reinterpret_cast<f32x4*>(slab + (tap * NTP + ps * NPW + p) * 256) = acc[a];
     }
+  });
   if constexpr (BIAS) {
     if (cls == 0 && cg == 0 && l15 == 0) {
       float* brow = k.bias_slab + ((int64_t)widx * KS + ks) * (NTP * 16);
@@ -247,7 +346,23 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   }
 }
 
+// dw[cp][ch][tap] += sum over the workgroups' slabs (vsseg_slab_sum: 64 elements x 16 slab lanes per block, fixed summation order); element e of a slab =
+// (chunk, tap, P tile, lane, r) as the flush wrote it
+__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void cwgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int hchunks, int ntp, int slab_chunk, vsseg_wgrad_desc d) {
+  __shared__ float lds[VSSEG_SLAB_THREADS];
+  const int64_t total = (int64_t)hchunks * slab_chunk;
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const float s = vsseg_slab_sum(slab, total, i, nslab, lds);
+  if (threadIdx.x >= 64 || i >= total) return;
+  const int chunk = (int)(i / slab_chunk), e = (int)(i - (int64_t)chunk * slab_chunk);
+  const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8, ptile = tile % ntp, tap = tile / ntp;
+  const int cp = ptile * 16 + (lane >> 4) * 4 + r, ch = chunk * 16 + (lane & 15);
+  if (cp >= d.cp_valid || ch >= d.ch_valid) return;
+  d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[tap] * d.stride_tap] += s;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
+constexpr int CW_ZERO_BYTES = 16384;
 static const char* cw_check(const vsseg_wgrad_desc* d) {
   if (d->p.dtype != VSSEG_BF16 || d->h.dtype != VSSEG_BF16) return "operands are not bf16";
   if (d->ntaps != 27) return "3x3x3 taps only";
@@ -256,7 +371,7 @@ static const char* cw_check(const vsseg_wgrad_desc* d) {
   for (int a = 0; a < 3; ++a)
     if (d->hs[a] != 1) return "stride-1 lattices only";
   if (d->q[0] != d->p.x || d->q[1] != d->p.y || d->q[2] != d->p.z || d->q[0] != d->h.x || d->q[1] != d->h.y || d->q[2] != d->h.z || d->p.n != d->h.n) return "lattice, P and H extents differ";
-  if (d->q[0] % CW_TX || d->q[1] % CW_TY || d->q[2] % CW_TZ) return "extent is not a multiple of the 2x4x32 tile";
+  if (d->q[1] % CW_TY || d->q[2] % CW_TZ) return "y / z extent is not a multiple of the 8 x 32 strip";
   if (d->ntp != 3 && d->ntp != 4) return "P must have 48 or 64 channels";
   if (d->p.c != d->ntp * 16 || d->cp_valid != d->p.c || d->p.ptr2) return "P channels must be ntp x 16, one part";
   if (d->p.pitch % 8 || ((uintptr_t)d->p.ptr & 15)) return "P must be 16-byte aligned voxel rows";
@@ -269,7 +384,8 @@ static const char* cw_check(const vsseg_wgrad_desc* d) {
   if (d->ntp == 4 && cg != 1) return "64 P channels: hgroup must be 1";
   if ((d->h.c / 16) % cg) return "hgroup must divide the number of 16-channel H chunks";
   if ((d->h.c / 16) / cg > 8) return "more than 8 chunk classes";
-  if ((int64_t)d->p.n * d->q[0] * d->q[1] * d->q[2] / (CW_TX * CW_TY * CW_TZ) >= (1ll << 24)) return "too many tiles";
+  if ((int64_t)d->p.n * d->q[0] * d->q[1] * d->q[2] / (CW_TY * CW_TZ) >= (1ll << 24)) return "too many steps";
+  if (d->h.pitch * 2 * 31 + 16 > CW_ZERO_BYTES) return "H pitch too large for the zero page";
   return nullptr;
 }
 
@@ -281,14 +397,12 @@ template <int NPW, int PS, int CG, bool BIAS, int EXP = 0> static int cw_launch_
     hipFuncSetAttribute(reinterpret_cast<const void*>(&cwgrad_kernel<NPW, PS, CG, BIAS, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((cwgrad_kernel<NPW, PS, CG, BIAS, EXP>), dim3((unsigned)grid), dim3(256), 2 * cw_buf_bytes(NPW * PS, CG), s, k);
+  hipLaunchKernelGGL((cwgrad_kernel<NPW, PS, CG, BIAS, EXP>), dim3((unsigned)grid), dim3(256), cw_lds_bytes(NPW * PS, CG), s, k);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel)");
   return VSSEG_OK;
 }
 
-int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, int hchunks, int slab_chunk, hipStream_t s);  // wgrad.hip
-
-int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_t s) {
+int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStream_t s) {
   const char* why = cw_check(d);
   if (why) { vsseg_set_error("vsseg_wgrad: march = 2 (compute kernel) not applicable: %s", why); return VSSEG_EINVAL; }
   VSSEG_CHECK(d->scratch, "vsseg_wgrad: no scratch");
@@ -302,51 +416,62 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* zeros, hipStream_
   k.p_vox_bytes = d->p.pitch * 2;
   k.h_vox_bytes = d->h.pitch * 2;
   k.X = d->q[0]; k.Y = d->q[1]; k.Z = d->q[2];
-  k.ntx = k.X / CW_TX; k.nty = k.Y / CW_TY; k.ntz = k.Z / CW_TZ;
-  k.mg_tx = magic(k.ntx); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);
-  const int tiles = d->p.n * k.ntx * k.nty * k.ntz;
+  k.nty = k.Y / CW_TY; k.ntz = k.Z / CW_TZ;
+  k.mg_x = magic(k.X); k.mg_ty = magic(k.nty); k.mg_tz = magic(k.ntz);
+  const int steps = d->p.n * k.nty * k.ntz * k.X;  // (strip, x) list, x fastest
   k.hchunks = d->h.c / 16;
   k.ncls = k.hchunks / cg;
   k.pow2 = (k.ncls & (k.ncls - 1)) == 0;
   k.slab_chunk = 27 * d->ntp * 16 * 16;
-  // workgroups per class: one workgroup per CU over all classes, never more than tiles, and what the scratch holds (ksh slabs per workgroup, + a bias row)
+  // workgroups per class: one workgroup per CU over all classes, and what the scratch holds (ksh slabs per workgroup, + a bias row)
   int gpc = 256 / k.ncls;
   if (k.pow2) gpc &= ~7;  // whole rounds of the 8 XCDs (cw_widx)
-  const int64_t per_wg = (int64_t)ksh * ((int64_t)k.hchunks * k.slab_chunk + (d->dbias_p ? d->ntp * 16 : 0));
+  const int64_t per_wg = (int64_t)k.hchunks * k.slab_chunk + (d->dbias_p ? ksh * d->ntp * 16 : 0);  // one slab per workgroup (+ a bias row per K share)
   const int64_t cap = d->scratch_elems / per_wg;
   if (gpc > cap) gpc = k.pow2 ? (int)(cap & ~7ll) : (int)cap;
   if (d->persistent_blocks > 0 && gpc > d->persistent_blocks) gpc = k.pow2 ? (d->persistent_blocks & ~7) : d->persistent_blocks;
-  VSSEG_CHECK(gpc >= (k.pow2 ? 8 : 1), "vsseg_wgrad: scratch too small for the compute kernel (%lld floats per workgroup)", (long long)per_wg);
-  k.gpc = gpc;
+  VSSEG_CHECK(gpc >= (k.pow2 ? 8 : 1), "vsseg_wgrad: compute kernel: scratch (%lld floats per workgroup) or persistent_blocks allow fewer than %d workgroups per class", (long long)per_wg, k.pow2 ? 8 : 1);
   const int G = gpc * k.ncls;
-  // (XCD, class) groups: sizes by enumeration, tile ranges proportional to the sizes (every tile exactly once per class)
+  // (XCD, class) groups: sizes by enumeration, step ranges proportional to the sizes (every step exactly once per class)
   int gs[8][8] = {};
   for (int L = 0; L < G; ++L) ++gs[L & 7][cw_class(L, k.ncls, k.pow2)];
   for (int c = 0; c < k.ncls; ++c) {
     int64_t seen = 0;
     for (int x = 0; x < 8; ++x) {
-      const int64_t lo = (int64_t)tiles * seen / gpc;
+      const int64_t lo = (int64_t)steps * seen / gpc;
       seen += gs[x][c];
-      const int64_t hi = (int64_t)tiles * seen / gpc;
-      k.tstart[x][c] = (int)lo;
-      k.tcnt[x][c] = (int)(hi - lo);
+      const int64_t hi = (int64_t)steps * seen / gpc;
+      k.fstart[x][c] = (int)lo;
+      k.fcnt[x][c] = (int)(hi - lo);
       k.gsz[x][c] = (short)(gs[x][c] > 0 ? gs[x][c] : 1);
     }
   }
-  k.zeros = zeros;
+  {
+    static void* zpage[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    VSSEG_CHECK(dev >= 0 && dev < 16, "vsseg_wgrad: device index");
+    if (!zpage[dev] && (hipMalloc(&zpage[dev], CW_ZERO_BYTES) != hipSuccess || hipMemset(zpage[dev], 0, CW_ZERO_BYTES) != hipSuccess)) zpage[dev] = nullptr;
+    VSSEG_CHECK(zpage[dev], "vsseg_wgrad: could not allocate the zero page");
+    k.zeros = reinterpret_cast<const char*>(zpage[dev]);
+  }
   k.slab = d->scratch;
-  k.bias_slab = d->dbias_p ? d->scratch + (int64_t)gpc * ksh * k.hchunks * k.slab_chunk : nullptr;
+  k.bias_slab = d->dbias_p ? d->scratch + (int64_t)gpc * k.hchunks * k.slab_chunk : nullptr;
   int rc;
   const bool b = d->dbias_p != nullptr;
   if (d->ntp == 3 && cg == 1) rc = b ? cw_launch_inst<3, 1, 1, true>(k, G, s) : cw_launch_inst<3, 1, 1, false>(k, G, s);
   else if (d->ntp == 3 && !b && getenv("VSSEG_CW_EXP")) {
     const int e = atoi(getenv("VSSEG_CW_EXP"));
-    rc = e == 1 ? cw_launch_inst<3, 1, 2, false, 1>(k, G, s) : e == 2 ? cw_launch_inst<3, 1, 2, false, 2>(k, G, s) : e == 3 ? cw_launch_inst<3, 1, 2, false, 3>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
+    rc = e == 1 ? cw_launch_inst<3, 1, 2, false, 1>(k, G, s) : e == 2 ? cw_launch_inst<3, 1, 2, false, 2>(k, G, s) : e == 3 ? cw_launch_inst<3, 1, 2, false, 3>(k, G, s) : e == 4 ? cw_launch_inst<3, 1, 2, false, 4>(k, G, s) : e == 5 ? cw_launch_inst<3, 1, 2, false, 5>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   } else if (d->ntp == 3) rc = b ? cw_launch_inst<3, 1, 2, true>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   else rc = b ? cw_launch_inst<2, 2, 1, true>(k, G, s) : cw_launch_inst<2, 2, 1, false>(k, G, s);
   if (rc) return rc;
-  rc = vsseg_wgrad_reduce_launch(d, d->scratch, gpc * ksh, k.hchunks, k.slab_chunk, s);
-  if (rc || !d->dbias_p) return rc;
+  {
+    const int total = k.hchunks * k.slab_chunk;
+    hipLaunchKernelGGL(cwgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)d->scratch, gpc, k.hchunks, d->ntp, k.slab_chunk, *d);
+    VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel, reduce)");
+  }
+  if (!d->dbias_p) return VSSEG_OK;
   hipLaunchKernelGGL(vsseg_slab_add_kernel, dim3((d->ntp * 16 + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)k.bias_slab, gpc * ksh, d->ntp * 16, d->cp_valid, d->dbias_p);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel, bias)");
   return VSSEG_OK;
