@@ -36,8 +36,8 @@ constexpr int CW_HY = CW_TY + 2;         // halo columns of a plane, 1 KiB each 
 constexpr int CW_RING = 4;               // planes x - 1, x, x + 1 of the current step + plane x + 2 in flight
 constexpr int CW_PROWS = CW_TZ + 2;      // P column with its z halo
 constexpr int cw_prow(int ntp) { return (ntp & 1) ? ntp * 32 : ntp * 32 + 32; }  // bytes per P voxel row in LDS: an odd number of 32-byte groups
-constexpr int cw_pdrows(int ntp) { return (CW_TY * CW_PROWS * (cw_prow(ntp) / 16) + 63) / 64; }
-constexpr int cw_lds_bytes(int ntp, int cg) { return CW_RING * cg * CW_HY * 1024 + 2 * cw_pdrows(ntp) * 1024; }
+constexpr int cw_nhd(int cg) { return (cg * CW_HY + 3) / 4; }  // H columns per wave and plane
+constexpr int cw_lds_bytes(int ntp, int cg) { return CW_RING * cw_nhd(cg) * 4 * 1024 + 2 * CW_TY * CW_PROWS * cw_prow(ntp); }
 
 struct CwK {
   const char* p;
@@ -64,10 +64,6 @@ __host__ __device__ inline int cw_class(int L, int ncls, int pow2) { return pow2
 __host__ __device__ inline int cw_widx(int L, int ncls, int pow2) { return pow2 ? ((L >> 3) / ncls) * 8 + (L & 7) : L / ncls; }
 
 typedef __attribute__((address_space(3))) bf16x4 cw_lds_b4;
-__device__ __forceinline__ void cw_dma16_v(const void* gsrc, unsigned lds_wave_base) {  // per-lane 64-bit source (vsseg_dma16 with an integer LDS address)
-  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(lds), "v"(gsrc) : "memory", "m0");
-}
 // LDS addresses are carried as 32-bit integers: a generic pointer that went through a select makes hipcc (ROCm 7.2) emit the generic -> LDS null check as
 // `v_cmp_ne_u32 0, src_shared_base`, which its own verifier rejects ("Operand has incorrect register class")
 __device__ __forceinline__ bf16x8 cw_frag(unsigned a, int second) {  // two transpose reads: voxels 4g .. 4g+3 and 16 + 4g .. of the lane's channel
@@ -75,12 +71,6 @@ __device__ __forceinline__ bf16x8 cw_frag(unsigned a, int second) {  // two tran
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cw_lds_b4*)(uintptr_t)(a + (unsigned)second));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-// 16-byte LDS-DMA with a wave-uniform 64-bit base and a 32-bit lane offset (the H columns: no vector arithmetic per instruction)
-__device__ __forceinline__ void cw_dma16_s(const char* sbase, unsigned voff, unsigned lds_wave_base) {
-  const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");
-}
-
 // Compile-time loops: the accumulator index decides the register class of an MFMA below, so it must be a constant expression (not just unrollable).
 template <typename F, int... I> __device__ __forceinline__ void cw_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F> __device__ __forceinline__ void cw_for(F&& f) { cw_for_impl(f, std::make_integer_sequence<int, N>{}); }
@@ -105,10 +95,10 @@ __device__ __forceinline__ void cw_mfma_drain() { asm volatile("s_nop 7\n\ts_nop
 // plane are shared by KS = 4 / (PS * CG) waves
 template <int NPW, int PS, int CG, bool BIAS, int EXP = 0>
 __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
-  constexpr int KS = 4 / (PS * CG), NTP = NPW * PS, PROW = cw_prow(NTP), PPR = PROW / 16, PREAL = NTP * 2;
-  constexpr int PCOL = CW_PROWS * PROW, HPLANE = CG * CW_HY * 1024, HBYTES = CW_RING * HPLANE, PSLOTS = CW_TY * CW_PROWS * PPR, PDROWS = cw_pdrows(NTP);
-  constexpr int PBUF = PDROWS * 1024, NPD = (PDROWS + 3) / 4, NHD = (CG * CW_HY + 3) / 4, NK = CW_TY / KS, NDMA = NHD + NPD;
-  static_assert(KS >= 1 && KS * PS * CG == 4 && CW_TY % KS == 0 && NDMA <= NK * 9 && NHD <= 6, "wave roles");
+  constexpr int KS = 4 / (PS * CG), NTP = NPW * PS, PROW = cw_prow(NTP), PREAL = NTP * 2;
+  constexpr int PCOL = CW_PROWS * PROW, NHD = cw_nhd(CG), HPLANE = NHD * 4 * 1024, HBYTES = CW_RING * HPLANE, PBUF = CW_TY * PCOL;
+  constexpr int NPI = CW_TY * CW_TZ * PREAL / 256, NPD = NPI + 1, NK = CW_TY / KS, NDMA = NHD + NPD, NTAP = NK * 9, PHALO = CW_TY * PREAL;
+  static_assert(KS >= 1 && KS * PS * CG == 4 && CW_TY % KS == 0 && NDMA <= NTAP && NHD <= 6 && (CW_TY * CW_TZ * PREAL) % 256 == 0 && PHALO <= 64, "wave roles");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned sm0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = lane >> 4, l15 = lane & 15;
@@ -123,21 +113,14 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   const int64_t gcnt = k.fcnt[xcd][cls];
   const int f_lo = k.fstart[xcd][cls] + (int)(gcnt * rank / gsz), f_hi = k.fstart[xcd][cls] + (int)(gcnt * (rank + 1) / gsz);
 
-  // ---- LDS-DMA tables.  H: column j = i*4 + wave of the CG x 10 plane columns; lane -> (z = lane >> 1, 16-byte half of the chunk) ----
+  // ---- operand pieces (16 bytes per lane), NDMA per wave and step.  REGISTER PATH: a global load now, a ds_write_b128 a whole step later.  The first
+  //      versions used LDS-DMA (global_load_lds): each such instruction held its wave for ~85 cycles of a CU-wide serial resource — 48 per step, issued
+  //      from the MFMA stream, cost their full 0.12 ms on top of the 0.31 ms of the MFMAs (measured: H only + 0.06, P only + 0.06, neither 0.31): the MFMA
+  //      wave IS the loader here, there is no second wave per SIMD to take the stall.  And every instruction between two MFMA groups is a bubble for the
+  //      one wave of the SIMD: a piece costs a scalar select + one load, and one vector add + one store, placed between the MFMAs of a tap.
+  //   H piece u < NHD: column q = u*4 + wave of the plane's CG x 10 columns; lane -> (voxel z = lane >> 1, 16-byte half of the chunk): scalar base + lane offset
   const unsigned h_lane = (unsigned)(lane >> 1) * (unsigned)k.h_vox_bytes + (unsigned)(lane & 1) * 16u;
-  // P: slot j = (u*4 + wave)*64 + lane of [column][row 0..33][PPR 16-byte slots]; padding slots are never written
-  int prel[NPD];
-  unsigned pflags = 0;  // 2 bits per u: 0 interior row, 1 row z0 - 1, 2 row z0 + 32, 3 no piece
-#pragma unroll
-  for (int u = 0; u < NPD; ++u) {
-    const int j = (u * 4 + wave) * 64 + lane;
-    const int c = j / (CW_PROWS * PPR), rem = j - c * (CW_PROWS * PPR), row = rem / PPR, pc = rem - row * PPR;
-    const bool real = j < PSLOTS && pc < PREAL;
-    prel[u] = real ? (c * Z + row - 1) * k.p_vox_bytes + pc * 16 : 0;
-    pflags |= (unsigned)(!real ? 3 : (row == 0 ? 1 : (row == CW_PROWS - 1 ? 2 : 0))) << (2 * u);
-  }
-
-  // ---- LDS-DMA addressing.  Everything wave-uniform lives in scalar registers: per H column one 64-bit scalar add + two selects, no vector arithmetic ----
+  const unsigned h_st = sm0 + (unsigned)(wave * 1024 + lane * 16);  // + slot * HPLANE + u * 4096
   int hconst[NHD];      // byte offset of this wave's column u inside a plane of its H part: hy * Z * vox + chunk * 32
   unsigned hbits = 0;   // per u: bits [4u, 4u+4) = hy (0..9); bit 24 + u: the column's chunk lives in part 1
   const int hys = Z * k.h_vox_bytes;
@@ -149,39 +132,60 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
     hbits |= (chunk >= k.h_split_chunk ? 1u : 0u) << (24 + u);
   }
   hbits = __builtin_amdgcn_readfirstlane(hbits);
+  //   P piece v < NPI: piece (v*4 + wave)*64 + lane of the plane's interior [column][row 1..32][real 16-byte pieces]: no condition at all;
+  //   v == NPI: the z halo — wave 0: row 0 (voxel z0 - 1), wave 1: row 33 (z0 + 32) of every column, zeros at the volume's z borders (wave-uniform)
+  unsigned prel[NPD], plds[NPD];  // byte offset inside the P plane in memory (from voxel (y0, z0 - 1)) / inside the LDS buffer
+#pragma unroll
+  for (int v = 0; v < NPD; ++v) {
+    int c, row, pc;
+    if (v < NPI) {
+      const int j = (v * 4 + wave) * 64 + lane;
+      c = j / (CW_TZ * PREAL);
+      const int rem = j - c * (CW_TZ * PREAL);
+      row = 1 + rem / PREAL;
+      pc = rem % PREAL;
+    } else {
+      const int j = lane < PHALO ? lane : PHALO - 1;
+      c = j / PREAL;
+      pc = j % PREAL;
+      row = wave == 0 ? 0 : CW_PROWS - 1;
+    }
+    prel[v] = (unsigned)((c * Z + row) * k.p_vox_bytes + pc * 16);
+    plds[v] = sm0 + (unsigned)(HBYTES + c * PCOL + row * PROW + pc * 16);
+  }
   const int64_t hxs = (int64_t)Y * hys, pxs = (int64_t)Y * Z * k.p_vox_bytes;  // bytes per x plane of H / P
-  // run state (wave-uniform): plane 0 of the strip, biased to row y0 - 1 (H) / y0 (P) and voxel z0
+  // run state (wave-uniform): plane 0 of the strip, biased to row y0 - 1 (H) / row y0 (P) and voxel z0 (H) / z0 - 1 (P)
   const char *hrun0 = nullptr, *hrun1 = nullptr, *prun = nullptr;
   unsigned colmask = 0, s_edge = 0;  // valid rows of the halo; z borders of the volume
-  // Operand piece u of plane xx: u < NHD: H column (u*4 + wave), ring slot xx & 3;  else P piece row, buffer xx & 1.  hp0 / hp1 / pp: plane xx of the run's
-  // H parts / of P.  REGISTER PATH: a 16-byte global load per lane now, one ds_write_b128 later (ld / st below).  The first two versions used LDS-DMA
-  // (global_load_lds): each such instruction held its wave for ~85 cycles of a CU-wide serial resource — 48 per step, issued from the MFMA stream,
-  // cost their full 0.12 ms on top of the 0.31 ms of the MFMAs (measured: H only + 0.06, P only + 0.06, neither 0.31) — the MFMA wave IS the loader here,
-  // there is no second wave per SIMD to take the stall.  Ordinary loads pipeline; the data waits in 4 registers per piece.
-  // live = false sends every lane to the zero page (a step without a successor still executes its slots: no branch in the MFMA stream)
   typedef unsigned cw_u32x4 __attribute__((ext_vector_type(4)));
-  auto ld = [&](auto uc, int xx, const char* hp0, const char* hp1, const char* pp, bool live) -> cw_u32x4 {
+  typedef __attribute__((address_space(3))) cw_u32x4 cw_lds_u32x4;
+  // piece u of H plane xh (u < NHD) / of P plane xp (clamped into the volume by the caller: a plane nobody will read is still loaded, from valid memory)
+  auto ld = [&](auto uc, int xh, int xp, cw_u32x4& dst) {
     constexpr int u = decltype(uc)::value;
     if constexpr (u < NHD) {
-      const bool ok = live & ((unsigned)xx < (unsigned)X) & (((colmask >> ((hbits >> (4 * u)) & 15u)) & 1u) != 0) & (CG * CW_HY % 4 == 0 || u * 4 + wave < CG * CW_HY);  // the zero padding of the convolution comes from the zero page
-      const char* base = (((hbits >> (24 + u)) & 1u) ? hp1 : hp0) + hconst[u];
-      return *reinterpret_cast<const cw_u32x4*>((ok ? base : k.zeros) + h_lane);
+      if (CG * CW_HY % 4 != 0 && u * 4 + wave >= CG * CW_HY) return;  // wave-uniform: this wave has no column u
+      const bool ok = ((unsigned)xh < (unsigned)X) & (((colmask >> ((hbits >> (4 * u)) & 15u)) & 1u) != 0);  // the zero padding of the convolution comes from the zero page
+      const char* base = (((hbits >> (24 + u)) & 1u) ? hrun1 : hrun0) + xh * hxs + hconst[u];
+      dst = *reinterpret_cast<const cw_u32x4*>((ok ? base : k.zeros) + h_lane);
+    } else if constexpr (u < NHD + NPI) {
+      dst = *reinterpret_cast<const cw_u32x4*>(prun + xp * pxs + prel[u - NHD]);
     } else {
-      constexpr int v = u - NHD;
-      const unsigned f = (pflags >> (2 * v)) & 3u;
-      return *reinterpret_cast<const cw_u32x4*>((!live || f == 3u || (f & s_edge)) ? k.zeros : pp + prel[v]);
+      if (wave >= 2) return;  // wave-uniform
+      const bool zero = (s_edge >> wave) & 1u;
+      const char* base = zero ? k.zeros : prun + xp * pxs;
+      if (lane < PHALO) dst = *reinterpret_cast<const cw_u32x4*>(base + (zero ? (unsigned)lane * 16u : prel[NPI]));
     }
   };
-  typedef __attribute__((address_space(3))) cw_u32x4 cw_lds_u32x4;
-  auto st = [&](auto uc, int xx, const cw_u32x4& val) {
+  auto st = [&](auto uc, int xh, int xp, const cw_u32x4& val) {
     constexpr int u = decltype(uc)::value;
     if constexpr (u < NHD) {
-      const int q = u * 4 + wave;
-      if (CG * CW_HY % 4 == 0 || q < CG * CW_HY) *(cw_lds_u32x4*)(uintptr_t)(sm0 + (unsigned)((xx & 3) * HPLANE + q * 1024 + lane * 16)) = val;
+      if (CG * CW_HY % 4 != 0 && u * 4 + wave >= CG * CW_HY) return;
+      *(cw_lds_u32x4*)(uintptr_t)(h_st + (unsigned)((xh & 3) * HPLANE + u * 4096)) = val;
+    } else if constexpr (u < NHD + NPI) {
+      *(cw_lds_u32x4*)(uintptr_t)(plds[u - NHD] + (unsigned)((xp & 1) * PBUF)) = val;
     } else {
-      constexpr int v = u - NHD;
-      const int row = v * 4 + wave;
-      if ((PDROWS % 4 == 0 || row < PDROWS) && ((pflags >> (2 * v)) & 3u) != 3u) *(cw_lds_u32x4*)(uintptr_t)(sm0 + (unsigned)(HBYTES + (xx & 1) * PBUF + row * 1024 + lane * 16)) = val;
+      if (wave >= 2) return;
+      if (lane < PHALO) *(cw_lds_u32x4*)(uintptr_t)(plds[NPI] + (unsigned)((xp & 1) * PBUF)) = val;
     }
   };
 
@@ -202,6 +206,8 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   const int h_lane_off = (cg * CW_HY + ks) * 1024 + r4 * 32 + qc;
   const int p_lane_off = HBYTES + ks * PCOL + r4 * PROW + ps * NPW * 32 + qc;
   int exp_dummy = 0;
+  cw_u32x4 stage[NDMA];  // pieces on their way through the registers
+  cw_for<NDMA>([&](auto uc) { stage[decltype(uc)::value] = cw_u32x4{0u, 0u, 0u, 0u}; });
 
   int f = f_lo;
   while (f < f_hi) {
@@ -218,36 +224,36 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
     colmask = 0;
 #pragma unroll
     for (int hy = 0; hy < CW_HY; ++hy) colmask |= ((unsigned)(y0 - 1 + hy) < (unsigned)Y ? 1u : 0u) << hy;
-    {
-      const int64_t hoff = ((((int64_t)n * X) * Y + (y0 - 1)) * Z + z0) * k.h_vox_bytes;
-      hrun0 = k.h0 + hoff;
-      hrun1 = k.h1 + hoff;
-      prun = k.p + ((((int64_t)n * X) * Y + y0) * Z + z0) * k.p_vox_bytes;
-    }
+    hrun0 = k.h0 + ((((int64_t)n * X) * Y + (y0 - 1)) * Z + z0) * k.h_vox_bytes;
+    hrun1 = k.h1 + ((((int64_t)n * X) * Y + (y0 - 1)) * Z + z0) * k.h_vox_bytes;
+    prun = k.p + ((((int64_t)n * X) * Y + y0) * Z + (z0 - 1)) * k.p_vox_bytes;
     int nsteps = X - x0;
     if (nsteps > f_hi - f) nsteps = f_hi - f;
     f += nsteps;
+    const int xlast = X - 1;
     __syncthreads();  // every wave is done with the previous run's planes
-    // prime: H planes x0 - 1, x0, x0 + 1 and P plane x0
+    // prime through the same registers, two round trips: P plane x0 + H plane x0 - 1, then H planes x0 and x0 + 1 (the second in the P pieces' registers)
+    cw_for<NDMA>([&](auto uc) { ld(uc, x0 - 1, x0, stage[decltype(uc)::value]); });
+    cw_for<NDMA>([&](auto uc) { st(uc, x0 - 1, x0, stage[decltype(uc)::value]); });
+    static_assert(NPD >= NHD, "prime");
     cw_for<NHD>([&](auto uc) {
-      const cw_u32x4 a0 = ld(uc, x0 - 1, hrun0 + (x0 - 1) * hxs, hrun1 + (x0 - 1) * hxs, nullptr, true);
-      const cw_u32x4 a1 = ld(uc, x0, hrun0 + x0 * hxs, hrun1 + x0 * hxs, nullptr, true);
-      const cw_u32x4 a2 = ld(uc, x0 + 1, hrun0 + (x0 + 1) * hxs, hrun1 + (x0 + 1) * hxs, nullptr, true);
-      st(uc, x0 - 1, a0);
-      st(uc, x0, a1);
-      st(uc, x0 + 1, a2);
+      constexpr int u = decltype(uc)::value;
+      ld(uc, x0, 0, stage[u]);
+      ld(uc, x0 + 1, 0, stage[NHD + u]);
     });
-    cw_for<NPD>([&](auto vc) {
-      constexpr auto uc = std::integral_constant<int, NHD + decltype(vc)::value>{};
-      st(uc, x0, ld(uc, x0, nullptr, nullptr, prun + x0 * pxs, true));
+    cw_for<NHD>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      st(uc, x0, 0, stage[u]);
+      st(uc, x0 + 1, 0, stage[NHD + u]);
     });
+    // the pieces of step x0 + 1 (H plane x0 + 2, P plane x0 + 1) start their way through the registers: a load has a whole step to land
+    cw_for<NDMA>([&](auto uc) { ld(uc, x0 + 2, x0 + 1 < xlast ? x0 + 1 : xlast, stage[decltype(uc)::value]); });
     for (int sti = 0; sti < nsteps; ++sti) {
       const int x = x0 + sti;
-      const bool more = sti + 1 < nsteps;
-      const char *hp0 = hrun0 + (x + 2) * hxs, *hp1 = hrun1 + (x + 2) * hxs, *pp = prun + (x + 1) * pxs;  // the next step's planes (scalar)
+      const int xp2 = x + 2 < xlast ? x + 2 : xlast;  // P plane of the step after the next, clamped into the volume (scalar)
       __syncthreads();  // planes x - 1 .. x + 1 of H and plane x of P are in LDS for every wave; every wave is done with step x - 1
-      cw_u32x4 stage[NDMA];  // the next step's pieces on their way through the registers
-      const unsigned Hs[3] = {sm0 + (unsigned)(((x - 1) & 3) * HPLANE + h_lane_off), sm0 + (unsigned)((x & 3) * HPLANE + h_lane_off), sm0 + (unsigned)(((x + 1) & 3) * HPLANE + h_lane_off)};
+      unsigned Hs[3] = {sm0 + (unsigned)(((x - 1) & 3) * HPLANE + h_lane_off), sm0 + (unsigned)((x & 3) * HPLANE + h_lane_off), sm0 + (unsigned)(((x + 1) & 3) * HPLANE + h_lane_off)};
+      asm volatile("" : "+v"(Hs[0]), "+v"(Hs[1]), "+v"(Hs[2]));  // three address registers per step, immediates per read (hipcc otherwise adds a scalar slot offset in front of every read)
       const unsigned Ps = sm0 + (unsigned)((x & 1) * PBUF + p_lane_off);
       bf16x8 pa[3][NPW], hb[3];  // P fragments of the K-step (refilled for the next one behind their last MFMA); H fragments: a ring, read two taps ahead
 #pragma unroll
@@ -259,15 +265,10 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
       hb[0] = h_frag(std::integral_constant<int, 0>{});
       hb[1] = h_frag(std::integral_constant<int, 1>{});
       __builtin_amdgcn_sched_barrier(0);
-      cw_for<NK * 9>([&](auto jc) {
+      cw_for<NTAP>([&](auto jc) {
         constexpr int j = decltype(jc)::value, i = j / 9, t = j % 9;
-        if constexpr (j + 2 < NK * 9 && EXP != 3) hb[(j + 2) % 3] = h_frag(std::integral_constant<int, (j + 2 < NK * 9 ? j + 2 : 0)>{});
-        // the next step's operands, H plane x + 2 and P plane x + 1: one load per tap in the first taps, one LDS store per tap in the last ones
-        if constexpr (j < NDMA && EXP != 1) stage[j < NDMA ? j : 0] = ld(std::integral_constant<int, (j < NDMA ? j : 0)>{}, j < NHD ? x + 2 : x + 1, hp0, hp1, pp, more);
-        if constexpr (j >= NK * 9 - NDMA && EXP != 1) {
-          constexpr int u = j - (NK * 9 - NDMA);
-          st(std::integral_constant<int, u>{}, u < NHD ? x + 2 : x + 1, stage[u]);
-        }
+        constexpr int NQ = 3 * NPW, Q_ST = NQ / 3, Q_LD = 2 * NQ / 3;  // MFMAs of the tap; the piece's store / load sit behind MFMA Q_ST - 1 / Q_LD - 1
+        if constexpr (j + 2 < NTAP && EXP != 3) hb[(j + 2) % 3] = h_frag(std::integral_constant<int, (j + 2 < NTAP ? j + 2 : 0)>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BIAS && t == 4) {  // the centre tap's iteration carries the bias MFMAs (shift 0 = the plane's own voxels, each exactly once)
 #pragma unroll
@@ -276,12 +277,26 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
             else accb[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[1][p], ones, accb[p], 0, 0, 0);
           }
         }
-        cw_for<3 * NPW>([&](auto qc_) {
-          constexpr int q = decltype(qc_)::value, a = t * 3 * NPW + q;
+        cw_for<NQ>([&](auto qc_) {
+          constexpr int q = decltype(qc_)::value, a = t * NQ + q;
           bf16x8& pa_q = pa[q / NPW][q % NPW];
           const bf16x8& hb_j = hb[j % 3];
+          // operand pieces, one per tap in the first taps: the piece loaded during the previous step (H plane x + 2 / P plane x + 1, read from the next step
+          // on) goes to LDS, the same registers then take the piece of the step after (H plane x + 3 / P plane x + 2)
+          if constexpr (j < NDMA && EXP != 1 && (q == Q_ST || q == Q_LD)) {
+            constexpr auto uc = std::integral_constant<int, (j < NDMA ? j : 0)>{};
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (q == Q_ST) {
+              if constexpr (EXP == 6) exp_dummy ^= (int)stage[uc.value][0];
+              else st(uc, x + 2, x + 1, stage[uc.value]);
+            } else {
+              if constexpr (EXP == 7) stage[uc.value] = cw_u32x4{0u, 0u, 0u, 0u};
+              else ld(uc, x + 3, xp2, stage[uc.value]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if constexpr (EXP == 2) exp_dummy ^= (int)pa_q[0] ^ (int)hb_j[q & 7];
-          else if constexpr (ASM) cw_mfma<(a < NAG), q == 0>(acc[a], pa_q, hb_j);
+          else if constexpr (ASM) cw_mfma<(a < NAG), (q == 0 || (j < NDMA && (q == Q_ST || q == Q_LD)))>(acc[a], pa_q, hb_j);
           else acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa_q, hb_j, acc[a], 0, 0, 0);
           if constexpr (t == 8 && i + 1 < NK && EXP != 3) {  // last tap: this P fragment is dead — refill it for the next K-step (used 3 * NPW MFMAs from now)
             __builtin_amdgcn_sched_barrier(0);
@@ -294,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
     }
   }
   if constexpr (ASM) cw_mfma_drain();
-  if (EXP == 2 && exp_dummy == 0x12345) k.slab[0] = 1.f;
+  if ((EXP == 2 || EXP == 6) && exp_dummy == 0x12345) k.slab[0] = 1.f;
 
   // ---- flush.  The KS waves that share a chunk hold partial sums of the same tiles: they meet in LDS first (tile group o goes to the wave with K share o,
   //      which adds the others' copies in share order), so a workgroup leaves ONE slab, and every tile leaves as one coalesced 1 KiB store (a lane's four
@@ -462,7 +477,7 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
   if (d->ntp == 3 && cg == 1) rc = b ? cw_launch_inst<3, 1, 1, true>(k, G, s) : cw_launch_inst<3, 1, 1, false>(k, G, s);
   else if (d->ntp == 3 && !b && getenv("VSSEG_CW_EXP")) {
     const int e = atoi(getenv("VSSEG_CW_EXP"));
-    rc = e == 1 ? cw_launch_inst<3, 1, 2, false, 1>(k, G, s) : e == 2 ? cw_launch_inst<3, 1, 2, false, 2>(k, G, s) : e == 3 ? cw_launch_inst<3, 1, 2, false, 3>(k, G, s) : e == 4 ? cw_launch_inst<3, 1, 2, false, 4>(k, G, s) : e == 5 ? cw_launch_inst<3, 1, 2, false, 5>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
+    rc = e == 1 ? cw_launch_inst<3, 1, 2, false, 1>(k, G, s) : e == 2 ? cw_launch_inst<3, 1, 2, false, 2>(k, G, s) : e == 3 ? cw_launch_inst<3, 1, 2, false, 3>(k, G, s) : e == 6 ? cw_launch_inst<3, 1, 2, false, 6>(k, G, s) : e == 7 ? cw_launch_inst<3, 1, 2, false, 7>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   } else if (d->ntp == 3) rc = b ? cw_launch_inst<3, 1, 2, true>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   else rc = b ? cw_launch_inst<2, 2, 1, true>(k, G, s) : cw_launch_inst<2, 2, 1, false>(k, G, s);
   if (rc) return rc;

@@ -1007,14 +1007,21 @@ class Plan:
             if eng.es == 2 and not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1) and d.h.c == Lr.cin and (d.p.c in (8, 16, 32) or pc2) and not d.p.ptr2:
                 mtiles = P.march_wgrad_tiles(Lr.cin, 8 if pc2 else d.p.c, wg.q, self.n, scr.numel())
             assert mtiles or not pc2
+            # the compute kernel (csrc/cwgrad.hip, march = 2) on the MFMA-bound stride-1 3x3x3 layers of levels 2-3: H chunks per workgroup (hgroup) 1 or 2
+            cgs = []
+            if (eng.compute_wgrad and eng.es == 2 and not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 3) and gl is None and not pc2 and d.p.c in (48, 64) and d.p.c == Lr.cout
+                    and d.h.c == Lr.cin and Lr.cin % 16 == 0 and wg.q[1] % 8 == 0 and wg.q[2] % 32 == 0 and not d.p.ptr2):
+                cgs = [g for g in ((2, 1) if d.p.c == 48 else (1,)) if hch % g == 0 and hch // g <= 8]
             live_tile = L.i3(wg.tile)
             if self.tune:  # measured per launch: {double-buffered DMA pipeline | one buffer} x H-chunk group x workgroups per CU, and the marching kernel's tiles
-                key = f"wgrad3|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}" + ("|gin" if gl is not None else "") + ("|c2" if pc2 else "")
+                key = f"wgrad{4 if cgs else 3}|w{tuple(Lr.wshape)}|T{int(Lr.transposed)}|q{wg.q}|n{self.n}|es{self.eng.es}|two{int(bool(d.h.ptr2))}|pc{d.p.c}" + ("|gin" if gl is not None else "") + ("|c2" if pc2 else "")
                 cache = _tune_cache()
                 if key in cache and os.environ.get("VSSEG_AUTOTUNE", "1") != "force":
                     hit = cache[key]
                     if hit[0] == "m":
                         d.march, live_tile = 1, L.i3(hit[1:4])
+                    elif hit[0] == "c":
+                        d.march, d.hgroup = 2, int(hit[1])
                     else:
                         d.single_buffer, d.hgroup, wpc = (int(v) for v in hit)
                     tuned = " tuned[cache]"
@@ -1051,24 +1058,32 @@ class Plan:
                     for mt in mtiles:
                         d.march, d.tile = 1, L.i3(mt)
                         ms[("m", *mt)] = measure()
+                    for g in cgs:
+                        d.march, d.hgroup, d.tile = 2, g, L.i3(wg.tile)
+                        set_blocks(4)
+                        ms[("c", g)] = measure()
                     d.dw, d.dbias_p, d.tile = live_dw, live_db, L.i3(wg.tile)
                     bestk = min(ms, key=ms.get)
                     if bestk[0] == "m":
                         d.march, live_tile = 1, L.i3(bestk[1:4])
+                    elif bestk[0] == "c":
+                        d.march, d.hgroup = 2, bestk[1]
                     else:
                         d.march = 0
                         d.single_buffer, d.hgroup, wpc = bestk
                     cache[key] = list(bestk)
                     _tune_cache.dirty = True
                     tuned = f" tuned[best of {len(ms)}: {min(ms.values()):.3f} ms, default {ms.get((0, hgs[0], 4), float('nan')):.3f}]"
+            elif cgs:  # untuned lowering: the compute kernel wherever it applies, two chunks per workgroup where they divide
+                d.march, d.hgroup = 2, cgs[0]
             elif gl is not None or pc2:  # untuned lowering of a gated H operand / a compact P: the marching kernel is the only one that reads them — its first tile
                 assert mtiles, "gate-on-load / a compact P was enabled for a layer without a marching weight-gradient tile"
                 d.march, live_tile = 1, L.i3(mtiles[0])
             d.tile = live_tile
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} " + (f"march tile={tuple(d.tile)}" if d.march else f"tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}") + tuned,
-                                                          name=(f"mwgrad<bf16,{wg.ntp}>" if d.march else f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>"), kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} " + (f"compute chunks/wg={d.hgroup}" if d.march == 2 else f"march tile={tuple(d.tile)}" if d.march else f"tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}") + tuned,
+                                                          name=(f"cwgrad<bf16,{wg.ntp}>" if d.march == 2 else f"mwgrad<bf16,{wg.ntp}>" if d.march else f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>"), kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
                 B.append([lib.vsseg_channel_sum, [L.Tensor(dy.ptr, dy.dtype, Lr.cout, dy.pitch, dy.n, dy.x, dy.y, dy.z), self._gp(Lr.bkey)]])
@@ -1427,6 +1442,7 @@ class Engine:
         self.class_split = os.environ.get("VSSEG_CLASS_SPLIT", "1") != "0"  # ... of the stride-(2,2,2) transitions as one launch of the general kernel (planner.class_split_plans)
         self.fuse_classes = os.environ.get("VSSEG_FUSE_CLASSES", "1") != "0" and not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
+        self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
         self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
         # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip): "0" = off, "1" = every
