@@ -41,6 +41,9 @@ def bench_name(short_name):
     m = re.match(r"wgrad_kernel<(bf16|float), (\d+), (\d+)(, \d+)?>", short_name)  # MAXT / H-group variants of one (type, NTP) share a bench name
     if m:
         return f"wgrad<{'bf16' if m.group(1) == 'bf16' else 'f32'},{m.group(3)}>"
+    m = re.match(r"cwgrad_kernel<(\d+), (\d+), ", short_name)  # compute weight gradient (3x3x3 stride-1 layers): bench name by the P tiles (NPW x PS)
+    if m:
+        return f"cwgrad<bf16,{int(m.group(1)) * int(m.group(2))}>"
     if short_name.startswith("wgrad_narrow_kernel"):
         return "wgrad_narrow"
     m = re.match(r"chain_kernel<(\d+),", short_name)  # chained marching convolution (inference): input channels of its first stage
