@@ -205,7 +205,7 @@ typedef struct {
   int32_t tz;              /* plan: z voxels per workgroup column (1, 2, 4 or 8; in.z a multiple) */
   int32_t mtw;             /* ... 16-voxel M-tiles per wave: a workgroup owns ALL rows, in.y == waves * mtw * 16 / tz */
   int32_t lx;              /* ... x positions per workgroup (a segment re-fetches 4 input planes and recomputes 2 planes of h) */
-  int32_t waves;           /* ... waves per workgroup: 4 or 8 */
+  int32_t waves;           /* ... waves per workgroup: 4, 8 or 16 */
   int32_t lead;            /* ... iterations between the fetch of an input plane and its use: 1 (several small workgroups per CU) or 3 (one large one; always 3 for a compact input) */
 } vsseg_chain_desc;
 int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);

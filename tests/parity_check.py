@@ -36,7 +36,14 @@ from tests.helpers import load, synth_input, synth_label
 # BatchNorm channels (worst: single bottleneck channels, 768 voxels per channel); the fp32 mode gives 2e-5 / 4e-4.  A WRONG gradient — a PReLU branch decided on another
 # tensor, a keep-mask that does not match the forward's, a dropped residual term — moves these ratios by O(0.1 .. 1): the bars (1e-2 slopes, 1e-1 BatchNorm) sit a
 # factor 10 under that and a factor 2 over the bf16 noise; `prelu_over_2e-3` lists the slopes above the tighter 2e-3.
-BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4, prelu_err_over_terms_worst=1e-2, bn_err_over_terms_worst=1e-1)
+# Round 6 (VERDICT round 5 / ADVICE): the two sum-of-terms bars sit at 1.5x the measured bf16 values (slopes 4.7e-3 at batch 4, 6.1e-3 at batch 1, 2.0e-3 at 384x384x64 -> 7e-3;
+# BatchNorm channels 4.7e-2 -> 7e-2); they are REQUIRED (a golden without `gabs:*` fields, or a metric block that was skipped, fails: it does not pass by absence); and the sign
+# agreement of the slopes is a hard floor again next to them (measured 0.85-0.88; below 0.75 two more slopes have flipped).
+BARS = dict(loss_abs=2e-2, logits_rel_l2=3e-2, att_max_abs=5e-2, grad_cos=0.97, grad_rel_l2_median=0.12, grad_rel_l2_worst=0.4, prelu_err_over_terms_worst=7e-3, bn_err_over_terms_worst=7e-2,
+            prelu_sign_agreement=0.75)
+# the fp32 compute mode against the same goldens (bench.py's fp32 parity block, tests/test_gpu_network.py): measured 2.2e-5 (slopes) / 4.4e-4 (BatchNorm channels)
+BARS_FP32 = dict(loss_abs=2e-5, logits_rel_l2=1e-4, att_max_abs=2e-4, grad_cos=0.9999, grad_rel_l2_median=3e-3, grad_rel_l2_worst=1.5e-1, prelu_err_over_terms_worst=1e-4, bn_err_over_terms_worst=2e-3,
+                 prelu_sign_agreement=0.95)
 
 
 def golden_train_case(name="net_train_b1_384x128x128.npz"):
@@ -125,7 +132,22 @@ def train_step_metrics(model, loss_fn, batch: int = 1, golden: str = "net_train_
     return out
 
 
+REQUIRED = ("loss_abs", "logits_rel_l2", "att_max_abs", "grad_cos", "grad_rel_l2_median", "grad_rel_l2_worst", "prelu_err_over_terms_worst", "bn_err_over_terms_worst", "prelu_sign_agreement")
+
+
+def failures(m: Dict[str, float], bars=BARS):
+    """The bars `m` misses, as (name, measured or None, bar).  Every bar of REQUIRED must be present in both `m` and `bars`: a metric that was not computed (a golden
+    without the `gabs:*` sums, a skipped block) is a failure, not a pass."""
+    out = []
+    for k in REQUIRED:
+        if k not in bars:
+            out.append((k, m.get(k), None))
+        elif k not in m or not np.isfinite(m[k]):
+            out.append((k, None, bars[k]))
+        elif (m[k] < bars[k]) if k in ("grad_cos", "prelu_sign_agreement") else (m[k] > bars[k]):
+            out.append((k, m[k], bars[k]))
+    return out
+
+
 def passes(m: Dict[str, float], bars=BARS) -> bool:
-    return (m["loss_abs"] <= bars["loss_abs"] and m["logits_rel_l2"] <= bars["logits_rel_l2"] and m["att_max_abs"] <= bars["att_max_abs"] and m["grad_cos"] >= bars["grad_cos"]
-            and m["grad_rel_l2_median"] <= bars["grad_rel_l2_median"] and m["grad_rel_l2_worst"] <= bars["grad_rel_l2_worst"]
-            and m.get("prelu_err_over_terms_worst", 0.0) <= bars.get("prelu_err_over_terms_worst", float("inf")) and m.get("bn_err_over_terms_worst", 0.0) <= bars.get("bn_err_over_terms_worst", float("inf")))
+    return not failures(m, bars)

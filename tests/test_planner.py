@@ -268,3 +268,26 @@ def test_chained_launch_plans_cover_the_benchmark_window_and_nothing_else():
         assert real.size == int(np.prod(wshape)) and len(set(real.tolist())) == real.size  # every weight element exactly once
     rm = P.residual_tile_pack_map(16, 2, (32, 16, 1, 1, 1))
     assert rm.size == 1 * 2 * 64 * 8 and (rm >= 0).sum() == 32 * 16
+
+
+@pytest.mark.parametrize("kind,k,st,cin,cout,fine", [("convT_fwd", (3, 3, 3), (2, 2, 2), 96, 80, (8, 8, 8)), ("conv_dgrad", (3, 3, 3), (2, 2, 2), 80, 80, (16, 8, 16)),
+                                                     ("convT_fwd", (3, 3, 1), (2, 2, 1), 48, 32, (8, 8, 4)), ("conv_dgrad", (3, 3, 3), (2, 2, 2), 64, 64, (8, 4, 8))])
+def test_deep_class_plans_mirror_the_kernels_lds_request(kind, k, st, cin, cout, fine):
+    """planner.deep_lds_bytes mirrors dc_check() of csrc/dconv.hip also for the all-classes launches, whose K-group table has one section per parity class
+    (the planner sized it for one class; the untuned VSSEG_DEEP=force lowering could then be refused by the kernel)."""
+    import ctypes
+
+    from tests import gpu_harness as H
+    from vs_seg_amd import _lib as L
+
+    lib = L.lib()
+    coarse = tuple(f // s for f, s in zip(fine, st))
+    wshape = (cin, cout, *k) if kind == "convT_fwd" else (cout, cin, *k)
+    kc, nreal = (cin, cout) if kind == "convT_fwd" else (cout, cin)
+    plans = P.deep_class_plans(kind, wshape, k, st, coarse, 2, kc, nreal, nreal, 1)
+    assert plans, "no all-classes plan for a level 3-5 transition"
+    for pl in plans:
+        inp = L.Tensor(4096, L.BF16, kc, kc, 1, *coarse)
+        out = L.Tensor(8192, L.BF16, pl.nt * 16, pl.nt * 16, 1, *fine)
+        d = H.igemm_desc(pl, torch.zeros(1), inp, out)
+        assert lib.vsseg_igemm_lds_bytes(ctypes.byref(d)) == pl.lds, (pl.tile, pl.mtw, pl.nt, len(pl.classes), lib.vsseg_last_error())

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 template <int NT, int MODE> static int cc_launch_mode(const CconvK& k, int nsplit, hipStream_t s) {
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {}; bool& attr_set = vsseg_dev_once(attr_set_dev);  // per device: the LDS opt-in is a per-device function attribute
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&cconv_kernel<NT, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;

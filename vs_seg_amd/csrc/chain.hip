@@ -413,7 +413,7 @@ template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD, in
   return (CC ? 5 : 3 + LEAD + (NR ? 1 : 0)) * WIA * 1024 + CH_HR * PB + (3 * CM + 5 * NTB * 16) * 4 + 16;
 }
 template <int CIN, int CM, int NTB, int TZ, int MT, int CC, int NW, int LEAD, int NR> static int ch_launch(const ChainK& k, int grid, hipStream_t s) {
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = ch_lds<CIN, CM, NTB, TZ, MT, CC, NW, LEAD, NR>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&chain_kernel<CIN, CM, NTB, TZ, MT, CC, NW, LEAD, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -462,7 +462,7 @@ static const ChEntry* ch_find(const vsseg_chain_desc* d, const char** why) {
   if (d->act_b < VSSEG_ACT_NONE || d->act_b > VSSEG_ACT_SIGMOID) return no("act_b");
   if (d->act_a != VSSEG_ACT_NONE && d->act_a != VSSEG_ACT_PRELU && d->act_a != VSSEG_ACT_RELU) return no("act_a");
   if ((d->tz != 1 && d->tz != 2 && d->tz != 4 && d->tz != 8) || d->mtw < 1 || (d->waves != 4 && d->waves != 8 && d->waves != 16) || d->in.y != d->waves * d->mtw * 16 / d->tz || d->in.z % d->tz || d->lx < 1)
-    return no("plan: 4 or 8 waves, y must be waves * mtw * 16 / tz rows, z a multiple of tz, lx >= 1");
+    return no("plan: 4, 8 or 16 waves, y must be waves * mtw * 16 / tz rows, z a multiple of tz, lx >= 1");
   for (const ChEntry& e : ch_table)
     if (e.cin == cin && e.cm == d->cmid && e.ntb == ntb && e.nr == d->res_tiles && e.tz == d->tz && e.mt == d->mtw && e.cc == (c1 ? 1 : 0) && e.nw == d->waves && e.lead == d->lead) return e.lds() <= 160 * 1024 ? &e : no("more than 160 KB of LDS");
   return no("no instantiation for this (channels, tz, mtw, waves, lead)");

@@ -256,6 +256,14 @@ static __global__ __launch_bounds__(VSSEG_SLAB_THREADS) void vsseg_slab_add_kern
 // instead of on eight different ones (PMC: the gate map was fetched 8x, r03_pmc_hbm.txt).  Identity when the grid is not a multiple of 8.
 __device__ __forceinline__ int vsseg_xcd_contiguous(int b, int grid) { return (grid & 7) == 0 ? (b & 7) * (grid >> 3) + (b >> 3) : b; }
 
+// The once-flag of a launcher for the CURRENT device (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device function attribute: a process-wide flag
+// left the opt-in for more than 64 KiB of LDS unapplied on a second device of the same process)
+static inline bool& vsseg_dev_once(bool (&flags)[16]) {
+  static bool never;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { never = false; return never; }
+  return flags[dev];
+}
 static inline int64_t tensor_voxels(const vsseg_tensor& t) { return (int64_t)t.n * t.x * t.y * t.z; }
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid_for(int64_t work_items, int block, int cap = 256 * 16) {

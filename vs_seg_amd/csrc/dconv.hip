@@ -243,12 +243,12 @@ __global__ __launch_bounds__(DC_THREADS) void dconv_kernel(const DconvK k) {
   // ================= prologue: everything that touches memory is issued first =================
   const int nks0 = (k.ntaps * k.cgs + 3) >> 2;
   const int cnt0 = nks0 > wave ? (nks0 - 1 - wave) / DC_WAVES + 1 : 0;   // one class: K-steps wave, wave + 4, ...
-  const int cl_first = classes ? kp->wave_cls[wave][0] : 0;
   const int ncls_w = classes ? kp->wave_ncls[wave] : 0;
+  const int cl_first = ncls_w ? kp->wave_cls[wave][0] : 0;  // (a wave without a class — 2 or 3 classes over 4 waves — preloads nothing: count 0 below)
   DC_MARK(1);
   issue_halo(0);
   if (!classes) k_preload(k.wpack + ((int64_t)(row0 * k.nchunks) * k.ksteps + wave) * (NT * 1024) + lane * 16, (int64_t)DC_WAVES * NT * 1024, cnt0);
-  else k_preload(k.wpack + (int64_t)cl_first * k.ksteps * (NT * 1024) + lane * 16, (int64_t)NT * 1024, (__shfl(cnt_l, cl_first) * k.cgs + 3) >> 2);
+  else k_preload(k.wpack + (int64_t)cl_first * k.ksteps * (NT * 1024) + lane * 16, (int64_t)NT * 1024, ncls_w ? (__shfl(cnt_l, cl_first) * k.cgs + 3) >> 2 : 0);
   if (tid < NT * 16) { epi[tid] = e_bias; epi[NT * 16 + tid] = e_scale; epi[2 * NT * 16 + tid] = e_shift; }
   // K-group tables: K-group p = ks*4 + g of a class -> (tap p / cgs, channel group p % cgs) -> byte offset inside the halo relative to the voxel
   {
@@ -522,7 +522,7 @@ int vsseg_dconv_lds_bytes(const vsseg_igemm_desc* d) {
 }
 
 template <int MT, int NT> static int dc_launch(const DconvK& k, dim3 grid, int lds, hipStream_t s) {
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {}; bool& attr_set = vsseg_dev_once(attr_set_dev);  // per device: the LDS opt-in is a per-device function attribute
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&dconv_kernel<MT, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
@@ -546,7 +546,7 @@ int vsseg_dconv_launch(const vsseg_igemm_desc* d, const void* zeros, hipStream_t
   DcGeom gm;
   const char* why = dc_check(d, gm);
   if (why) { vsseg_set_error("vsseg_igemm: depth -7 (deep-level kernel) not applicable: %s", why); return VSSEG_EINVAL; }
-  DconvK k;
+  DconvK k{};
   auto magic = [](int dv) { return dv <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)dv - 1) / (unsigned)dv); };
   k.in0 = reinterpret_cast<const char*>(d->in.ptr);
   k.in1 = d->in.ptr2 ? reinterpret_cast<const char*>(d->in.ptr2) - (int64_t)d->in.csplit * 2 : k.in0;

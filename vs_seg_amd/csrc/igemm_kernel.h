@@ -766,7 +766,7 @@ template <typename T, int NT, int MTW, int MODE, int KS = 0> static int launch_m
     if (k.d.ksteps == 14 && !k.d.class_split) return launch_mode<T, NT, MTW, MODE, 14>(k, grid, lds, s);  // (class_split: the K-step count differs per workgroup row)
     if (k.d.ksteps == 7 && !k.d.class_split) return launch_mode<T, NT, MTW, MODE, 7>(k, grid, lds, s);
   }
-  static bool attr_set = false;
+  static bool attr_set_dev[16] = {}; bool& attr_set = vsseg_dev_once(attr_set_dev);  // per device: the LDS opt-in is a per-device function attribute
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<T, NT, MTW, MODE, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;

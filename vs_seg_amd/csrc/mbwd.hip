@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, mb_lds_bytes(CY, CX, TZ, MT, RES) > 80 * 1024 
 // ---- host side ------------------------------------------------------------------------------------------------------
 template <int CY, int CX, int TZ, int MT, int RES> static int mb_lds() { return mb_lds_bytes(CY, CX, TZ, MT, RES); }
 template <int CY, int CX, int TZ, int MT, bool US, int RES> static int mb_launch_r(const MbwdK& k, int grid, hipStream_t s) {
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mb_lds<CY, CX, TZ, MT, RES>();
   if (lds > 160 * 1024) { vsseg_set_error("vsseg_conv_bwd_fused: %d bytes of LDS", lds); return VSSEG_EINVAL; }
   if (!init) {
@@ -420,7 +420,7 @@ template <int CY, int CX, int TZ, int MT, bool US, int RES> static int mb_launch
   return VSSEG_OK;
 }
 template <int CY, int CX, int TZ, int MT, bool US> static int mb_launch_xg(const MbwdK& k, int grid, hipStream_t s) {  // x gated on load: the level-1 decoder unit (64 -> 32 + residual)
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mb_lds<CY, CX, TZ, MT, 1>();
   if (lds > 160 * 1024) { vsseg_set_error("vsseg_conv_bwd_fused: %d bytes of LDS", lds); return VSSEG_EINVAL; }
   if (!init) {

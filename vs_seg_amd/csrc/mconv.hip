@@ -498,7 +498,7 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds() {
   return lds > red ? lds : red;
 }
 template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG> static int mc_launch_mode(const MconvK& k, int grid, hipStream_t s) {
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mc_lds<CIN, NT, TZ, MT, WREG>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, WREG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -510,7 +510,7 @@ template <int CIN, int NT, int TZ, int MT, int MODE, bool WREG> static int mc_la
 }
 template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_launch_res(const MconvK& k, int grid, hipStream_t s) {  // + NR residual tiles: plain / statistics epilogues
   if (k.aux_mode) { vsseg_set_error("vsseg_igemm: residual tiles combine with the plain and the statistics epilogue only"); return VSSEG_EINVAL; }
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mc_lds<CIN, NT, TZ, MT, WREG>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -535,7 +535,7 @@ template <int CIN, int NT, int TZ, int MT, bool WREG, int NR> static int mc_laun
   return VSSEG_OK;
 }
 template <int CIN, int NT, int TZ, int MT, int MODE, int CC> static int mc_launch_c1_mode(const MconvK& k, int grid, hipStream_t s) {
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mc_lds<CIN, NT, TZ, MT, false>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, MODE, false, 0, CC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -564,7 +564,7 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_lds_ps() {  
 template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(const MconvK& k, int grid, hipStream_t s) {
   if constexpr ((CIN == 32 && NT == 4) || (CIN == 48 && NT == 8 && !WREG)) {  // the transposed convolutions: plain (eval) / statistics epilogue
     constexpr int TPC = NT / 4;
-    static bool init = false;
+    static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
     const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
     if (!init) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -578,7 +578,7 @@ template <int CIN, int NT, int TZ, int MT, bool WREG> static int mc_launch_ps(co
     return VSSEG_OK;
   } else if constexpr (((CIN == 16 && NT == 4) || (CIN == 32 && NT == 8)) && !WREG) {  // the data gradients of the strided convolutions: plain / accumulating epilogue
     constexpr int TPC = NT / 4;
-    static bool init = false;
+    static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
     const int lds = mc_lds_ps<CIN, NT, TZ, MT, WREG>();
     if (!init) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&mconv_kernel<CIN, NT, TZ, MT, 0, WREG, 0, 0, TPC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -321,7 +321,7 @@ template <int CH, int CP, int TZ, int MT> static int mw_lds() {
   return MW_NR * ((ROWS * TZ * (CH / 8) * 16 + 255) / 256 * 256) + 2 * ((TYB * TZ * (CP / 8) * 16 + 255) / 256 * 256);
 }
 template <int CH, int CP, int TZ, int MT, bool US, bool GIN> static int mw_launch_g(const MwgradK& k, int grid, hipStream_t s) {
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mw_lds<CH, CP, TZ, MT>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US, GIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -332,7 +332,7 @@ template <int CH, int CP, int TZ, int MT, bool US, bool GIN> static int mw_launc
   return VSSEG_OK;
 }
 template <int CH, int CP, int TZ, int MT, bool US> static int mw_launch_pc2(const MwgradK& k, int grid, hipStream_t s) {  // gated H + compact two-channel P: the logits convolution
-  static bool init = false;
+  static bool init_dev[16] = {}; bool& init = vsseg_dev_once(init_dev);  // per device: the LDS opt-in is a per-device function attribute
   const int lds = mw_lds<CH, CP, TZ, MT>();
   if (!init) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&mwgrad_kernel<CH, CP, TZ, MT, US, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

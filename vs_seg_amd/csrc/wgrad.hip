@@ -359,7 +359,7 @@ template <typename T, int MAXT, int NTP, int HG> static int wg_launch(WgradK& k,
     vsseg_set_error("vsseg_wgrad: maxt %d x ntp %d x hgroup %d accumulator tiles exceed the register budget", MAXT, NTP, HG);
     return VSSEG_EINVAL;
   } else {
-    static bool attr_set = false;
+    static bool attr_set_dev[16] = {}; bool& attr_set = vsseg_dev_once(attr_set_dev);  // per device: the LDS opt-in is a per-device function attribute
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<T, MAXT, NTP, HG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;

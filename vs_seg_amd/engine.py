@@ -392,8 +392,10 @@ class Plan:
                     ch.cached = True
                     return pl
         pl = self._autotune(ch, d)
-        if self.eng.deep == "1":  # (VSSEG_DEEP=0 / force are experiment modes: their restricted candidate lists must not overwrite the measured choices of the full list)
-            cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth]
+        # the choice always enters the IN-PROCESS cache: later plans of this process replay it, and under data parallel rank 0 broadcasts this cache so that every rank runs
+        # the same kernels.  VSSEG_DEEP=0 / force are experiment modes: their restricted candidate lists are never written to the cache FILE
+        cache[key] = [list(pl.tile), pl.nt, pl.nsplit, pl.ck, pl.depth]
+        if self.eng.deep == "1":
             _tune_cache.dirty = True
         return pl
 
@@ -506,8 +508,8 @@ class Plan:
                 best = min(best, e0.elapsed_time(e1))
             times.append(best)
         use = times[1] < times[0]
+        cache[key] = int(use)  # in-process always (every later plan and, under data parallel, every rank repeats the choice); the cache FILE only outside the experiment modes
         if self.eng.deep == "1":
-            cache[key] = int(use)
             _tune_cache.dirty = True
         self.class_split_ms = getattr(self, "class_split_ms", []) + [(key, times)]
         return use

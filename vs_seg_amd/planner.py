@@ -570,8 +570,8 @@ def deep_red_tiles(mt, nt):
     return mt * nt if mt * nt <= 24 else (mt * nt + 1) // 2
 
 
-def deep_lds_bytes(tile, is_, taps, ck, ksteps, mt, nt, classes: bool) -> int:
-    """Mirror of dc_check() in csrc/dconv.hip: K-group table | epilogue constants | statistics rows | halo (voxel stride padded to an odd number of 16-byte
+def deep_lds_bytes(tile, is_, taps, ck, ksteps, mt, nt, classes: int) -> int:
+    """Mirror of dc_check() in csrc/dconv.hip (`classes` = number of parity classes of the launch, 0 for an ordinary one): K-group table (one per class) | epilogue constants | statistics rows | halo (voxel stride padded to an odd number of 16-byte
     units) | the four waves' accumulator slabs (their own space when every parity class re-reads the halo, else the halo's)."""
     halo = 1
     for a in range(3):
@@ -579,7 +579,7 @@ def deep_lds_bytes(tile, is_, taps, ck, ksteps, mt, nt, classes: bool) -> int:
         halo *= (tile[a] - 1) * is_[a] + (max(offs) - min(offs) + 1)
     vs = ((ck // 8) | 1) * 16
     hb, rb = round_up(halo * vs, 1024), DEEP_WAVES * deep_red_tiles(mt, nt) * 1024  # (whole 1 KiB DMA rows)
-    off = round_up(ksteps * 16, 16) + 3 * nt * 64 + DEEP_WAVES * 2 * nt * 64
+    off = round_up(ksteps * 16 * max(1, classes), 16) + 3 * nt * 64 + DEEP_WAVES * 2 * nt * 64
     return off + (hb + rb if classes else max(hb, rb))
 
 
@@ -608,7 +608,7 @@ def deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1, in_split=0, limi
                 continue
             for ck in cks:
                 ksteps = (len(cls.taps) * (ck // 8) + 3) // 4
-                lds = deep_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, mt, nt, False)
+                lds = deep_lds_bytes(tile, cls.is_, cls.taps, ck, ksteps, mt, nt, 0)
                 if lds > LDS_LIMIT:
                     continue
                 pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, tuple(tile), mt, nt, nsplit, ck, kc // ck, ksteps, lds, -7)
@@ -643,7 +643,7 @@ def deep_class_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, n=1,
         if nvox < 16 * mt or not _deep_ok(choose_tile(q, union.taps, 16 * mt), mt, nt):
             continue
         tile = choose_tile(q, union.taps, 16 * mt)
-        lds = deep_lds_bytes(tile, union.is_, union.taps, kc, ksteps, mt, nt, True)
+        lds = deep_lds_bytes(tile, union.is_, union.taps, kc, ksteps, mt, nt, len(classes))
         if lds > LDS_LIMIT:
             continue
         pl = IgemmPlan(kind, union, tuple(q), kc, nreal, kreal, tuple(tile), mt, nt, len(classes), kc, 1, ksteps, lds, -7)
