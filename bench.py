@@ -94,6 +94,18 @@ def parity_block(args, dev):
     out = {k: (round(v, 8) if isinstance(v, float) else v) for k, v in met.items()}
     out.update({"pass": PC.passes(met, bars), "failed_bars": PC.failures(met, bars), "bars": bars, "golden": "tests/golden/net_train_b1_384x128x128.npz (reference fwd+Dice_spvPA+bwd, fp32 CPU)",
                 "config": f"{args.dtype}, batch {args.batch} (golden input replicated), tuned launch plans, dropout 0"})
+    if not getattr(args, "no_c3_parity", False):  # BASELINE config 3 at its own size against its fixture (hard Dice + blended logits), same weights' seed as the fixture
+        from tests.helpers import load
+
+        torch.manual_seed(1000 + int(load("c3_swi_512x512x120.npz")["seed"]))
+        m3 = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, num_res_units=2, norm="batch", dropout=0.0, attention_module=True, compute_dtype=args.dtype, **HP)
+        m3.load_state_dict(seeded_weights_for(m3.state_dict(), int(load("c3_swi_512x512x120.npz")["seed"])))
+        c3 = PC.c3_metrics(m3.to(dev))
+        c3.pop("out")
+        cb = PC.C3_BARS["bf16" if args.dtype == "bf16" else "fp32"]
+        out["c3_sliding_window"] = dict({k: round(v, 8) for k, v in c3.items()}, bars=cb, golden="tests/golden/c3_swi_512x512x120.npz (reference network per window x oracle blend)")
+        out["c3_sliding_window"]["pass"] = bool(c3["dice_abs"] < cb["dice_abs"] and c3["logits_rel_l2"] < cb["logits_rel_l2"])
+        del m3
     del m
     torch.cuda.empty_cache()
     return out
@@ -312,6 +324,7 @@ def main():
     ap.add_argument("--fp32-steps", type=int, default=3, help="also time N steps of the fp32 parity mode (exact-fp32 MFMA, the mode that meets the 1e-3 logits bar) at the same batch; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity check of the benchmarked configuration against the reference golden")
+    ap.add_argument("--no-c3-parity", action="store_true", help="skip the BASELINE config 3 part of the parity block (sliding window at 512x512x120 + hard Dice against its fixture)")
     ap.add_argument("--profile", action="store_true", help="print the per-kernel HIP-event breakdown of one step to stderr")
     args = ap.parse_args()
     self_launch(args)
