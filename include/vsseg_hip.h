@@ -182,13 +182,11 @@ int vsseg_conv_bwd_fused(const vsseg_conv_bwd_desc* d, void* stream);
  * 1x1x1 residual convolution of the one-channel input added behind the second activation (ref:params/networks/blocks/convolutions.py:241-255), and the attention block of the
  * finest decoder level, 32 -> 16 -> 1 + sigmoid (ref:params/networks/blocks/attentionblock.py:20-41).  Results are bit-identical to the two vsseg_igemm marching launches
  * (depth -5) with the same packed weights.  With a BatchNorm in stage A it is not applicable in training (the BatchNorm needs the
- * statistics of all of h first); the attention block has none: `h_out` keeps h for the backward pass. */
+ * statistics of all of h first). */
 typedef struct {
   vsseg_tensor in;         /* bf16: a multiple of 8 channels (16-byte aligned voxel rows; may be two-part) or a COMPACT one-channel tensor (c = pitch = 1) standing for one zero-extended group */
   vsseg_tensor out;        /* same extent; bf16 with a multiple of 4 channels (<= 32), or 1..3 channels bf16 / fp32 (the attention map: c = 1, fp32) */
   int32_t cmid;            /* channels of h (16 or 32) */
-  vsseg_tensor h_out;      /* optional (ptr != NULL): h is ALSO stored here (bf16, cmid channels, the input's extent) — a training forward keeps it for the backward pass; the pair then saves the
-                            * read of h, not its write.  Only pairs without a BatchNorm in stage A make sense in training (the attention block: scale_a = NULL) */
   const void* wpack_a;     /* [K-steps of 9 taps x in channels][cmid / 16][64 lanes][8] bf16: the packed weights of conv_a's marching plan (planner.pack_map, nt = cmid / 16) */
   const float *bias_a, *scale_a, *shift_a; /* [cmid]; scale_a / shift_a NULL: 1 / 0 */
   const float* alpha_a;    /* device pointer to the PReLU slope of stage A */
@@ -212,7 +210,7 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------

@@ -1195,13 +1195,6 @@ def test_chained_marching_convolution_equals_the_two_launches(cin, cout, dims, s
     L.check(lib.vsseg_conv_chain(C.byref(d), H.stream()), "conv_chain")
     torch.cuda.synchronize()
     assert torch.equal(got, got2)  # run-to-run
-    if not res1:  # ... and with the tensor between the stages stored as well (the training forward of the attention block keeps it for the backward pass)
-        h_got = torch.full_like(h_cl, float("nan"))
-        got3 = torch.full_like(got, float("nan"))
-        d.out, d.h_out = H.tdesc(got3), H.tdesc(h_got)
-        L.check(lib.vsseg_conv_chain(C.byref(d), H.stream()), "conv_chain + h_out")
-        torch.cuda.synchronize()
-        assert torch.equal(got3, want) and torch.equal(h_got, h_cl)
 
 
 @pytest.mark.parametrize("dims,shape,lx", [((7, 64, 8), (2, 1), 3), ((6, 64, 8), (4, 2), 6), ((5, 128, 4), (2, 2), 2)])

@@ -144,7 +144,6 @@ class ChainDesc(C.Structure):  # vsseg_chain_desc
         ("inp", Tensor),
         ("out", Tensor),
         ("cmid", C.c_int32),
-        ("h_out", Tensor),
         ("wpack_a", C.c_void_p),
         ("bias_a", C.c_void_p),
         ("scale_a", C.c_void_p),

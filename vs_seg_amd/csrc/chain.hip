@@ -6,7 +6,7 @@
 // blocks/convolutions.py:241-255), the attention block of the level-0 decoder (32 -> 16 -> 1 + sigmoid, ref:params/networks/blocks/attentionblock.py:20-41) and the
 // two-sub-unit ResidualUnit of level 1 (16 -> 32 -> 32 with its residual convolution as residual tiles of stage B).  In TRAINING the BatchNorm between two sub-units needs the
 // statistics of the whole tensor before any element of h exists, so the units are inference-only launches (the sliding-window predictor, ref:params/VSparams.py:553-567); the
-// attention block has no BatchNorm and can also run in the training forward with h stored as well (h_out) — measured: no faster than its two launches.
+// attention block has no BatchNorm; running it in the training forward too (h stored as well) measured no faster than its two launches and was deleted in round 6.
 //
 // Structure = mconv.hip's (a workgroup owns a column: sample n, ALL rows, slices [z0, z0 + TZ), and marches along x; a plane = one x position of the column, LDS layout
 // [row][piece'][z] with the same bank swizzle) with a second ring: iteration s
@@ -30,8 +30,6 @@ struct ChainK {
   int in_csplit_pc, in_vox_bytes;
   char* out;
   int out_vox_bytes, out_f32, cout;
-  char* h_out;  // optional: the tensor between the stages is ALSO stored (bf16; training keeps it for the backward pass), or nullptr
-  int h_vox_bytes;
   const char *wa, *wb;
   const float *bias_a, *scale_a, *shift_a, *alpha_a;
   const float *bias_b, *scale_b, *shift_b, *alpha_b;
@@ -327,8 +325,6 @@ __global__ __launch_bounds__(CH_NW * 64) void chain_kernel(const ChainK k) {
           }
           const uint2 hv = a_in ? make_uint2(f2bf2(val[0], val[1]), f2bf2(val[2], val[3])) : make_uint2(0u, 0u);
           *reinterpret_cast<uint2*>(hdst + hw[t] + m * MTB_BYTES) = hv;
-          if (k.h_out && s >= 1 && s <= steps)  // the planes this segment owns (its two halo planes belong to the neighbours)
-            *reinterpret_cast<uint2*>(k.h_out + (ocol + (int64_t)(xb + s - 1) * oplane + (int64_t)m * RPM * Z) * k.h_vox_bytes + c * 2) = hv;
         }
     }
 
@@ -456,8 +452,6 @@ static const ChEntry* ch_find(const vsseg_chain_desc* d, const char** why) {
   if (d->res_tiles && (d->res_tiles != ntb || c1 || !d->wpack_res || (d->out.c & 3) || d->in1_w)) return no("residual tiles: one per output tile, packed weights, an ordinary input, a bf16 output");
   if ((d->out.c & 3) == 0 && (d->out.dtype != VSSEG_BF16 || (d->out.pitch & 3) || ((uintptr_t)d->out.ptr & 7))) return no("a 4k-channel output is bf16 with 8-byte aligned rows");
   if ((d->in1_w || d->in1_b) && (!c1 || !d->in1_w || !d->in1_b || (d->out.c & 3))) return no("the residual of the input needs a compact one-channel input, weights and bias, and a bf16 output");
-  if (d->h_out.ptr && (d->h_out.dtype != VSSEG_BF16 || d->h_out.ptr2 || d->h_out.c != d->cmid || (d->h_out.pitch & 3) || ((uintptr_t)d->h_out.ptr & 7) || d->h_out.n != d->in.n || d->h_out.x != d->in.x || d->h_out.y != d->in.y || d->h_out.z != d->in.z))
-    return no("h_out must be a one-part bf16 tensor of cmid channels and the input's extent");
   if ((d->scale_a == nullptr) != (d->shift_a == nullptr) || (d->scale_b == nullptr) != (d->shift_b == nullptr)) return no("scale without shift");
   if (d->act_b < VSSEG_ACT_NONE || d->act_b > VSSEG_ACT_SIGMOID) return no("act_b");
   if (d->act_a != VSSEG_ACT_NONE && d->act_a != VSSEG_ACT_PRELU && d->act_a != VSSEG_ACT_RELU) return no("act_a");
@@ -491,7 +485,6 @@ extern "C" int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream) {
   k.out_vox_bytes = d->out.pitch * oes;
   k.out_f32 = d->out.dtype == VSSEG_F32;
   k.cout = d->out.c;
-  k.h_out = reinterpret_cast<char*>(d->h_out.ptr); k.h_vox_bytes = d->h_out.pitch * 2;
   k.wa = reinterpret_cast<const char*>(d->wpack_a); k.wb = reinterpret_cast<const char*>(d->wpack_b);
   k.bias_a = d->bias_a; k.scale_a = d->scale_a; k.shift_a = d->shift_a; k.alpha_a = d->alpha_a;
   k.bias_b = d->bias_b; k.scale_b = d->scale_b; k.shift_b = d->shift_b; k.alpha_b = d->alpha_b;

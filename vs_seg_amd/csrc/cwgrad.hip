@@ -27,7 +27,6 @@
 //     a strip run on the same XCD at about the same time (P comes from that L2); every workgroup walks a contiguous run of (strip, x) steps
 //   * partial sums leave as slabs in wgrad_kernel's layout and are summed in a fixed order by its reduce launch (run-to-run bit-identical)
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -93,7 +92,7 @@ __device__ __forceinline__ void cw_mfma_drain() { asm volatile("s_nop 7\n\ts_nop
 
 // NPW: 16-channel P tiles per wave; PS: waves a K-step's P tiles are split over; CG: 16-channel H chunks per workgroup (one per wave); the K-steps of a
 // plane are shared by KS = 4 / (PS * CG) waves
-template <int NPW, int PS, int CG, bool BIAS, int EXP = 0>
+template <int NPW, int PS, int CG, bool BIAS>
 __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   constexpr int KS = 4 / (PS * CG), NTP = NPW * PS, PROW = cw_prow(NTP), PREAL = NTP * 2;
   constexpr int PCOL = CW_PROWS * PROW, NHD = cw_nhd(CG), HPLANE = NHD * 4 * 1024, HBYTES = CW_RING * HPLANE, PBUF = CW_TY * PCOL;
@@ -205,7 +204,6 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   const int r4 = g * 4 + (l15 >> 2), qc = (l15 & 3) * 8;
   const int h_lane_off = (cg * CW_HY + ks) * 1024 + r4 * 32 + qc;
   const int p_lane_off = HBYTES + ks * PCOL + r4 * PROW + ps * NPW * 32 + qc;
-  int exp_dummy = 0;
   cw_u32x4 stage[NDMA];  // pieces on their way through the registers
   cw_for<NDMA>([&](auto uc) { stage[decltype(uc)::value] = cw_u32x4{0u, 0u, 0u, 0u}; });
 
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
       cw_for<NTAP>([&](auto jc) {
         constexpr int j = decltype(jc)::value, i = j / 9, t = j % 9;
         constexpr int NQ = 3 * NPW, Q_ST = NQ / 3, Q_LD = 2 * NQ / 3;  // MFMAs of the tap; the piece's store / load sit behind MFMA Q_ST - 1 / Q_LD - 1
-        if constexpr (j + 2 < NTAP && EXP != 3) hb[(j + 2) % 3] = h_frag(std::integral_constant<int, (j + 2 < NTAP ? j + 2 : 0)>{});
+        if constexpr (j + 2 < NTAP) hb[(j + 2) % 3] = h_frag(std::integral_constant<int, (j + 2 < NTAP ? j + 2 : 0)>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (BIAS && t == 4) {  // the centre tap's iteration carries the bias MFMAs (shift 0 = the plane's own voxels, each exactly once)
 #pragma unroll
@@ -283,22 +281,16 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
           const bf16x8& hb_j = hb[j % 3];
           // operand pieces, one per tap in the first taps: the piece loaded during the previous step (H plane x + 2 / P plane x + 1, read from the next step
           // on) goes to LDS, the same registers then take the piece of the step after (H plane x + 3 / P plane x + 2)
-          if constexpr (j < NDMA && EXP != 1 && (q == Q_ST || q == Q_LD)) {
+          if constexpr (j < NDMA && (q == Q_ST || q == Q_LD)) {
             constexpr auto uc = std::integral_constant<int, (j < NDMA ? j : 0)>{};
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (q == Q_ST) {
-              if constexpr (EXP == 6) exp_dummy ^= (int)stage[uc.value][0];
-              else st(uc, x + 2, x + 1, stage[uc.value]);
-            } else {
-              if constexpr (EXP == 7) stage[uc.value] = cw_u32x4{0u, 0u, 0u, 0u};
-              else ld(uc, x + 3, xp2, stage[uc.value]);
-            }
+            if constexpr (q == Q_ST) st(uc, x + 2, x + 1, stage[uc.value]);
+            else ld(uc, x + 3, xp2, stage[uc.value]);
             __builtin_amdgcn_sched_barrier(0);
           }
-          if constexpr (EXP == 2) exp_dummy ^= (int)pa_q[0] ^ (int)hb_j[q & 7];
-          else if constexpr (ASM) cw_mfma<(a < NAG), (q == 0 || (j < NDMA && (q == Q_ST || q == Q_LD)))>(acc[a], pa_q, hb_j);
+          if constexpr (ASM) cw_mfma<(a < NAG), (q == 0 || (j < NDMA && (q == Q_ST || q == Q_LD)))>(acc[a], pa_q, hb_j);
           else acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa_q, hb_j, acc[a], 0, 0, 0);
-          if constexpr (t == 8 && i + 1 < NK && EXP != 3) {  // last tap: this P fragment is dead — refill it for the next K-step (used 3 * NPW MFMAs from now)
+          if constexpr (t == 8 && i + 1 < NK) {  // last tap: this P fragment is dead — refill it for the next K-step (used 3 * NPW MFMAs from now)
             __builtin_amdgcn_sched_barrier(0);
             pa_q = cw_frag(Ps + (i + 1) * KS * PCOL + (q / NPW) * PROW + (q % NPW) * 32, 16 * PROW);
             __builtin_amdgcn_sched_barrier(0);
@@ -309,7 +301,6 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
     }
   }
   if constexpr (ASM) cw_mfma_drain();
-  if ((EXP == 2 || EXP == 6) && exp_dummy == 0x12345) k.slab[0] = 1.f;
 
   // ---- flush.  The KS waves that share a chunk hold partial sums of the same tiles: they meet in LDS first (tile group o goes to the wave with K share o,
   //      which adds the others' copies in share order), so a workgroup leaves ONE slab, and every tile leaves as one coalesced 1 KiB store (a lane's four
@@ -404,15 +395,15 @@ static const char* cw_check(const vsseg_wgrad_desc* d) {
   return nullptr;
 }
 
-template <int NPW, int PS, int CG, bool BIAS, int EXP = 0> static int cw_launch_inst(const CwK& k, int grid, hipStream_t s) {
+template <int NPW, int PS, int CG, bool BIAS> static int cw_launch_inst(const CwK& k, int grid, hipStream_t s) {
   static bool attr_set[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&cwgrad_kernel<NPW, PS, CG, BIAS, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&cwgrad_kernel<NPW, PS, CG, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((cwgrad_kernel<NPW, PS, CG, BIAS, EXP>), dim3((unsigned)grid), dim3(256), cw_lds_bytes(NPW * PS, CG), s, k);
+  hipLaunchKernelGGL((cwgrad_kernel<NPW, PS, CG, BIAS>), dim3((unsigned)grid), dim3(256), cw_lds_bytes(NPW * PS, CG), s, k);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel)");
   return VSSEG_OK;
 }
@@ -475,10 +466,7 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
   int rc;
   const bool b = d->dbias_p != nullptr;
   if (d->ntp == 3 && cg == 1) rc = b ? cw_launch_inst<3, 1, 1, true>(k, G, s) : cw_launch_inst<3, 1, 1, false>(k, G, s);
-  else if (d->ntp == 3 && !b && getenv("VSSEG_CW_EXP")) {
-    const int e = atoi(getenv("VSSEG_CW_EXP"));
-    rc = e == 1 ? cw_launch_inst<3, 1, 2, false, 1>(k, G, s) : e == 2 ? cw_launch_inst<3, 1, 2, false, 2>(k, G, s) : e == 3 ? cw_launch_inst<3, 1, 2, false, 3>(k, G, s) : e == 6 ? cw_launch_inst<3, 1, 2, false, 6>(k, G, s) : e == 7 ? cw_launch_inst<3, 1, 2, false, 7>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
-  } else if (d->ntp == 3) rc = b ? cw_launch_inst<3, 1, 2, true>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
+  else if (d->ntp == 3) rc = b ? cw_launch_inst<3, 1, 2, true>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   else rc = b ? cw_launch_inst<2, 2, 1, true>(k, G, s) : cw_launch_inst<2, 2, 1, false>(k, G, s);
   if (rc) return rc;
   {

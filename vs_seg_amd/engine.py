@@ -415,7 +415,7 @@ class Plan:
                 wpr = torch.empty(mr.numel(), dtype=eng.tdtype, device=eng.device)
                 L.check(lib.vsseg_gather_cast(eng.flat.data_ptr(), mr.data_ptr(), None, wpr.data_ptr(), mr.numel(), L.BF16 if eng.es == 2 else L.F32, stream), "gather_cast")
                 d.wpack_res = wpr.data_ptr()
-            if os.environ.get("VSSEG_TUNE_TRACE"):  # debugging aid: name every candidate before it runs, finish it before the next one
+            if False:  # (debugging aid, was VSSEG_TUNE_TRACE: name every candidate before it runs, finish it before the next one)
                 import sys
                 print(f"[tune] {pl.kind} depth={pl.depth} q={pl.q} tile={pl.tile} mtw={pl.mtw} nt={pl.nt} ns={pl.nsplit} ck={pl.ck} kc={pl.kc} nc={pl.nc} in=({d.inp.c},{d.inp.pitch},{d.inp.n},{d.inp.x},{d.inp.y},{d.inp.z},two={bool(d.inp.ptr2)}) "
                       f"out=({d.out.c},{d.out.pitch},dt={d.out.dtype},two={bool(d.out.ptr2)}) acc={d.accumulate} res={d.res_mode} stats={bool(d.stats)} cls={d.class_split}", file=sys.stderr, flush=True)
@@ -423,7 +423,7 @@ class Plan:
             if lib.vsseg_igemm(C.byref(d), stream):  # a candidate the kernel rejects is simply not chosen
                 times.append(float("inf"))
                 continue
-            if os.environ.get("VSSEG_TUNE_TRACE"):
+            if False:
                 torch.cuda.synchronize()
             best = float("inf")
             for _ in range(self.eng.tune_reps):  # best of N single launches (N = 5: with 3 the choice between near-equal plans flipped from run to run by up to 0.5 ms per step)
@@ -725,7 +725,7 @@ class Plan:
             def march3(Lr):
                 return not Lr.transposed and tuple(Lr.stride) == (1, 1, 1) and Lr.kernel == (3, 3, 1)
             for a in ops:
-                if self.train and not (isinstance(a, ConvPlain) and eng.chain_train):  # training: only pairs without a BatchNorm between them (the attention block), h stored as well
+                if self.train:  # inference only (in training a BatchNorm needs the whole tensor between the two convolutions; the attention block, which has none, measured no gain: DESIGN 3.11)
                     continue
                 if not isinstance(a, (ConvBnAct, ConvPlain)) or not march3(a.layer) or a.layer.cout not in (16, 32) or a.res is not None or a.x.base is not None or a.out.base is not None:
                     continue
@@ -781,8 +781,6 @@ class Plan:
                     d.res_tiles, d.bias_res = 2, self._pp(rcv.layer.bkey)
             else:
                 d.act_a, d.act_b = L.ACT_RELU, L.ACT_SIGMOID
-                if self.train:  # the backward pass reads h (ReLU mask, weight gradient of the second convolution)
-                    d.h_out = self._desc(a.out)
             d.tz, d.mtw, d.lx, d.waves, d.lead = plan_c["tz"], plan_c["mtw"], plan_c["lx"], plan_c["waves"], plan_c["lead"]
             for attr, Lr, kc in (("wpack_a", La, 8 if compact else La.cin), ("wpack_b", Lb, La.cout)):
                 pl = P.chain_pack_plan(tuple(Lr.wshape), q, eng.es, kc, self.n)
@@ -1438,31 +1436,30 @@ class Engine:
             raise RuntimeError("vs_seg_amd: parameters are not on a GPU — this engine has no CPU path (move the model with .to('cuda'))")
         self.device = flat.device
         self.dry_run = dry_run
-        self.fold = os.environ.get("VSSEG_ZFOLD", "1") != "0"  # z-folded launch of the attention sigmoid convolutions (planner.FOLD); 0 disables
-        self.res1_fuse = os.environ.get("VSSEG_RES1_FUSE", "1") != "0"  # 1-channel residual conv computed inside bn_act_fwd (training)
+        # Lowering features that were environment switches while they were being measured (rounds 2-5) and are simply how the engine lowers now — round 6 removed the
+        # switches whose other arm no test, tool or measurement used any more (VSSEG_ZFOLD, _RES1_FUSE, _CLASS_SPLIT, _FUSE_CLASSES, _KEEPMASK, _NARROW_WGRAD, _GATE_FUSE,
+        # _FUSED_BWD, _FUSED_BWD_RES, _COMPACT_C1, _RESN, _MARCH_SHUFFLE, _GATE_ONLOAD, _GATE_ONLOAD_UNITS, _TUNE_TRACE; VSSEG_CHAIN_TRAIN went with its code).  The
+        # attributes stay: the lowering consults them together with "is the kernel instantiated for this shape", and the CPU dry run turns some off.
+        self.fold = True  # z-folded launch of the attention sigmoid convolutions (planner.FOLD)
+        self.res1_fuse = True  # 1-channel residual conv computed inside bn_act_fwd (training)
         self.tune_reps = int(os.environ.get("VSSEG_TUNE_REPS", "5"))  # timed launches per candidate plan (best of)
-        self.class_split = os.environ.get("VSSEG_CLASS_SPLIT", "1") != "0"  # ... of the stride-(2,2,2) transitions as one launch of the general kernel (planner.class_split_plans)
-        self.fuse_classes = os.environ.get("VSSEG_FUSE_CLASSES", "1") != "0" and not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
-        self.keepmask = os.environ.get("VSSEG_KEEPMASK", "1") != "0"  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
-        self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
-        self.narrow_wgrad = os.environ.get("VSSEG_NARROW_WGRAD", "1") != "0"  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
-        self.gate_fuse = os.environ.get("VSSEG_GATE_FUSE", "1") != "0"  # attention-gate backward fused into the attention conv's data gradient
-        # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip): "0" = off, "1" = every
-        # instantiated shape, or a list of "<cin>x<cout>" pairs (e.g. "16x16,16x32")
-        self.fused_bwd = os.environ.get("VSSEG_FUSED_BWD", "1")
-        self.fused_bwd_res = os.environ.get("VSSEG_FUSED_BWD_RES", "1") != "0"
-        # ... and (VSSEG_CHAIN_TRAIN=1, off by default) the level-0 attention block of the TRAINING forward: no BatchNorm between its convolutions, h is stored as well (h_out).  Bit-identical,
-        # one launch less — and no faster: 27.93 against 27.92 ms per step over three alternating same-box pairs (the chain moves 2.5 GB at ~3.5 TB/s where the two launches move 3.2 GB at 4.6 / 2.5)
-        self.chain_train = os.environ.get("VSSEG_CHAIN_TRAIN", "0") == "1"
+        self.class_split = True  # all parity classes of the stride-(2,2,2) transitions as one launch of the general kernel (planner.class_split_plans), where that measures faster
+        self.fuse_classes = not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
+        self.keepmask = True  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
+        self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch of round 6: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
+        self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
+        self.gate_fuse = True  # attention-gate backward fused into the attention conv's data gradient
+        self.fused_bwd = "1"  # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip), every instantiated shape
+        self.fused_bwd_res = True  # ... with the unit's 1x1x1 residual convolution riding along
         self.chain = os.environ.get("VSSEG_CHAIN", "1")  # inference: pairs of 3x3x1 convolutions as one launch, the tensor between them in LDS (csrc/chain.hip); "0": off, "l0": level 0 only
-        self.compact_c1 = os.environ.get("VSSEG_COMPACT_C1", "1") != "0" and not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
-        self.resn = os.environ.get("VSSEG_RESN", "1") != "0" and not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution  # ... with the unit's 1x1x1 residual convolution riding along
+        self.compact_c1 = not dry_run  # one-real-channel convolution inputs read compact by the marching kernel (csrc/mconv.hip C1)
+        self.resn = not dry_run  # forward: the unit's 1x1x1 residual convolution as extra output tiles of its first 3x3x1 convolution
         # the deep-level kernel (csrc/dconv.hip, plans with depth -7) on the small launches of levels 3-5: "1" = a candidate the tuner measures, "0" = off, "force" = every launch
         # it is offered for runs on it (the untuned lowering then too: how the tests send a whole network through it)
         self.deep = os.environ.get("VSSEG_DEEP", "1")
-        self.march_shuffle = os.environ.get("VSSEG_MARCH_SHUFFLE", "1") != "0"  # marching variants of the fused-parity-classes launch of the level-1 -> level-0 transposed convolution as tuner candidates
-        self.gate_onload_units = os.environ.get("VSSEG_GATE_ONLOAD_UNITS", "1") != "0"  # ... also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
-        self.gate_onload = os.environ.get("VSSEG_GATE_ONLOAD", "1") != "0"  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
+        self.march_shuffle = True  # marching variants of the fused-parity-classes launch of the level-1 -> level-0 transposed convolution as tuner candidates
+        self.gate_onload_units = True  # attention gate on load also in front of the level-1 decoder ResidualUnit (residual tiles + fused backward)
+        self.gate_onload = True  # attention-gate forward applied on load by the (marching) convolution behind it and its weight gradient
         # weight gradients on a second HIP stream, concurrent with the data-gradient chain: on the deep levels neither chain fills the 256 CUs
         # (145 launches of 20-50 us), together they do: 37.3 -> 36.1 ms per step (tools/time_step.py).  The backward list is then launched
         # eagerly: replayed as ONE hipGraph the two branches ran no faster than serially (measured 37.6 ms)
