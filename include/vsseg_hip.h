@@ -210,7 +210,7 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------
@@ -260,6 +260,14 @@ int vsseg_wgrad_narrow(vsseg_tensor t, const void* s, int32_t k3, int32_t sign, 
  * to vsseg_bn_act_bwd_apply, which is then not launched and d(conv output) is never written (the network input needs no data gradient).  bf16 only. */
 int vsseg_wgrad_narrow_bn(vsseg_tensor y, vsseg_tensor dout, const uint8_t* keep, const float* mean, const float* invstd, const float* gamma, const float* scale, const float* shift, const float* alpha,
                           const float* mean_dz, const float* mean_dzx, float p_drop, const void* s, float* dw, int64_t stride_c, float* scratch, int64_t scratch_elems, void* stream);
+
+/* Forward of a stride-1 3x3x1 convolution with ONE output channel (+ bias, + sigmoid): the second convolution of AttentionBlock1 on the two finest levels
+ * (ref:params/networks/blocks/attentionblock.py:20-35: conv2 = Convolution(C/2 -> 1, conv_only) followed by Sigmoid).  A bandwidth kernel on the vector ALUs
+ * (csrc/nconv.hip): every input voxel is read once, the output voxel's nine taps are partial sums exchanged between neighbouring threads.  in: one-part bf16,
+ * 16 or 32 channels, y extent 16 .. 256 (a power of two; a workgroup owns all rows), z a multiple of 512 / y.  w: the fp32 master weights [1][C][3][3][1]
+ * (rounded to bf16 inside, as the packed weights of the MFMA launches are).  out: dense one-channel fp32 / bf16 tensor of the input's extent.  lx: x planes per
+ * workgroup (<= 0: all).  Outside this domain the call fails with VSSEG_EINVAL (no fallback: the caller lowers vsseg_igemm instead). */
+int vsseg_conv_to1(vsseg_tensor in, const float* w, const float* bias /* [1] or NULL */, int32_t act /* VSSEG_ACT_NONE | VSSEG_ACT_SIGMOID */, vsseg_tensor out, int32_t lx, void* stream);
 
 /* dst[i] = map[i] >= 0 ? cast(src[map[i]]) : 0 — (re)packs the fp32 master weights into MFMA fragment order. */
 int vsseg_gather_cast(const float* src, const int32_t* map, const int32_t* map2 /* optional second addend, or NULL */, void* dst, int64_t n, int32_t dst_dtype, void* stream);

@@ -182,6 +182,52 @@ def test_marching_weight_gradient(cin, cout, dims, split, tile):
         assert torch.equal(a, b) and not torch.equal(a, dw)
 
 
+@pytest.mark.parametrize("c,dims,batch,lx,act,odt", [(16, (9, 128, 8), 2, 4, "sigmoid", "fp32"), (16, (5, 64, 16), 1, 0, "none", "fp32"), (32, (7, 64, 8), 2, 3, "sigmoid", "fp32"),
+                                                      (32, (4, 32, 32), 1, 2, "sigmoid", "bf16"), (16, (3, 16, 64), 1, 1, "sigmoid", "fp32"), (32, (12, 256, 4), 1, 5, "none", "fp32")])
+def test_narrow_output_convolution_matches_definition(c, dims, batch, lx, act, odt):
+    """vsseg_conv_to1 (csrc/nconv.hip): the C -> 1 stride-1 3x3x1 convolution + bias (+ sigmoid) of the attention blocks on the vector ALUs, partial sums exchanged between
+    neighbouring threads — against torch's fp64 convolution of the same bf16-rounded operands (weights rounded to bf16 as the kernel and the MFMA launches round them),
+    over x segments, image borders in x and y, every supported row count; and against the MFMA launch it replaces (same products, another summation order)."""
+    lib = L.lib()
+    torch.manual_seed(33)
+    x = _round(torch.randn(batch, c, *dims), "bf16")
+    w = torch.randn(1, c, 3, 3, 1) * 0.2
+    b = torch.randn(1)
+    y = F.conv3d(x.double(), _round(w, "bf16").double(), b.double(), padding=(1, 1, 0))
+    if act == "sigmoid":
+        y = torch.sigmoid(y)
+    xcl = H.to_cl(x, torch.bfloat16)
+    out = torch.full((batch, *dims, 1), float("nan"), device="cuda", dtype=H.DT[odt])
+    wd, bd = w.reshape(-1).cuda(), b.cuda()
+    od = L.Tensor(out.data_ptr(), L.F32 if odt == "fp32" else L.BF16, 1, 1, batch, *dims)
+    L.check(lib.vsseg_conv_to1(H.tdesc(xcl), wd.data_ptr(), bd.data_ptr(), L.ACT_SIGMOID if act == "sigmoid" else L.ACT_NONE, od, lx, H.stream()), "conv_to1")
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 4, 1, 2, 3)
+    assert not torch.isnan(got).any()
+    np.testing.assert_allclose(got.numpy(), y.float().numpy(), atol=(2e-5 if odt == "fp32" else 8e-3) * max(1.0, float(y.abs().max())))
+    if odt == "fp32" and act == "none":  # the general kernel on the same operands
+        o2 = torch.zeros(batch, *dims, 8, device="cuda", dtype=torch.float32)
+        H.run_lattice_op("conv_fwd", w, xcl, o2, (1, 1, 1), bias=bd.data_ptr())
+        np.testing.assert_allclose(got.numpy(), H.from_cl(o2, 1).numpy(), atol=2e-4 * float(y.abs().max()))
+
+
+def test_narrow_output_convolution_rejects_what_it_does_not_cover():
+    lib = L.lib()
+    w = torch.zeros(1, 16, 3, 3, 1).reshape(-1).cuda()
+
+    def attempt(c, dims, ocl=1):
+        x = torch.zeros(1, *dims, c, device="cuda", dtype=torch.bfloat16)
+        out = torch.zeros(1, *dims, ocl, device="cuda", dtype=torch.float32)
+        od = L.Tensor(out.data_ptr(), L.F32, ocl, ocl, 1, *dims)
+        with pytest.raises(RuntimeError, match="vsseg_conv_to1"):
+            L.check(lib.vsseg_conv_to1(H.tdesc(x), w.data_ptr(), None, L.ACT_SIGMOID, od, 0, H.stream()), "conv_to1")
+
+    attempt(48, (4, 32, 16))   # 48 channels
+    attempt(16, (4, 24, 16))   # y extent not a power of two
+    attempt(16, (4, 32, 8))    # z not a multiple of 512 / y = 16
+    attempt(16, (4, 64, 8), 2)  # two output channels
+
+
 COMPUTE_WGRAD_CASES = [
     # cin (H), cout (P), dims, batch, H split, H chunks per workgroup, bias gradient, workgroups per class (None: one per CU)
     (32, 48, (5, 8, 64), 2, 0, 2, False, None),    # level-2 encoder unit0: one chunk class, two K-step shares; runs of a single x step

@@ -44,6 +44,8 @@ def bench_name(short_name):
     m = re.match(r"cwgrad_kernel<(\d+), (\d+), ", short_name)  # compute weight gradient (3x3x3 stride-1 layers): bench name by the P tiles (NPW x PS)
     if m:
         return f"cwgrad<bf16,{int(m.group(1)) * int(m.group(2))}>"
+    if short_name.startswith("nconv_kernel"):  # narrow-output convolution (C -> 1, vector ALUs)
+        return "nconv<bf16>"
     if short_name.startswith("wgrad_narrow_kernel"):
         return "wgrad_narrow"
     m = re.match(r"chain_kernel<(\d+),", short_name)  # chained marching convolution (inference): input channels of its first stage

@@ -171,7 +171,7 @@ class ChainDesc(C.Structure):  # vsseg_chain_desc
 
 # every exported entry point of include/vsseg_hip.h (the non-GPU tests check the .so exports each of them)
 SYMBOLS = [
-    "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_conv_chain", "vsseg_conv_chain_lds_bytes", "vsseg_wgrad", "vsseg_conv_bwd_fused", "vsseg_wgrad_narrow", "vsseg_wgrad_narrow_bn", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
+    "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_conv_chain", "vsseg_conv_chain_lds_bytes", "vsseg_conv_to1", "vsseg_wgrad", "vsseg_conv_bwd_fused", "vsseg_wgrad_narrow", "vsseg_wgrad_narrow_bn", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
     "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_att_bwd",
@@ -205,6 +205,7 @@ def lib():
         L.vsseg_igemm_lds_bytes.argtypes = [C.POINTER(IgemmDesc)]
         L.vsseg_conv_chain.argtypes = [C.POINTER(ChainDesc), vp]
         L.vsseg_conv_chain_lds_bytes.argtypes = [C.POINTER(ChainDesc)]
+        L.vsseg_conv_to1.argtypes = [Tensor, vp, vp, i32, Tensor, i32, vp]
         L.vsseg_wgrad.argtypes = [C.POINTER(WgradDesc), vp]
         L.vsseg_conv_bwd_fused.argtypes = [C.POINTER(ConvBwdDesc), vp]
         L.vsseg_wgrad_narrow.argtypes = [Tensor, vp, i32, i32, vp, C.c_int64, vp, vp, C.c_int64, vp]

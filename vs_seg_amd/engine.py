@@ -873,6 +873,21 @@ class Plan:
                     self._igemm(F, gch, self._desc(gl.x), self._desc(op.out), bias=self._pp(Lr.bkey), bias2=self._pp(absorbed.layer.bkey) if absorbed is not None else 0, act=ACT_CODE[op.act],
                                 in_gate=self._alloc(gl.att, self.bufs).data_ptr())
                     continue
+                # the C -> 1 stride-1 3x3x1 convolution that closes an attention block of the two finest levels: a bandwidth kernel on the vector ALUs (csrc/nconv.hip: every
+                # input voxel read once, partial sums exchanged between neighbouring threads) instead of an MFMA launch with one real output channel
+                yext, zext = self.lv[Lr.level][1], self.lv[Lr.level][2]
+                if (eng.narrow_fwd and eng.es == 2 and not eng.dry_run and Lr.cout == 1 and Lr.cin in (16, 32) and Lr.kernel == (3, 3, 1) and tuple(Lr.stride) == (1, 1, 1) and not Lr.transposed
+                        and absorbed is None and op.res is None and op.x.parts is None and op.x.base is None and op.out.base is None and op.act in ("none", "sigmoid")
+                        and yext in (16, 32, 64, 128, 256) and zext % (512 // yext) == 0):
+                    xd, od = self._desc(op.x), self._desc(op.out)
+                    if od.c == 1 and od.pitch == 1 and not xd.ptr2:
+                        nzb = zext // (512 // yext)
+                        nxs = max(1, round(256 / (self.n * nzb)))  # about one 512-thread workgroup per CU (measured best at batch 1 and 4 on both levels: tools/bench_nconv.py)
+                        lx = -(-self.lv[Lr.level][0] // nxs)
+                        nq = float(self._vox(Lr.level))
+                        F.append([lib.vsseg_conv_to1, [xd, self._pp(Lr.wkey), self._pp(Lr.bkey), ACT_CODE[op.act], od, lx],
+                                  dict(name="nconv<bf16>", kind="hbm", flops=2.0 * nq * 9 * Lr.cin, bytes=nq * (2.0 * Lr.cin + (4.0 if od.dtype == L.F32 else 2.0)), tag=f"{Lr.prefix[-40:]} {Lr.cin}->1 k={Lr.kernel} lx={lx}")])
+                        continue
                 xin, out = self._xdesc(op.x, cp.fold_fwd), self._desc(op.out)
                 res = self._desc(op.res) if (op.res is not None and absorbed is None) else None
                 for ch in cp.fwd:
@@ -1447,6 +1462,7 @@ class Engine:
         self.fuse_classes = not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = True  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch of round 6: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
+        self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = True  # attention-gate backward fused into the attention conv's data gradient
         self.fused_bwd = "1"  # BatchNorm-backward apply + data gradient + weight gradient of the stride-1 3x3x1 blocks of levels 0-1 in ONE launch (csrc/mbwd.hip), every instantiated shape
