@@ -40,6 +40,15 @@ python bench.py --steps 2 --warmup 1 --swi-volumes 0 --fp32-steps 0 --no-cpu-bas
 (tools/probes/chain_probe > $OUT/chain_probe.txt 2>&1 || true)
 (timeout 600 python tools/bench_dconv.py 4 > $OUT/dconv_bench.txt 2>&1 || true)
 (timeout 300 python tools/bench_chain.py 1 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt || true)
+# round 6: the compute weight-gradient kernel against the tile kernel on the six 3x3x3 stride-1 layers of levels 2-3, and the narrow-output convolution
+(for cfg in "96 32 128 96 48" "96 32 128 48 48" "96 32 128 32 48" "48 16 64 128 64" "48 16 64 64 64" "48 16 64 48 64"; do set -- $cfg; timeout 300 python tools/bench_wgrad.py --dims $1 $2 $3 --cin $4 --cout $5 --kernel 3 3 3 2>&1 | grep -v "amdgpu.ids\|rejected"; done > $OUT/cwgrad_bench.txt || true)
+(timeout 300 python tools/bench_nconv.py 4 2>&1 | grep -v amdgpu.ids > $OUT/nconv_bench.txt; timeout 300 python tools/bench_nconv.py 1 2>&1 | grep -v amdgpu.ids >> $OUT/nconv_bench.txt || true)
+(cd /tmp; B="python $R/tools/bench_wgrad.py --dims 96 32 128 --cin 96 --cout 48 --kernel 3 3 3 --compute-only --reps 3"
+ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/cwa -- $B > /dev/null 2>&1
+ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_LDS SQ_BUSY_CU_CYCLES -d $OUT/cwb -- $B > /dev/null 2>&1
+ rocprofv3 --pmc FETCH_SIZE -d $OUT/cwc -- $B > /dev/null 2>&1
+ rocprofv3 --pmc WRITE_SIZE -d $OUT/cwd -- $B > /dev/null 2>&1
+ cd $R; python tools/pmc_dump.py "cwgrad_kernel<3, 1, 2" $OUT/cwa/*/*.db $OUT/cwb/*/*.db $OUT/cwc/*/*.db $OUT/cwd/*/*.db > $OUT/cwgrad_pmc.txt; rm -rf $OUT/cwa $OUT/cwb $OUT/cwc $OUT/cwd) || true
 python tools/rocprof_summary.py kernel $OUT/kt/*/*.db > $OUT/kernel_stats.txt
 python tools/rocprof_summary.py kernel $OUT/kts/*/*.db > $OUT/swi_kernel_stats.txt
 python tools/rocprof_summary.py pmc $OUT/sfetch/*/*.db $OUT/swrite/*/*.db > $OUT/swi_pmc_hbm.txt
