@@ -302,44 +302,17 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   }
   if constexpr (ASM) cw_mfma_drain();
 
-  // ---- flush.  The KS waves that share a chunk hold partial sums of the same tiles: they meet in LDS first (tile group o goes to the wave with K share o,
-  //      which adds the others' copies in share order), so a workgroup leaves ONE slab, and every tile leaves as one coalesced 1 KiB store (a lane's four
-  //      values = 16 bytes).  The first version stored 4-byte values into wgrad_kernel's [tap][cP][16] layout, one slab per K share: 85 MB per launch of the
-  //      96 -> 48 layer in 64-byte fragments, 0.06 ms of a 0.42 ms launch.
-  constexpr int GT = (NACC + KS - 1) / KS;  // tiles per owner
-  typedef __attribute__((address_space(3))) f32x4 cw_lds_f4;
-  if constexpr (KS > 1) {
-    cw_for<KS>([&](auto oc) {
-      constexpr int o = decltype(oc)::value;
-      __syncthreads();  // the operand planes (first round) / the previous round's copies are no longer read
-      if (ks != o) {
-        const int sender = (ps * CG + cg) * (KS - 1) + (ks < o ? ks : ks - 1);
-        cw_for<GT>([&](auto ic) {
-          constexpr int a = o * GT + decltype(ic)::value;
-          if constexpr (a < NACC) *(cw_lds_f4*)(uintptr_t)(sm0 + (unsigned)(((sender * GT + decltype(ic)::value) * 64 + lane) * 16)) = acc[a];
-        });
-      }
-      __syncthreads();
-      if (ks == o) {
-        cw_for<GT>([&](auto ic) {
-          constexpr int a = o * GT + decltype(ic)::value;
-          if constexpr (a < NACC) {
-#pragma unroll
-            for (int sdr = 0; sdr < KS - 1; ++sdr) acc[a] += *(cw_lds_f4*)(uintptr_t)(sm0 + (unsigned)(((((ps * CG + cg) * (KS - 1) + sdr) * GT + decltype(ic)::value) * 64 + lane) * 16));
-          }
-        });
-      }
-    });
-  }
-  // slab of the workgroup: [chunk][tap][P tile][64 lanes][4]; lane (g, l15), value r = element (cP = tile*16 + g*4 + r, cH = chunk*16 + l15)
+  // ---- flush: every tile leaves as one coalesced 1 KiB store (a lane's four values = 16 bytes), one slab per (workgroup, K share).  The first version stored 4-byte
+  //      values into wgrad_kernel's [tap][cP][16] layout: 64-byte fragments, 0.06 ms of a 0.42 ms launch.  (Adding the K shares of a workgroup up through LDS first
+  //      halves the slab bytes but made hipcc spill accumulators to scratch memory around the exchange — and a kernel with a scratch segment pays for it at EVERY
+  //      launch: in bench.py's process the four launches of a step took 6.8 ms instead of 1.2.  No scratch, twice the slabs.)
+  // slab of (workgroup, K share): [chunk][tap][P tile][64 lanes][4]; lane (g, l15), value r = element (cP = tile*16 + g*4 + r, cH = chunk*16 + l15)
   const int chunk = cls * CG + cg;
-  float* slab = k.slab + ((int64_t)widx * k.hchunks + chunk) * k.slab_chunk + lane * 4;
+  float* slab = k.slab + (((int64_t)widx * KS + ks) * k.hchunks + chunk) * k.slab_chunk + lane * 4;
   cw_for<NACC>([&](auto ic) {
     constexpr int a = decltype(ic)::value, t = a / (3 * NPW), sft = (a / NPW) % 3, p = a % NPW;
-    if (KS == 1 || a / GT == ks) {
-      const int tap = t * 3 + (2 - sft);  // P shifted by sft - 1 pairs P[z' - dz] with H[z']: dz = 1 - sft
-      *reinterpret_cast<f32x4*>(slab + (tap * NTP + ps * NPW + p) * 256) = acc[a];
-    }
+    constexpr int tap = t * 3 + (2 - sft);  // P shifted by sft - 1 pairs P[z' - dz] with H[z']: dz = 1 - sft
+    *reinterpret_cast<f32x4*>(slab + (tap * NTP + ps * NPW + p) * 256) = acc[a];
   });
   if constexpr (BIAS) {
     if (cls == 0 && cg == 0 && l15 == 0) {
@@ -432,7 +405,7 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
   // workgroups per class: one workgroup per CU over all classes, and what the scratch holds (ksh slabs per workgroup, + a bias row)
   int gpc = 256 / k.ncls;
   if (k.pow2) gpc &= ~7;  // whole rounds of the 8 XCDs (cw_widx)
-  const int64_t per_wg = (int64_t)k.hchunks * k.slab_chunk + (d->dbias_p ? ksh * d->ntp * 16 : 0);  // one slab per workgroup (+ a bias row per K share)
+  const int64_t per_wg = (int64_t)ksh * ((int64_t)k.hchunks * k.slab_chunk + (d->dbias_p ? d->ntp * 16 : 0));  // one slab (+ a bias row) per workgroup and K share
   const int64_t cap = d->scratch_elems / per_wg;
   if (gpc > cap) gpc = k.pow2 ? (int)(cap & ~7ll) : (int)cap;
   if (d->persistent_blocks > 0 && gpc > d->persistent_blocks) gpc = k.pow2 ? (d->persistent_blocks & ~7) : d->persistent_blocks;
@@ -462,7 +435,7 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
     k.zeros = reinterpret_cast<const char*>(zpage[dev]);
   }
   k.slab = d->scratch;
-  k.bias_slab = d->dbias_p ? d->scratch + (int64_t)gpc * k.hchunks * k.slab_chunk : nullptr;
+  k.bias_slab = d->dbias_p ? d->scratch + (int64_t)gpc * ksh * k.hchunks * k.slab_chunk : nullptr;
   int rc;
   const bool b = d->dbias_p != nullptr;
   if (d->ntp == 3 && cg == 1) rc = b ? cw_launch_inst<3, 1, 1, true>(k, G, s) : cw_launch_inst<3, 1, 1, false>(k, G, s);
@@ -471,7 +444,7 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
   if (rc) return rc;
   {
     const int total = k.hchunks * k.slab_chunk;
-    hipLaunchKernelGGL(cwgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)d->scratch, gpc, k.hchunks, d->ntp, k.slab_chunk, *d);
+    hipLaunchKernelGGL(cwgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)d->scratch, gpc * ksh, k.hchunks, d->ntp, k.slab_chunk, *d);
     VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel, reduce)");
   }
   if (!d->dbias_p) return VSSEG_OK;
