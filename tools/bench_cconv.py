@@ -1,5 +1,5 @@
 """Times the compute-bound kernel (depth -3) against every plan of the general kernel on the level-2/3 3x3x3 layer shapes (HIP events, best of 5).
-Usage on the GPU box: python tools/bench_cconv.py"""
+Usage on the GPU box: python tools/bench_cconv.py [--compute-only] [--batch N]"""
 import ctypes as C
 import os
 import sys
@@ -21,7 +21,8 @@ CASES = [("conv_fwd", 96, 48, L2, "plain"), ("conv_fwd", 96, 48, L2, "stats"), (
 
 def main():
     lib = L.lib()
-    n = 4
+    n = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 4
+    only = "--compute-only" in sys.argv  # time the depth -3 plans only
     for kind, cin, cout, dims, mode in CASES:
         w = torch.randn(cout, cin, *K3) / (cin * 27) ** 0.5
         kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
@@ -33,6 +34,8 @@ def main():
         kw = dict(stats=stats.data_ptr(), stats_stride=P.round_up(nreal, 16)) if mode == "stats" else (dict(accumulate=1) if mode == "accumulate" else {})
         cands = P.candidate_plans(kind, tuple(w.shape), cls, dims, 2, kc_pad=kc, aux_es=2 if mode == "accumulate" else 0)
         res = []
+        if only:
+            cands = [pl for pl in cands if pl.depth == -3]
         for pl in cands:
             d = H.igemm_desc(pl, H.pack(pl, w, x.dtype), H.tdesc(x), H.tdesc(out), **kw)
             if lib.vsseg_igemm(C.byref(d), H.stream()):
@@ -48,6 +51,9 @@ def main():
                 best = min(best, e0.elapsed_time(e1))
             res.append((best, pl))
         tf = 2.0 * n * np.prod(dims) * 27 * kreal * nreal / 1e9  # GFLOP
+        if only:
+            print(f"{kind} K={kreal} N={nreal} {dims} x{n} {mode}: compute kernel " + ", ".join(f"{r[0] * 1e3:.1f} us ({tf / r[0]:.0f} TFLOP/s)" for r in res), flush=True)
+            continue
         bg = min((r for r in res if r[1].depth != -3), key=lambda r: r[0])
         cc = [r for r in res if r[1].depth == -3]
         print(f"{kind} K={kreal} N={nreal} {dims} {mode}: general best {bg[0]:.3f} ms ({tf / bg[0]:.0f} TFLOP/s, tile={bg[1].tile} nt={bg[1].nt} ck={bg[1].ck} ns={bg[1].nsplit})"

@@ -132,29 +132,31 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
     return t;
   };
   // ---- LDS-DMA of one stage = (tile, 16-channel chunk): halo chunk + packed weights of the chunk into buffer `buf` ----
-  auto issue = [&](const Tile& t, int ch, int buf) {
-    char* Hdst = smem + buf * BUF;
-    const int64_t ivox = (((int64_t)t.n * X + (t.x0 - 1)) * Y + (t.y0 - 1)) * Z + (t.z0 - 1);
-    const char* org = (ch >= k.in_csplit_ch ? k.in1 : k.in0) + ivox * k.in_vox_bytes + ch * CC_VB;
-    const int ix = t.x0 - 1, iy = t.y0 - 1, iz = t.z0 - 1;
-#pragma unroll
-    for (int u = 0; u < CC_NH; ++u) {
-      const int row = u * 8 + wave;
-      if (row >= CC_HROWS) break;  // wave-uniform
+  constexpr int NPIECES = CC_NH + NW;
+  // piece p of a stage: p < CC_NH -> halo row p*8 + wave, else packed-weight row (p - CC_NH)*8 + wave (1 KiB each: 16 bytes per lane); rows past the end: no piece (wave-uniform)
+  auto piece_row = [&](int p) __attribute__((always_inline)) { return (p < CC_NH ? p : p - CC_NH) * 8 + wave; };
+  auto piece_on = [&](int p) __attribute__((always_inline)) { return p < CC_NH ? piece_row(p) < CC_HROWS : (p < NPIECES && piece_row(p) < WROWS); };
+  auto piece_src = [&](const Tile& t, int ch, int p) __attribute__((always_inline)) -> const void* {
+    if (p < CC_NH) {
+      const int u = p;
+      const int64_t ivox = (((int64_t)t.n * X + (t.x0 - 1)) * Y + (t.y0 - 1)) * Z + (t.z0 - 1);
+      const char* org = (ch >= k.in_csplit_ch ? k.in1 : k.in0) + ivox * k.in_vox_bytes + ch * CC_VB;
+      const int ix = t.x0 - 1, iy = t.y0 - 1, iz = t.z0 - 1;
       // branch-free bounds test (boundary tiles are 2/3 of a 96x32x128 level: the zero padding of the convolution comes from the zero page)
       const unsigned h = hxyz[u];
       const int gx = ix + (int)(h & 255u), gy = iy + (int)((h >> 8) & 255u), gz = iz + (int)((h >> 16) & 255u);
       const bool ok = (h != 0xffffffffu) & ((unsigned)gx < (unsigned)X) & ((unsigned)gy < (unsigned)Y) & ((unsigned)gz < (unsigned)Z);
-      vsseg_dma16(ok ? (const void*)(org + rel[u]) : k.zeros, Hdst + row * 1024);
+      return ok ? (const void*)(org + rel[u]) : k.zeros;
     }
-    const char* wsrc = k.wpack + ((int64_t)(split * nch + ch) * WROWS) * 1024 + lane * 16;
-    char* Wdst = Hdst + CC_HBYTES;
+    return k.wpack + ((int64_t)(split * nch + ch) * WROWS + piece_row(p)) * 1024 + lane * 16;
+  };
+  auto piece_dst = [&](int buf, int p) __attribute__((always_inline)) { return smem + buf * BUF + (p < CC_NH ? 0 : CC_HBYTES) + piece_row(p) * 1024; };  // (wave base: + lane*16 for a register store)
+  auto issue_piece = [&](const Tile& t, int ch, int buf, int p) __attribute__((always_inline)) {
+    if (piece_on(p)) vsseg_dma16(piece_src(t, ch, p), piece_dst(buf, p));
+  };
+  auto issue = [&](const Tile& t, int ch, int buf) {
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int row = i * 8 + wave;
-      if (row >= WROWS) break;
-      vsseg_dma16(wsrc + row * 1024, Wdst + row * 1024);
-    }
+    for (int p = 0; p < NPIECES; ++p) issue_piece(t, ch, buf, p);
   };
 
   __syncthreads();  // epilogue constants visible
@@ -201,10 +203,9 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
         }
       }
     }
-    if (s + 1 < nstages) {
+    const bool more = s + 1 < nstages;
+    if (more) {
       if (ch_issue == 0) t_issue = tile_of(ti_issue);
-      issue(t_issue, ch_issue, (s + 1) & 1);
-      if (++ch_issue == nch) { ch_issue = 0; ++ti_issue; }
     }
     {
       // K loop: the fragments of step ks+1 are read before the MFMAs of step ks are issued (two register sets), so that a wave's LDS latency
@@ -229,7 +230,13 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ac[m], acc[m][t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) {
+            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ac[m], acc[m][t], 0, 0, 0);
+            // piece ks of the NEXT stage, in the middle of this K-step's MFMAs: an LDS-DMA instruction holds its wave for ~85 cycles (a per-CU serial resource);
+            // issued here the SIMD's other wave multiplies meanwhile.  All NPIECES of them back to back at the top of the stage, as rounds 2-5 had it, stopped both waves of
+            // every SIMD at once: 380 us per launch (96 -> 48 at 96x32x128 x 4) against 322 us this way and 283 us with no fetch at all
+            if (m == 1 && t == NT - 1 && ks < NPIECES && more) issue_piece(t_issue, ch_issue, (s + 1) & 1, ks);
+          }
         __builtin_amdgcn_sched_barrier(0);
         if (ks + 1 < CC_KS) {
 #pragma unroll
@@ -239,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
         }
       }
     }
+    if (more && ++ch_issue == nch) { ch_issue = 0; ++ti_issue; }
     if (!last) { ++ch_cur; continue; }
     ch_cur = 0;
     ++ti_cur;
