@@ -26,6 +26,41 @@ def test_normalize_intensity_matches_host():
         np.testing.assert_allclose(y.cpu().numpy(), DO.host_normalize_intensity(v), atol=2e-5)
 
 
+@pytest.mark.parametrize("dims,origin,c,dtype", [
+    ((16, 12, 24), (0, 0, 0), 1, torch.bfloat16),      # the network input of a training step: plain cast into the compact layout (four z per thread)
+    ((16, 12, 24), (-3, 5, -2), 1, torch.float32),     # a sliding-window crop hanging over three faces of the volume (zero padding), unaligned rows
+    ((16, 12, 24), (4, -7, 6), 8, torch.bfloat16),     # zero-extended to one 8-channel group
+    ((16, 12, 22), (2, 1, 3), 1, torch.bfloat16),      # z % 4 != 0: the scalar kernel
+    ((8, 8, 12), (-2, -2, 13), 1, torch.float32),      # z range partly / rows entirely outside
+])
+def test_stage_input_crops_pads_and_casts(dims, origin, c, dtype):
+    """vsseg_stage_input (the window crop of the sliding-window predictor, ref:params/VSparams.py:553-567, and the cast of the network input): out[b][q] = vol[b][q + origin], zero
+    outside the volume, channel 0 of a c-channel row — both kernels (four z-consecutive voxels per thread / one voxel per thread), bit-exact against a numpy restatement."""
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    n, src = 2, (19, 17, 29)
+    vol = rng.standard_normal((n, *src)).astype(np.float32)
+    ref = np.zeros((n, *dims), np.float32)
+    for ax_x in range(dims[0]):
+        gx = ax_x + origin[0]
+        if not 0 <= gx < src[0]:
+            continue
+        for ax_y in range(dims[1]):
+            gy = ax_y + origin[1]
+            if not 0 <= gy < src[1]:
+                continue
+            z0, z1 = max(0, -origin[2]), min(dims[2], src[2] - origin[2])
+            if z1 > z0:
+                ref[:, ax_x, ax_y, z0:z1] = vol[:, gx, gy, z0 + origin[2]:z1 + origin[2]]
+    out = torch.full((n, *dims, c), 7.0, dtype=dtype, device="cuda")
+    dst = L.Tensor(out.data_ptr(), L.F32 if dtype == torch.float32 else L.BF16, c, c, n, *dims)
+    L.check(lib.vsseg_stage_input(torch.from_numpy(vol).cuda().data_ptr(), n, L.i3(src), L.i3(origin), dst, torch.cuda.current_stream().cuda_stream))
+    got = out.float().cpu().numpy()
+    want = torch.from_numpy(ref).to(dtype).float().numpy()
+    np.testing.assert_array_equal(got[..., 0], want)
+    assert not got[..., 1:].any()
+
+
 def _case(vol, lab):
     return {"image": torch.from_numpy(vol).cuda(), "label": torch.from_numpy(lab).cuda()}
 

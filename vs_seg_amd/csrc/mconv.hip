@@ -87,6 +87,10 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   constexpr int G = CIN / 8, CINB = CIN * 2, RS = TZ * G, RPM = 16 / TZ, TYB = MT * 4 * RPM, ROWS = TYB + 2;
   constexpr int PLANE_SLOTS = ROWS * RS, PLANE_BYTES = (PLANE_SLOTS * 16 + 255) / 256 * 256, NINST = (PLANE_SLOTS + 255) / 256;  // ring slots start on a 256-byte bank row
   constexpr int KSTEPS = PS ? (4 * G + 3) / 4 : (9 * G + 3) / 4, KSW = KSTEPS, W_BYTES = WREG ? 0 : KSW * NT * 1024;
+  // the 64-channel launches (18 K-steps per plane, 36+ MFMAs per wave): the next plane's LDS-DMA instructions are issued one at a time BETWEEN the K-steps — an LDS-DMA holds its
+  // wave ~85 cycles of a per-CU serial resource, and all of a wave's pieces in front of its K loop kept the matrix pipe idle that long: 64 -> 32 at 192x64x128 x 4
+  // 0.33 -> 0.29 ms.  The shorter K loops (16 / 32 channels: HBM-bound, a plane's MFMAs do not cover the issue) measured 3-15 % SLOWER that way (tools/bench_mconv.py)
+  constexpr bool SPREAD = KSTEPS >= 18 && CC == 0;
   constexpr int MT_BYTES = RPM * RS * 16;  // LDS bytes between consecutive M-tiles (RPM rows)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Wl = smem;
@@ -157,6 +161,14 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
   const int64_t col0 = (((int64_t)n * X) * Y + y0) * Z + z0;  // voxel (n, 0, y0, z0)
   const char* org0 = k.in0 + col0 * k.in_vox_bytes;
   const char* org1 = k.in1 + col0 * k.in_vox_bytes;
+  auto issue_piece = [&](int i, int u) __attribute__((always_inline)) {
+    const int x = xb - 1 + i;
+    char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES;
+    const bool inside = (unsigned)x < (unsigned)X;
+    const char* p0 = org0 + (int64_t)x * plane_stride;
+    const char* p1 = org1 + (int64_t)x * plane_stride;
+    if ((okmask >> u) & 1u) vsseg_dma16(inside ? (const void*)(((p1mask >> u) & 1u ? p1 : p0) + rel[u]) : k.zeros, dst + (u * 4 + wave) * 1024);
+  };
   auto issue = [&](int i) {  // DMA plane i (x = xb - 1 + i) into ring slot i & 3; planes outside the image are zero
     const int x = xb - 1 + i;
     char* dst = Rl + (i & (MC_NR - 1)) * PLANE_BYTES;
@@ -320,8 +332,9 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
     if (i < steps) load_aux(i + 1, auxn, gaten);         // next step's auxiliary operand, in front of the DMAs
     if (i + 2 <= steps + 1) {
       if constexpr (C1) loadc(i + 2, cvn);
-      else { load_gate(i + 2, gin); issue(i + 2); }
+      else { load_gate(i + 2, gin); if constexpr (!SPREAD) issue(i + 2); }
     }
+    const bool spread_on = SPREAD && i + 2 <= steps + 1;
     const int sm1 = ((i - 1) & (MC_NR - 1)) * PLANE_BYTES, s0 = (i & (MC_NR - 1)) * PLANE_BYTES, sp1 = ((i + 1) & (MC_NR - 1)) * PLANE_BYTES;
 
     f32x4 acc[MT][NT];
@@ -356,6 +369,13 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(const MconvK k) {
 #pragma unroll
             for (int t = 0; t < NR; ++t) racc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres[ks >= KLO ? ks - KLO : 0][t], av, racc[m][t], 0, 0, 0);
           }
+        }
+      }
+      if constexpr (SPREAD) {  // the next plane's DMA pieces between the K-steps instead of all in front of them
+        if (spread_on) {
+#pragma unroll
+          for (int u = 0; u < NINST; ++u)
+            if (ks == (KSTEPS > NINST ? (u * KSTEPS) / NINST : (u < KSTEPS ? u : KSTEPS - 1))) issue_piece(i + 2, u);
         }
       }
     }
