@@ -14,7 +14,11 @@
 //     step), every LDS offset an instruction immediate; per K-step and wave 4 + NT ds_read_b128 feed 4 x NT MFMAs (LDS pipe <= 60 % busy)
 //   * both operands of a chunk — the halo (6x10x18 voxels x 16 channels = 34 KiB) and the packed weights (14 x NT KiB) — arrive by LDS-DMA
 //     into one of two LDS buffers while the other is multiplied: one counted `s_waitcnt vmcnt` + one s_barrier per stage, nothing inside the K
-//     loop waits on memory.  The DMAs are issued from inline assembly (common.h) so hipcc keeps its `vmcnt(0)` out of the K loop
+//     loop waits on memory.  The DMAs are issued from inline assembly (common.h) so hipcc keeps its `vmcnt(0)` out of the K loop — ONE per
+//     K-step, between the MFMAs of the step (round 6): an LDS-DMA instruction holds its wave ~85 cycles of a per-CU serial resource, and the
+//     9-11 of them a wave issues per stage, back to back at the top of the stage as rounds 2-5 had it, stopped both waves of every SIMD at once
+//     (96 -> 48 at 96x32x128 x 4: 380 us that way, 322 us this way, 283 us with the fetch removed; the register path global_load -> ds_write_b128
+//     measured 354 us: DESIGN.md 3.15)
 //   * same packed weights, K order, fp32 accumulation order and epilogue semantics as the general kernel: results agree bit for bit
 //     (tests/test_gpu_ops.py::test_compute_kernel_equals_general_kernel); XCD-contiguous persistent tile walk, one workgroup per CU
 #include "common.h"
@@ -133,6 +137,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
   };
   // ---- LDS-DMA of one stage = (tile, 16-channel chunk): halo chunk + packed weights of the chunk into buffer `buf` ----
   constexpr int NPIECES = CC_NH + NW;
+  static_assert(NPIECES <= CC_KS, "one DMA piece per K-step");
   // piece p of a stage: p < CC_NH -> halo row p*8 + wave, else packed-weight row (p - CC_NH)*8 + wave (1 KiB each: 16 bytes per lane); rows past the end: no piece (wave-uniform)
   auto piece_row = [&](int p) __attribute__((always_inline)) { return (p < CC_NH ? p : p - CC_NH) * 8 + wave; };
   auto piece_on = [&](int p) __attribute__((always_inline)) { return p < CC_NH ? piece_row(p) < CC_HROWS : (p < NPIECES && piece_row(p) < WROWS); };
@@ -232,9 +237,7 @@ __global__ __launch_bounds__(512, 2) void cconv_kernel(const CconvK k) {
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ac[m], acc[m][t], 0, 0, 0);
-            // piece ks of the NEXT stage, in the middle of this K-step's MFMAs: an LDS-DMA instruction holds its wave for ~85 cycles (a per-CU serial resource);
-            // issued here the SIMD's other wave multiplies meanwhile.  All NPIECES of them back to back at the top of the stage, as rounds 2-5 had it, stopped both waves of
-            // every SIMD at once: 380 us per launch (96 -> 48 at 96x32x128 x 4) against 322 us this way and 283 us with no fetch at all
+            // piece ks of the NEXT stage, in the middle of this K-step's MFMAs (header: the SIMD's other wave multiplies while this one sits in the DMA instruction)
             if (m == 1 && t == NT - 1 && ks < NPIECES && more) issue_piece(t_issue, ch_issue, (s + 1) & 1, ks);
           }
         __builtin_amdgcn_sched_barrier(0);
