@@ -1560,6 +1560,105 @@ def test_class_split_launch_equals_per_class_launches(kind, cin, cout, fine, mod
     assert lib.vsseg_igemm(C.byref(bad), H.stream()) == L.EINVAL and b"class_split" in lib.vsseg_last_error()
 
 
+@pytest.mark.parametrize("kind,cin,cout,coarse,mode,n", [("convT_fwd", 64, 48, (8, 8, 16), "stats", 2), ("convT_fwd", 64, 48, (4, 16, 8), "plain", 1), ("convT_fwd", 64, 48, (4, 8, 8), "eval", 3),
+                                                        ("conv_dgrad", 48, 48, (8, 16, 8), "accumulate", 2), ("conv_dgrad", 48, 48, (4, 8, 16), "plain", 1)])
+def test_transition_kernel_equals_class_split_launch_and_definition(kind, cin, cout, coarse, mode, n):
+    """Launch plans with depth -8 (csrc/tconv.hip): the eight output-parity classes of the 3x3x3 stride-(2,2,2) transposed convolution 64 -> 48 / of the data gradient of the
+    strided convolution 48 -> 48 between levels 2 and 3 (ref:params/networks/nets/unet2d5_spvPA.py:56-93) in one launch — against torch's fp64 result, and BIT FOR BIT
+    against the class-split launch of the general kernel on the same packed weights (same K order, one accumulator chain per output value), for the epilogues the network
+    uses there (statistics, plain, eval affine + PReLU, accumulate), tiles on every face of the volume, several tiles per workgroup."""
+    lib = L.lib()
+    k, st = (3, 3, 3), (2, 2, 2)
+    torch.manual_seed(29)
+    tdt = torch.bfloat16
+    fine = tuple(2 * c for c in coarse)
+    if kind == "convT_fwd":
+        x = _round(torch.randn(n, cin, *coarse), "bf16")
+        w = _round(torch.randn(cin, cout, *k) / (cin * 27 / 8) ** 0.5, "bf16")
+        want = F.conv_transpose3d(x.double(), w.double(), stride=st, padding=1, output_padding=1)
+        inp_cl, nout = H.to_cl(x, tdt, cin), cout
+    else:
+        w = _round(torch.randn(cout, cin, *k) / (cout * 27 / 8) ** 0.5, "bf16")
+        xd = torch.zeros(n, cin, *fine, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xd, w.double(), stride=st, padding=1)
+        gy = _round(torch.randn(*y.shape), "bf16")
+        y.backward(gy.double())
+        want, inp_cl, nout = xd.grad, H.to_cl(gy, tdt, cout), cin
+    assert tuple(want.shape[2:]) == fine and tuple(inp_cl.shape[1:4]) == coarse
+    bias = torch.randn(nout, device="cuda")
+    want = want + bias.cpu().double().view(1, -1, 1, 1, 1)
+    prev = H.to_cl(_round(torch.randn(n, nout, *fine), "bf16"), tdt)
+    kw = dict(bias=bias.data_ptr())
+    keep = []
+    if mode == "accumulate":
+        kw["accumulate"] = 1
+        want = want + H.from_cl(prev).double()
+    elif mode == "eval":
+        sc, sh, al = torch.rand(nout, device="cuda") + 0.5, torch.randn(nout, device="cuda"), torch.tensor([0.2], device="cuda")
+        keep += [sc, sh, al]
+        kw.update(scale=sc.data_ptr(), shift=sh.data_ptr(), alpha=al.data_ptr(), act=L.ACT_PRELU)
+        want = want * sc.cpu().double().view(1, -1, 1, 1, 1) + sh.cpu().double().view(1, -1, 1, 1, 1)
+        want = torch.where(want > 0, want, 0.2 * want)
+
+    def stats_buf():
+        return torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+
+    def epi(sbuf):
+        return dict(stats=sbuf.data_ptr(), stats_stride=P.round_up(nout, 16), **kw) if mode == "stats" else kw
+
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    tps = P.transition_plans(kind, tuple(w.shape), k, st, coarse, 2, inp_cl.shape[-1], nreal, kreal)
+    assert len(tps) == 1 and tps[0].depth == -8 and len(tps[0].classes) == 8
+    tp = tps[0]
+    out_t = prev.clone() if mode == "accumulate" else torch.full((n, *fine, nout), float("nan"), dtype=tdt, device="cuda")
+    st_t = stats_buf()
+    d = H.igemm_desc(tp, H.pack(tp, w, tdt), H.tdesc(inp_cl), H.tdesc(out_t), **epi(st_t))
+    assert lib.vsseg_igemm_lds_bytes(C.byref(d)) == tp.lds == P.transition_lds_bytes(inp_cl.shape[-1])
+    L.check(lib.vsseg_igemm(C.byref(d), H.stream()), "transition kernel")
+    torch.cuda.synchronize()
+    got = H.from_cl(out_t)
+    assert not torch.isnan(got).any()
+    np.testing.assert_allclose(got.numpy(), want.float().numpy(), atol=_tol("bf16", want))
+    # the class-split launch of the general kernel with the whole input in one channel chunk: the same accumulator chain per output value
+    csp = [pl for pl in P.class_split_plans(kind, tuple(w.shape), k, st, coarse, 2, inp_cl.shape[-1], nreal, kreal, aux_es=2 if mode == "accumulate" else 0) if pl.nchunks == 1]
+    assert csp
+    out_c = prev.clone() if mode == "accumulate" else torch.zeros_like(out_t)
+    st_c = stats_buf()
+    dc = H.igemm_desc(csp[0], H.pack(csp[0], w, tdt), H.tdesc(inp_cl), H.tdesc(out_c), **epi(st_c))
+    L.check(lib.vsseg_igemm(C.byref(dc), H.stream()), "class split")
+    torch.cuda.synchronize()
+    assert torch.equal(out_t, out_c), f"max {float((out_t.float() - out_c.float()).abs().max())}"
+    if mode == "stats":
+        a, b = H.stat_decode(st_c).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(st_t).view(L.STAT_SHARDS, 2, -1).sum(0)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_transition_kernel_rejects_what_it_does_not_cover():
+    lib = L.lib()
+    k, st = (3, 3, 3), (2, 2, 2)
+    w = torch.randn(64, 48, *k)
+    kreal, nreal = P.gemm_dims("convT_fwd", tuple(w.shape))
+    assert P.transition_plans("convT_fwd", tuple(w.shape), k, st, (6, 8, 8), 2, 64, nreal, kreal) == []      # x extent not a multiple of the tile
+    assert P.transition_plans("convT_fwd", (80, 64, *k), k, st, (8, 8, 8), 2, 80, 64, 80) == []               # 80 -> 64: the deep-level kernel's
+    assert P.transition_plans("conv_fwd", (48, 48, *k), k, st, (8, 8, 8), 2, 48, 48, 48) == []
+    tp = P.transition_plans("convT_fwd", tuple(w.shape), k, st, (4, 8, 8), 2, 64, nreal, kreal)[0]
+    x = torch.zeros(1, 4, 8, 8, 64, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 8, 16, 16, 48, dtype=torch.bfloat16, device="cuda")
+    wp = H.pack(tp, w, torch.bfloat16)
+
+    def rejected(mutate, what):
+        d = H.igemm_desc(tp, wp, H.tdesc(x), H.tdesc(out))
+        mutate(d)
+        assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL and b"transition kernel" in lib.vsseg_last_error(), what
+
+    rejected(lambda d: setattr(d, "mtw", 8), "mtw")
+    rejected(lambda d: setattr(d, "class_split", 4), "class_split")
+    rejected(lambda d: setattr(d, "res_mode", L.RES_ADD), "residual epilogue")
+    o32 = torch.zeros(1, 8, 16, 16, 48, dtype=torch.float32, device="cuda")
+    d = H.igemm_desc(tp, wp, H.tdesc(x), H.tdesc(o32))
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL and b"bf16" in lib.vsseg_last_error()
+
+
 DEEP_CASES = [
     # kind, kernel, stride, cin, cout, spatial size of the FINER side, mode, input split
     ("conv_fwd", (3, 3, 3), (1, 1, 1), 160, 80, (6, 8, 8), "stats", 80),       # level-4 decoder unit on the two-part concat

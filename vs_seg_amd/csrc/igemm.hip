@@ -5,6 +5,7 @@
 #include "cconv.h"
 #include "mconv.h"
 #include "dconv.h"
+#include "tconv.h"
 #include "chain.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
@@ -190,6 +191,7 @@ extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && d->depth == -3) return vsseg_cconv_lds_bytes(d);
   if (d && (d->depth == -5 || d->depth == -6)) return vsseg_mconv_lds_bytes(d);
   if (d && d->depth == -7) return vsseg_dconv_lds_bytes(d);
+  if (d && d->depth == -8) return vsseg_tconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
@@ -221,6 +223,12 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_dconv_launch(d, z, as_stream(stream));
+  }
+  if (d && d->depth == -8) {  // transition kernel (tconv.hip: the eight parity classes of a 3x3x3 stride-(2,2,2) transition between levels 2 and 3 in one launch): same contract
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_tconv_launch(d, z, as_stream(stream));
   }
   IgemmK k;
   int lds = igemm_prepare(d, k);

@@ -248,10 +248,12 @@ class Plan:
                 csp = P.class_split_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, aux_es=aux_es, in_split=in_split) if kind in ("convT_fwd", "conv_dgrad") else None
                 # ... or of the deep-level kernel (csrc/dconv.hip: a workgroup loads the halo of its coarse tile once and runs the classes one after the other)
                 dcp = P.deep_class_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, self.n, in_split) if (eng.deep != "0" and kind in ("convT_fwd", "conv_dgrad")) else []
+                # ... or of the transition kernel (csrc/tconv.hip: levels 2 <-> 3, the waves split the voxels, a stage per class)
+                tcp = P.transition_plans(kind, Lr.wshape, Lr.kernel, Lr.stride, q, eng.es, kc_pad, nreal, kreal, in_split) if (eng.transition and self.tune and kc_pad is not None and kind in ("convT_fwd", "conv_dgrad")) else []
                 if eng.deep == "force" and dcp:
                     alt = _Choice(dcp if self.tune else dcp[:1], woff, wshape=tuple(Lr.wshape))
-                elif csp or (dcp and self.tune):  # an alternative to the per-class launches below, decided per op at lowering time (Plan._use_class_split)
-                    alt = _Choice(((csp or []) + dcp) if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))
+                elif csp or ((dcp or tcp) and self.tune):  # an alternative to the per-class launches below, decided per op at lowering time (Plan._use_class_split)
+                    alt = _Choice(((csp or []) + dcp + tcp) if self.tune else csp[:1], woff, wshape=tuple(Lr.wshape))
             for cls in P.lattice_classes(kind, Lr.kernel, Lr.stride):
                 if fold:  # one real input or output channel, no taps along z: 8 z-neighbours become the channel group (planner.FOLD)
                     cands = P.folded_candidate_plans(kind, Lr.wshape, cls, q, eng.es, aux_es=aux_es, heuristic_only=not self.tune)
@@ -1462,6 +1464,7 @@ class Engine:
         self.fuse_classes = not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = True  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch of round 6: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
+        self.transition = os.environ.get("VSSEG_TRANSITION", "1") != "0"  # A/B switch of round 6: the level 2 <-> 3 transition kernel (csrc/tconv.hip, depth -8)
         self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
         self.gate_fuse = True  # attention-gate backward fused into the attention conv's data gradient

@@ -653,6 +653,44 @@ def deep_class_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, n=1,
     return out
 
 
+# ---- transition kernel (csrc/tconv.hip): depth -8 -----------------------------------------------------------------------
+TRANSITION_TILE = (4, 8, 8)
+
+
+def transition_lds_bytes(kc: int) -> int:
+    """Mirror of tc_lds_bytes() in csrc/tconv.hip: K-group table of the eight classes | epilogue constants | statistics rows | halo (5x9x9 coarse voxels, voxel stride padded
+    to an odd number of 16-byte units, whole 1 KiB DMA rows) | two weight buffers of the 8-tap class."""
+    cg = kc // 8
+    ksmax = (8 * cg + 3) // 4
+    off_epi = 8 * ksmax * 4 * 4
+    off_stat = off_epi + 3 * 3 * 16 * 4
+    off_halo = round_up(off_stat + 4 * 2 * 3 * 16 * 4, 1024)
+    hrows = (5 * 9 * 9 * (cg | 1) + 63) // 64
+    return off_halo + hrows * 1024 + 2 * ksmax * 3 * 1024
+
+
+def transition_plans(kind, wshape, kernel, stride, q, es, kc, nreal, kreal, in_split=0) -> List["IgemmPlan"]:
+    """All eight output-parity classes of a 3x3x3 stride-(2,2,2) transposed convolution / strided data gradient with 48 or 64 input and 48 output channels (the transition
+    between the 96x32x128 and 48x16x64 levels) as ONE launch of the transition kernel: 4x8x8 coarse tiles, the waves split the voxels, a stage per class (csrc/tconv.hip)."""
+    if kind not in ("convT_fwd", "conv_dgrad") or es != 2 or tuple(kernel) != (3, 3, 3) or tuple(stride) != (2, 2, 2) or kc not in (48, 64) or in_split or nreal != 48:
+        return []
+    if any(q[a] % TRANSITION_TILE[a] for a in range(3)):
+        return []
+    classes = lattice_classes(kind, kernel, stride)
+    if len(classes) != 8 or max(len(c.taps) for c in classes) > 8:
+        return []
+    offs = sorted({off for c in classes for off, _ in c.taps})
+    for a in range(3):
+        lo, hi = min(o[a] for o in offs), max(o[a] for o in offs)
+        if hi - lo != 1 or lo not in (0, -1):
+            return []
+    union = LatticeClass(classes[0].os, (0, 0, 0), classes[0].is_, [(off, (0, 0, 0)) for off in offs])
+    pl = IgemmPlan(kind, union, tuple(q), kc, nreal, kreal, TRANSITION_TILE, 16, 3, 8, kc, 1, (8 * (kc // 8) + 3) // 4, transition_lds_bytes(kc), -8)
+    pl.classes = classes
+    pl.pack_map = pack_map(pl, wshape)
+    return [pl]
+
+
 VSSEG_MAX_TAPS = 27
 
 
