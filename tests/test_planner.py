@@ -119,6 +119,45 @@ def test_class_split_plans_cover_every_parity_class_in_one_launch(k, s, cin, cou
         np.testing.assert_allclose(P.simulate_igemm(pl, gyc, w2.numpy().reshape(-1), tuple(x2.shape[2:])), _cl(x2.grad), atol=1e-9)
 
 
+@pytest.mark.parametrize("kind,cin,cout", [("convT_fwd", 64, 48), ("conv_dgrad", 48, 48)])
+def test_transition_plans_compute_the_transition_and_mirror_the_kernels_lds(kind, cin, cout):
+    """planner.transition_plans (csrc/tconv.hip, depth -8): one plan whose eight workgroup stages are the parity classes of the 3x3x3 stride-(2,2,2) transposed convolution /
+    strided data gradient between levels 2 and 3; its packed weights simulate to torch's result (numpy restatement of the kernel's indexing), its LDS request is the kernel's,
+    and nothing outside the two layers gets a plan."""
+    import ctypes
+
+    from tests import gpu_harness as H
+    from vs_seg_amd import _lib as L
+
+    k, s, coarse = (3, 3, 3), (2, 2, 2), (4, 8, 8)
+    fine = tuple(2 * c for c in coarse)
+    torch.manual_seed(6)
+    if kind == "convT_fwd":
+        x = torch.randn(1, cin, *coarse, dtype=torch.float64)
+        w = torch.randn(cin, cout, *k, dtype=torch.float64)
+        want = F.conv_transpose3d(x, w, stride=s, padding=1, output_padding=1)
+        xin, kc = _cl(x), cin
+    else:
+        w = torch.randn(cout, cin, *k, dtype=torch.float64)
+        xd = torch.zeros(1, cin, *fine, dtype=torch.float64, requires_grad=True)
+        y = F.conv3d(xd, w, stride=s, padding=1)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        want, xin, kc = xd.grad, _cl(gy), cout
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    plans = P.transition_plans(kind, tuple(w.shape), k, s, coarse, 2, kc, nreal, kreal)
+    assert len(plans) == 1
+    pl = plans[0]
+    assert pl.depth == -8 and pl.tile == P.TRANSITION_TILE and pl.mtw == 16 and pl.nt == 3 and pl.nsplit == 8 and len(pl.classes) == 8 and pl.ck == kc and pl.nchunks == 1
+    assert sorted(len(c.taps) for c in pl.classes) == [1, 2, 2, 2, 4, 4, 4, 8] and pl.lds == P.transition_lds_bytes(kc) <= P.LDS_LIMIT
+    np.testing.assert_allclose(P.simulate_igemm(pl, xin, w.numpy().reshape(-1), fine), _cl(want), atol=1e-9)
+    d = H.igemm_desc(pl, torch.zeros(1), L.Tensor(4096, L.BF16, kc, kc, 1, *coarse), L.Tensor(8192, L.BF16, 48, 48, 1, *fine))
+    assert L.lib().vsseg_igemm_lds_bytes(ctypes.byref(d)) == pl.lds, L.lib().vsseg_last_error()
+    assert P.transition_plans(kind, tuple(w.shape), k, s, (6, 8, 8), 2, kc, nreal, kreal) == []     # extent not a multiple of the 4x8x8 tile
+    assert P.transition_plans(kind, tuple(w.shape), k, s, coarse, 4, kc, nreal, kreal) == []        # fp32
+    assert P.transition_plans("convT_fwd", (80, 64, *k), k, s, (8, 8, 8), 2, 80, 64, 80) == []      # levels 3 -> 4: the deep-level kernel's
+
+
 def test_small_lds_budget_forces_channel_chunks():
     torch.manual_seed(2)
     k, s = (3, 3, 3), (1, 1, 1)

@@ -51,6 +51,14 @@ struct TconvK {
 };
 
 __device__ __forceinline__ unsigned tc_div(unsigned n, unsigned magic) { return magic ? __umulhi(n, magic) : n; }
+// The MFMAs are inline assembly with the accumulator tied in place ("+a"): with the builtin hipcc rotated five of the twelve accumulator tiles of the K loop through a[0:3]
+// (four v_accvgpr_mov and two s_nop behind every one of those MFMAs: the K loop ran at a third of its MFMA time).  hipcc pads no hazards around inline assembly (cwgrad.hip):
+// PAD = two wait states in front of the first MFMA of a block (a VALU move of an operand register may sit right in front of it), tc_mfma_drain before the results are read.
+template <bool PAD> __device__ __forceinline__ void tc_mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  if constexpr (PAD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void tc_mfma_drain() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory"); }
 
 // MODE: 0 plain, 1 + BatchNorm statistics, 2 accumulate (out += ...), 3 eval affine + activation
 template <int CG, int MODE>
@@ -91,7 +99,9 @@ __global__ __launch_bounds__(TC_THREADS, 1) void tconv_kernel(const TconvK k) {
     hrel[u] = ok ? ((hx * Y + hy) * Z + hz) * k.in_vox_bytes + pc * 16 : 0;
     hxyz[u] = ok ? (unsigned)(hx | (hy << 8) | (hz << 16)) : 0xffffffffu;
   }
-  // ---- this lane's voxel of each of its wave's M-tiles: v = (wave*MT + m)*16 + l15 -> (vx, vy, vz) = (v >> 6, (v >> 3) & 7, v & 7) ----
+  // ---- this lane's voxel of each of its wave's M-tiles: v = (wave*MT + m)*16 + l15 -> (vx, vy, vz) = (v >> 6, (v >> 3) & 7, v & 7): two y-rows of eight z.  (The operand reads of
+  //      this mapping are not conflict-free — SQ_LDS_BANK_CONFLICT is half of SQ_LDS_IDX_ACTIVE; the lane order that the LDS model of tools/lds_conflicts.py prefers, even z
+  //      on lanes 0-3 / 12-15 and odd z on lanes 4-11, measured 5-12 % SLOWER: the K loop is not what bounds this kernel) ----
   int abase[MT], ofine[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -173,40 +183,55 @@ __global__ __launch_bounds__(TC_THREADS, 1) void tconv_kernel(const TconvK k) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wc[NT], ac[MT], wn[NT], an[MT];
-    {
-      const int koff = kt[0];
+    // K loop: a ring of three operand sets, the fragments of K-step i + 2 are requested while K-step i multiplies (one wave per SIMD: with the next step only, the wave stood in
+    // s_waitcnt lgkmcnt(0) behind every block of twelve MFMAs — four waves' 28 KiB of fragment reads per K-step queue in the LDS — and with two sets and register copies it also
+    // paid 28 v_mov per step: 640 cycles per K-step against 192 of MFMA time).  The loop is unrolled by three so that the sets are named statically; clamped indices, no branch
+    // around a load (the last steps re-read the final fragments).
+    bf16x8 wr[3][NT], ar[3][MT];
+    auto ld = [&](auto sc, int kidx, int koff) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wc[t] = *reinterpret_cast<const bf16x8*>(Ws + t * 1024);
+      for (int t = 0; t < NT; ++t) wr[S][t] = *reinterpret_cast<const bf16x8*>(Ws + (kidx * NT + t) * 1024);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) ac[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff);
-    }
-    int koff_n = kt[(1 < last ? 1 : last) * 4];
-    for (int ks = 0; ks < nks; ++ks) {
-      const int nx = ks + 1 < last ? ks + 1 : last, nx2 = ks + 2 < last ? ks + 2 : last;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) wn[t] = *reinterpret_cast<const bf16x8*>(Ws + (nx * NT + t) * 1024);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) an[m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff_n);
-      koff_n = kt[nx2 * 4];
+      for (int m = 0; m < MT; ++m) ar[S][m] = *reinterpret_cast<const bf16x8*>(halo + abase[m] + koff);
+    };
+    int koff_q;  // the K-group offset of the K-step whose fragments are requested next
+    auto step = [&](auto sc, int ks) __attribute__((always_inline)) {
+      constexpr int S = decltype(sc)::value, S2 = (S + 2) % 3;
+      const int k2 = ks + 2 < last ? ks + 2 : last, k3 = ks + 3 < last ? ks + 3 : last;
+      ld(std::integral_constant<int, S2>{}, k2, koff_q);
+      koff_q = kt[k3 * 4];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[t], ac[m], acc[m][t], 0, 0, 0);
-        if (m == 1) {
-          for (int j = 0; j < per_ks; ++j) {
-            if (nrow < nrows) vsseg_dma16(nsrc + nrow * 1024, ndst + nrow * 1024);
-            nrow += TC_WAVES;
-          }
+        for (int t = 0; t < NT; ++t) {
+          if (m == 0 && t == 0) tc_mfma<true>(acc[m][t], wr[S][t], ar[S][m]);
+          else tc_mfma<false>(acc[m][t], wr[S][t], ar[S][m]);
         }
-      }
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) wc[t] = wn[t];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) ac[m] = an[m];
+      // this K-step's share of the next stage's weight rows, behind the step's MFMAs (they are in the matrix pipe while the wave sits in the DMA instructions)
+      for (int j = 0; j < per_ks; ++j) {
+        if (nrow < nrows) vsseg_dma16(nsrc + nrow * 1024, ndst + nrow * 1024);
+        nrow += TC_WAVES;
+      }
+    };
+    {
+      const int k1 = 1 < last ? 1 : last, k2 = 2 < last ? 2 : last;
+      const int koff0 = kt[0], koff1 = kt[k1 * 4];
+      koff_q = kt[k2 * 4];
+      ld(std::integral_constant<int, 0>{}, 0, koff0);
+      ld(std::integral_constant<int, 1>{}, k1, koff1);
     }
+    int ks = 0;
+    for (; ks + 3 <= nks; ks += 3) {
+      step(std::integral_constant<int, 0>{}, ks);
+      step(std::integral_constant<int, 1>{}, ks + 1);
+      step(std::integral_constant<int, 2>{}, ks + 2);
+    }
+    if (ks < nks) step(std::integral_constant<int, 0>{}, ks);
+    if (ks + 1 < nks) step(std::integral_constant<int, 1>{}, ks + 1);
+    tc_mfma_drain();
     const Tile t_this = t_cur;
     if (ci == 7 && more) {  // the next tile's halo, as soon as every wave has left this tile's last K loop: its latency lies behind this class's epilogue
       t_cur = tile_of((s >> 3) + 1);
