@@ -187,6 +187,11 @@ class Plan:
         x, y, z = self.lv[level]
         return L.Tensor(buf.data_ptr(), _tdtype(buf), c or buf.shape[-1], buf.shape[-1], self.n, x, y, z)
 
+    def _dpre_desc(self, buf: torch.Tensor, level: int) -> L.Tensor:
+        """d(pre-sigmoid) as vsseg_att_apply_bwd writes it: the 8-channel group in front of a row of 8 or 16 channels."""
+        t = self._tdesc(buf, level)
+        return L.Tensor(t.ptr, t.dtype, 8, t.pitch, t.n, t.x, t.y, t.z)
+
     def _pp(self, key: str) -> int:  # device address of a parameter inside the flat fp32 buffer
         return self.flat_ptr + 4 * self.eng.layout.param_off[key][0]
 
@@ -277,6 +282,7 @@ class Plan:
             return out
 
         self.cplans: Dict[str, _ConvPlans] = {}
+        self.wide_dpre: set = set()  # sigmoid convolutions whose d(pre-sigmoid) buffer is 16 channels wide (channel 0 real)
         for op in eng.prog.ops:
             if not isinstance(op, (ConvBnAct, ConvPlain)):
                 continue
@@ -303,7 +309,13 @@ class Plan:
                 if op.x.root.name != eng.prog.input.name:  # the network input needs no gradient
                     dk = "convT_dgrad" if Lr.transposed else "conv_dgrad"
                     q = dims_in if Lr.transposed else tuple((d + s - 1) // s for d, s in zip(dims_in, Lr.stride))
-                    dgrad = choices(dk, Lr, q, P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
+                    # the data gradient of a 3x3x3 C -> 1 convolution (the sigmoid convolutions of levels 2-3) reads d(pre-sigmoid) as ONE 16-channel chunk so that the compute
+                    # kernel (csrc/cconv.hip) is among its candidates: 0.16 -> 0.06 ms at level 2 (the general kernel on an 8-channel zero-extension was the only plan)
+                    wide = (eng.wide_dpre and self.tune and eng.es == 2 and Lr.cout == 1 and not Lr.transposed and Lr.kernel == (3, 3, 3) and tuple(Lr.stride) == (1, 1, 1)
+                            and not any(v % t for v, t in zip(q, P.COMPUTE_TILE)) and P.compute_split(Lr.cin) is not None)
+                    if wide:
+                        self.wide_dpre.add(Lr.prefix)
+                    dgrad = choices(dk, Lr, q, 16 if wide else P.round_up(Lr.cout, 8), eng.es, 0, absorbed)
                 wg = P.plan_wgrad(Lr.transposed, Lr.wshape, Lr.kernel, Lr.stride, dims_in if Lr.transposed else dims_out, eng.es)
             self.cplans[Lr.prefix] = _ConvPlans(fwd, dgrad, wg, fold_fwd)
         # ResidualUnit: the 1x1x1 residual convolution of the SAME input rides along in the unit's first 3x3x1 convolution (vsseg_igemm_desc.res_tiles, csrc/mconv.hip
@@ -1312,9 +1324,9 @@ class Plan:
                 cps = self.cplans[sig.prefix]
                 all_compact = (want_c1 and not sig.transposed and tuple(sig.stride) == (1, 1, 1) and sigop.x.parts is None and sigop.x.base is None and len(cps.dgrad) == 1
                                and self._compact_choice(cps.dgrad[0], sig) is not None)
-                dpre = None if all_compact else self._raw("dpre:" + op.att.name, op.att.level, 8)
+                dpre = None if all_compact else self._raw("dpre:" + op.att.name, op.att.level, 16 if sig.prefix in self.wide_dpre else 8)  # (channels 8..15 of the wide rows are never written: zero)
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
-                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._tdesc(dpre, op.att.level) if dpre is not None else L.Tensor(), None, dpre1],
+                B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._dpre_desc(dpre, op.att.level) if dpre is not None else L.Tensor(), None, dpre1],
                           self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + (8 if dpre is not None else 1) + 4)])
         self._finish_pack()
 
@@ -1464,6 +1476,7 @@ class Engine:
         self.fuse_classes = not dry_run  # output-parity classes of the stride-(2,2,1) level transitions as one launch (depth -4)
         self.keepmask = True  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch of round 6: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
+        self.wide_dpre = os.environ.get("VSSEG_WIDE_DPRE", "1") != "0"  # A/B switch of round 6: 16-channel rows for d(pre-sigmoid) of the 3x3x3 sigmoid convolutions (compute-kernel data gradient)
         self.transition = os.environ.get("VSSEG_TRANSITION", "1") != "0"  # A/B switch of round 6: the level 2 <-> 3 transition kernel (csrc/tconv.hip, depth -8)
         self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions

@@ -552,7 +552,7 @@ def compute_plan(kind, wshape, cls, q, es, kc, nreal, kreal, in_split=0) -> Opti
     offs = [tuple(t[0]) for t in cls.taps]
     if es != 2 or tuple(cls.is_) != (1, 1, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x3:
         return None
-    if any(v % t for v, t in zip(q, COMPUTE_TILE)) or kc % 16 or kc < 32 or kc != round_up(kreal, 16) or (in_split and in_split % 16):
+    if any(v % t for v, t in zip(q, COMPUTE_TILE)) or kc % 16 or (kc < 32 and kreal != 1) or kc != round_up(kreal, 16) or (in_split and in_split % 16):  # (one real channel in a 16-channel chunk: the data gradient of a C -> 1 convolution)
         return None
     sp = compute_split(nreal)
     if sp is None:
