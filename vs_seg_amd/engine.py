@@ -623,7 +623,7 @@ class Plan:
 
     @staticmethod
     def _igemm_name(pl: P.IgemmPlan, inp: L.Tensor) -> str:
-        """Kernel group of a convolution launch in the profiles: which of the four kernels its plan runs on."""
+        """Kernel group of a convolution launch in the profiles: which of the kernels its plan runs on."""
         if pl.depth in (-2, -4):
             return f"sconv<bf16,{pl.nt}>"
         if pl.depth == -3:
@@ -632,6 +632,8 @@ class Plan:
             return f"mconv<bf16,{pl.nt}>"
         if pl.depth == -7:
             return f"dconv<bf16,{pl.mtw},{pl.nt}>"
+        if pl.depth == -8:
+            return f"tconv<bf16,{pl.ck // 8}>"
         return f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"
 
     def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:
