@@ -133,7 +133,7 @@ def roofline_table(full, peak, traffic):
     return rows
 
 
-CONV_GROUPS = ("igemm", "sconv", "cconv", "mconv", "dconv", "tconv", "nconv", "wgrad", "mwgrad", "cwgrad", "mbwd")
+CONV_GROUPS = ("igemm", "sconv", "cconv", "mconv", "dconv", "tconv", "gconv", "nconv", "wgrad", "mwgrad", "cwgrad", "mbwd")
 
 
 def roofline_fractions(events, peak):

@@ -80,7 +80,9 @@ typedef struct {
   int32_t depth;           /* LDS-DMA prefetch distance in stages (1..3; 0 = 1): the halo ring holds depth+1 buffers.  -1: no prefetch, one buffer (half the LDS, more resident workgroups) */
                            /* negative depths below -1 select a specialised kernel with the same contract (outside its domain: VSSEG_EINVAL, never a fallback): -2 / -4 streaming (sconv.hip), -3 compute (cconv.hip),
                             * -5 / -6 marching (mconv.hip), -7 deep levels (dconv.hip), -8 the level 2 <-> 3 transition kernel (tconv.hip: class_split = 8 parity classes of a 3x3x3 stride-(2,2,2) transposed
-                            * convolution / strided data gradient, 48 or 64 input and 48 output channels, tile 4x8x8 with mtw = 16, nt = 3, ck = in.c, bf16, plain / statistics / eval affine / accumulate epilogue) */
+                            * convolution / strided data gradient, 48 or 64 input and 48 output channels, tile 4x8x8 with mtw = 16, nt = 3, ck = in.c, bf16, plain / statistics / eval affine / accumulate epilogue),
+                            * -9 the gathering marching kernel (gconv.hip: is = (2, 2, 1) 3x3x1 launches that read the fine level and write the coarse one — strided convolutions 16 -> 16 / 32 -> 32, data
+                            * gradients of the transposed convolutions 32 -> 16 / 48 -> 32 —, tile = (x steps, 64 * mtw / tz rows, tz), ck = in.c in {16, 32}, one-part bf16 tensors, the same four epilogues) */
   const void* wpack;       /* [nsplit][nchunks][ksteps][nt][64 lanes][8] in the compute dtype (== in.dtype) */
   /* epilogue: v = acc + bias; stats(v); v = v*scale+shift; v = act(v); residual; accumulate; store */
   const float* bias;       /* [cout] or NULL */
@@ -213,7 +215,7 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 6: + launch plans with depth -8 (transition kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------

@@ -842,6 +842,122 @@ def test_marching_kernel_equals_general_kernel(kind, cin, cout, dims, split, sha
                 np.testing.assert_allclose(H.stat_decode(stats).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
 
 
+GATHER_CASES = [
+    # kind, cin, cout (of the layer), COARSE dims, (tz, mtw), x steps per workgroup
+    ("conv_fwd", 16, 16, (6, 32, 8), (4, 2), 4),        # strided convolution level 0 -> 1: one row block, two z blocks, two x segments (4 + 2)
+    ("conv_fwd", 16, 16, (5, 64, 8), (8, 4), 5),        # two row blocks: fine rows 63 / 64 are each other's halo
+    ("conv_fwd", 16, 16, (4, 64, 4), (4, 4), 2),        # 64-row columns
+    ("conv_fwd", 32, 32, (7, 32, 4), (2, 1), 3),        # level 1 -> 2: TZ 2, eight rows per M-tile
+    ("conv_fwd", 32, 32, (5, 32, 8), (4, 2), 5),
+    ("conv_fwd", 32, 32, (4, 64, 8), (4, 2), 4),        # two row blocks
+    ("convT_dgrad", 32, 16, (6, 32, 8), (4, 2), 3),     # data gradient of the transposed convolution 32 -> 16: K = 16 (dy at the fine level), N = 32
+    ("convT_dgrad", 32, 16, (4, 64, 8), (4, 4), 4),
+    ("convT_dgrad", 48, 32, (7, 32, 4), (2, 1), 4),     # ... of 48 -> 32: K = 32, N = 48 (three channel tiles)
+    ("convT_dgrad", 48, 32, (5, 32, 8), (4, 2), 2),
+]
+
+
+@pytest.mark.parametrize("kind,cin,cout,dims,shape,lx", GATHER_CASES)
+def test_gathering_marching_kernel_equals_general_kernel(kind, cin, cout, dims, shape, lx):
+    """depth -9 selects the gathering marching kernel (csrc/gconv.hip: the stride-(2,2,1) 3x3x1 launches that read the fine level and write the coarse one — a workgroup walks
+    along x with a ring of FINE planes, stored as odd-row / even-row half planes).  Same packed weights, K order and fp32 accumulation as the general kernel with the whole
+    input in one chunk: outputs must be IDENTICAL bit for bit in every epilogue it has (plain, statistics, eval affine + PReLU, accumulate), across x segments, row blocks and
+    the image borders (16 input channels; with 32 the general kernel sums two 16-channel chunks one after the other: equal to a bf16 rounding in < 5 % of the values); and equal
+    torch's fp64 result."""
+    lib = L.lib()
+    dt, k, st = "bf16", (3, 3, 1), (2, 2, 1)
+    torch.manual_seed(11)
+    fine = (2 * dims[0], 2 * dims[1], dims[2])
+    n = 2
+    if kind == "conv_fwd":
+        x = _round(torch.randn(n, cin, *fine), dt)
+        w = _round(torch.randn(cout, cin, *k) / (cin * 9) ** 0.5, dt)
+        want = F.conv3d(x.double(), w.double(), stride=st, padding=P.same_pad(k))
+        inp_cl, nout = H.to_cl(x, H.DT[dt]), cout
+    else:  # y = convT(x): x coarse [cin], y fine [cout]; the data gradient gathers dy (fine, cout channels) into dx (coarse, cin channels)
+        w = _round(torch.randn(cin, cout, *k) / (cin * 9 / 4) ** 0.5, dt)
+        xd = torch.zeros(n, cin, *dims, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose3d(xd, w.double(), stride=st, padding=P.same_pad(k), output_padding=(1, 1, 0))
+        assert tuple(y.shape[2:]) == fine
+        gy = _round(torch.randn(*y.shape), dt)
+        y.backward(gy.double())
+        want, inp_cl, nout = xd.grad, H.to_cl(gy, H.DT[dt]), cin
+    assert tuple(want.shape[2:]) == dims
+    cls = P.lattice_classes(kind, k, st)
+    assert len(cls) == 1
+    cls = cls[0]
+    kc = inp_cl.shape[-1]
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    gen = P.plan_igemm(kind, tuple(w.shape), cls, dims, 2, kc_pad=kc, aux_es=2)
+    gen.pack_map = P.pack_map(gen, tuple(w.shape))
+    same_order = gen.nchunks == 1  # (32 input channels: the general kernel's plans stage two 16-channel chunks, its sum over K runs chunk by chunk — equal to fp32 rounding, not bit for bit)
+    tz, mtw = shape
+    gp = [pl for pl in P.gather_plans(kind, tuple(w.shape), cls, dims, 2, kc, nreal, kreal, n=n) if (pl.tile[2], pl.mtw) == (tz, mtw)]
+    assert gp, "no gathering plan for this shape"
+    gpl = dataclasses.replace(gp[0], tile=(lx, gp[0].tile[1], tz))
+    gpl.pack_map = P.pack_map(gpl, tuple(w.shape))
+    bias = torch.randn(nout, device="cuda")
+    res_t = H.to_cl(_round(torch.randn(n, nout, *dims), dt), H.DT[dt])
+    sc, sh, alpha = torch.rand(nout, device="cuda") + 0.5, torch.randn(nout, device="cuda"), torch.tensor([0.25], device="cuda")
+    for mode in ("plain", "stats", "eval", "accumulate"):
+        outs = []
+        for pl in (gen, gpl):
+            out = res_t.clone() if mode == "accumulate" else torch.full((n, *dims, nout), float("nan"), dtype=H.DT[dt], device="cuda")
+            kw, stats = dict(bias=bias.data_ptr()), None
+            if mode == "stats":
+                stats = torch.zeros(L.STAT_SHARDS * 2 * P.round_up(nout, 16), dtype=torch.float64, device="cuda")
+                kw.update(stats=stats.data_ptr(), stats_stride=P.round_up(nout, 16))
+            elif mode == "eval":
+                kw.update(scale=sc.data_ptr(), shift=sh.data_ptr(), act=L.ACT_PRELU, alpha=alpha.data_ptr())
+            elif mode == "accumulate":
+                kw.update(accumulate=1)
+            d = H.igemm_desc(pl, H.pack(pl, w, inp_cl.dtype), H.tdesc(inp_cl), H.tdesc(out), **kw)
+            if pl.depth == -9:
+                assert lib.vsseg_igemm_lds_bytes(C.byref(d)) == pl.lds
+            L.check(lib.vsseg_igemm(C.byref(d), H.stream()), f"igemm D={pl.depth} {mode}")
+            torch.cuda.synchronize()
+            outs.append((out, stats))
+        (og, sg), (om, sm) = outs
+        assert not torch.isnan(om.float()).any()
+        if same_order:
+            assert torch.equal(og, om), f"{mode}: gathering kernel differs from the general kernel (max {float((og.float() - om.float()).abs().max())})"
+        else:
+            np.testing.assert_allclose(om.float().cpu().numpy(), og.float().cpu().numpy(), atol=1.6e-2 * float(og.float().abs().max()), err_msg=mode)
+            assert float((om.float() != og.float()).float().mean()) < 0.05, f"{mode}: more than 5 % of the values differ from the general kernel's by a rounding"
+        if mode == "plain":
+            np.testing.assert_allclose(H.from_cl(om).numpy(), (want + bias.cpu().double().view(1, -1, 1, 1, 1)).float().numpy(), atol=_tol(dt, want))
+        if mode == "stats":
+            a, bb = H.stat_decode(sg).view(L.STAT_SHARDS, 2, -1).sum(0), H.stat_decode(sm).view(L.STAT_SHARDS, 2, -1).sum(0)
+            np.testing.assert_allclose(bb.cpu().numpy(), a.cpu().numpy(), rtol=1e-5, atol=1e-3)
+
+
+def test_gathering_marching_kernel_rejects_what_it_does_not_cover():
+    lib = L.lib()
+    k, st = (3, 3, 1), (2, 2, 1)
+    w = torch.randn(32, 32, *k)
+    cls = P.lattice_classes("conv_fwd", k, st)[0]
+    assert P.gather_plans("conv_fwd", (64, 64, *k), cls, (8, 32, 8), 2, 64, 64, 64) == []                                       # 64 channels
+    assert P.gather_plans("conv_fwd", tuple(w.shape), P.lattice_classes("conv_fwd", k, (1, 1, 1))[0], (8, 32, 8), 2, 32, 32, 32) == []   # stride 1: the marching kernel's
+    assert P.gather_plans("conv_fwd", tuple(w.shape), cls, (8, 24, 8), 2, 32, 32, 32) == []                                    # rows not a multiple of the column block
+    pl = P.gather_plans("conv_fwd", tuple(w.shape), cls, (8, 32, 8), 2, 32, 32, 32)[0]
+    pl.pack_map = P.pack_map(pl, tuple(w.shape))
+    x = torch.zeros(1, 16, 64, 8, 32, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(1, 8, 32, 8, 32, dtype=torch.bfloat16, device="cuda")
+    wp = H.pack(pl, w, torch.bfloat16)
+
+    def rejected(mutate, what):
+        d = H.igemm_desc(pl, wp, H.tdesc(x), H.tdesc(out))
+        mutate(d)
+        assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL and b"gathering marching kernel" in lib.vsseg_last_error(), what
+
+    rejected(lambda d: setattr(d, "mtw", 3), "mtw")
+    rejected(lambda d: setattr(d, "res_mode", L.RES_ADD), "residual epilogue")
+    rejected(lambda d: setattr(d, "act", L.ACT_SIGMOID), "sigmoid")
+    o32 = torch.zeros(1, 8, 32, 8, 32, dtype=torch.float32, device="cuda")
+    d = H.igemm_desc(pl, wp, H.tdesc(x), H.tdesc(o32))
+    assert lib.vsseg_igemm(C.byref(d), H.stream()) == L.EINVAL and b"bf16" in lib.vsseg_last_error()
+
+
 FUSED_BWD_CASES = [
     # cin, cout, dims, (x steps, rows, tz) of the fused launch
     (16, 16, (10, 64, 16), (4, 32, 8)),   # level-0 unit: two row blocks, two z blocks, three x segments (4 + 4 + 2)

@@ -158,6 +158,44 @@ def test_transition_plans_compute_the_transition_and_mirror_the_kernels_lds(kind
     assert P.transition_plans("convT_fwd", (80, 64, *k), k, s, (8, 8, 8), 2, 80, 64, 80) == []      # levels 3 -> 4: the deep-level kernel's
 
 
+@pytest.mark.parametrize("kind,cin,cout,coarse", [("conv_fwd", 16, 16, (3, 32, 4)), ("conv_fwd", 32, 32, (2, 32, 2)), ("convT_dgrad", 32, 16, (2, 32, 4)), ("convT_dgrad", 48, 32, (2, 32, 2))])
+def test_gather_plans_compute_the_strided_launches_and_mirror_the_kernels_lds(kind, cin, cout, coarse):
+    """planner.gather_plans (csrc/gconv.hip, depth -9): marching plans of the stride-(2,2,1) 3x3x1 launches that read the fine level — their packed weights simulate to torch's
+    strided convolution / transposed-convolution data gradient (numpy restatement of the kernel's indexing), their LDS request is the kernel's."""
+    import ctypes
+
+    from tests import gpu_harness as H
+    from vs_seg_amd import _lib as L
+
+    k, s = (3, 3, 1), (2, 2, 1)
+    fine = (2 * coarse[0], 2 * coarse[1], coarse[2])
+    torch.manual_seed(8)
+    if kind == "conv_fwd":
+        x = torch.randn(1, cin, *fine, dtype=torch.float64)
+        w = torch.randn(cout, cin, *k, dtype=torch.float64)
+        want, xin = F.conv3d(x, w, stride=s, padding=P.same_pad(k)), _cl(x)
+    else:
+        w = torch.randn(cin, cout, *k, dtype=torch.float64)
+        xd = torch.zeros(1, cin, *coarse, dtype=torch.float64, requires_grad=True)
+        y = F.conv_transpose3d(xd, w, stride=s, padding=P.same_pad(k), output_padding=(1, 1, 0))
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        want, xin = xd.grad, _cl(gy)
+    kreal, nreal = P.gemm_dims(kind, tuple(w.shape))
+    cls = P.lattice_classes(kind, k, s)
+    assert len(cls) == 1 and tuple(cls[0].is_) == (2, 2, 1)
+    plans = P.gather_plans(kind, tuple(w.shape), cls[0], coarse, 2, kreal, nreal, kreal)
+    assert plans and all(pl.depth == -9 and pl.nchunks == 1 and pl.ck == kreal and pl.tile[1] == 64 * pl.mtw // pl.tile[2] for pl in plans)
+    for pl in plans:
+        assert pl.lds == P.gather_lds_bytes(kreal, pl.nt, pl.tile[2], pl.mtw) <= P.LDS_LIMIT and (kreal, pl.nt, pl.tile[2], pl.mtw) in P.GATHER_SHAPES
+        pl.pack_map = P.pack_map(pl, tuple(w.shape))
+        np.testing.assert_allclose(P.simulate_igemm(pl, xin, w.numpy().reshape(-1), coarse)[..., :nreal], _cl(want), atol=1e-9)
+        d = H.igemm_desc(pl, torch.zeros(1), L.Tensor(4096, L.BF16, kreal, kreal, 1, *fine), L.Tensor(8192, L.BF16, nreal, nreal, 1, *coarse))
+        assert L.lib().vsseg_igemm_lds_bytes(ctypes.byref(d)) == pl.lds, L.lib().vsseg_last_error()
+    assert any(pl.depth == -9 for pl in P.candidate_plans(kind, tuple(w.shape), cls[0], coarse, 2, kc_pad=kreal, aux_es=0))
+    assert P.gather_plans(kind, tuple(w.shape), cls[0], coarse, 4, kreal, nreal, kreal) == []  # fp32
+
+
 def test_small_lds_budget_forces_channel_chunks():
     torch.manual_seed(2)
     k, s = (3, 3, 3), (1, 1, 1)

@@ -44,6 +44,7 @@ python bench.py --steps 2 --warmup 1 --swi-volumes 0 --fp32-steps 0 --no-cpu-bas
 (for cfg in "96 32 128 96 48" "96 32 128 48 48" "96 32 128 32 48" "48 16 64 128 64" "48 16 64 64 64" "48 16 64 48 64"; do set -- $cfg; timeout 300 python tools/bench_wgrad.py --dims $1 $2 $3 --cin $4 --cout $5 --kernel 3 3 3 2>&1 | grep -v "amdgpu.ids\|rejected"; done > $OUT/cwgrad_bench.txt || true)
 (timeout 300 python tools/bench_cconv.py --compute-only --batch 4 2>&1 | grep -v amdgpu.ids > $OUT/cconv_bench.txt; timeout 300 python tools/bench_cconv.py --compute-only --batch 1 2>&1 | grep -v amdgpu.ids >> $OUT/cconv_bench.txt || true)
 (timeout 600 python tools/bench_tconv.py 4 2>&1 | grep -v amdgpu.ids > $OUT/tconv_bench.txt; timeout 300 python tools/bench_tconv.py 1 2>&1 | grep -v amdgpu.ids | grep -E "^==|transition" >> $OUT/tconv_bench.txt || true)
+(timeout 600 python tools/bench_gconv.py 4 2>&1 | grep -v amdgpu.ids > $OUT/gconv_bench.txt; timeout 300 python tools/bench_gconv.py 1 2>&1 | grep -v amdgpu.ids | grep -E "^==|D=-9" >> $OUT/gconv_bench.txt || true)
 (timeout 300 python tools/bench_nconv.py 4 2>&1 | grep -v amdgpu.ids > $OUT/nconv_bench.txt; timeout 300 python tools/bench_nconv.py 1 2>&1 | grep -v amdgpu.ids >> $OUT/nconv_bench.txt || true)
 (cd /tmp; B="python $R/tools/bench_wgrad.py --dims 96 32 128 --cin 96 --cout 48 --kernel 3 3 3 --compute-only --reps 3"
  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/cwa -- $B > /dev/null 2>&1

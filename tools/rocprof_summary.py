@@ -51,6 +51,9 @@ def bench_name(short_name):
     m = re.match(r"chain_kernel<(\d+),", short_name)  # chained marching convolution (inference): input channels of its first stage
     if m:
         return f"chain<bf16,{m.group(1)}>"
+    m = re.match(r"gconv_kernel<(\d+), (\d+), ", short_name)  # gathering marching kernel (stride-(2,2,1) launches fine -> coarse): output channel tiles
+    if m:
+        return f"gconv<bf16,{m.group(2)}>"
     m = re.match(r"tconv_kernel<(\d+), ", short_name)  # transition kernel (levels 2 <-> 3): 8-channel groups of its input
     if m:
         return f"tconv<bf16,{m.group(1)}>"

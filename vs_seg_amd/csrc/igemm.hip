@@ -6,6 +6,7 @@
 #include "mconv.h"
 #include "dconv.h"
 #include "tconv.h"
+#include "gconv.h"
 #include "chain.h"
 
 __global__ void igemm_tile_setup_kernel(const IgemmK k, TileDesc* __restrict__ tab, int xb) {
@@ -192,6 +193,7 @@ extern "C" int vsseg_igemm_lds_bytes(const vsseg_igemm_desc* d) {
   if (d && (d->depth == -5 || d->depth == -6)) return vsseg_mconv_lds_bytes(d);
   if (d && d->depth == -7) return vsseg_dconv_lds_bytes(d);
   if (d && d->depth == -8) return vsseg_tconv_lds_bytes(d);
+  if (d && d->depth == -9) return vsseg_gconv_lds_bytes(d);
   IgemmK k;
   return igemm_prepare(d, k);
 }
@@ -229,6 +231,12 @@ extern "C" int vsseg_igemm(const vsseg_igemm_desc* d, void* stream) {
     const void* z = zero_page();
     VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
     return vsseg_tconv_launch(d, z, as_stream(stream));
+  }
+  if (d && d->depth == -9) {  // gathering marching kernel (gconv.hip: the stride-(2,2,1) 3x3x1 launches that read the fine level and write the coarse one): same contract
+    VSSEG_CHECK(d->in.ptr && d->out.ptr && d->wpack, "vsseg_igemm: null pointer");
+    const void* z = zero_page();
+    VSSEG_CHECK(z, "vsseg_igemm: could not allocate the zero page");
+    return vsseg_gconv_launch(d, z, as_stream(stream));
   }
   IgemmK k;
   int lds = igemm_prepare(d, k);

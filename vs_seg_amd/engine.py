@@ -634,6 +634,8 @@ class Plan:
             return f"dconv<bf16,{pl.mtw},{pl.nt}>"
         if pl.depth == -8:
             return f"tconv<bf16,{pl.ck // 8}>"
+        if pl.depth == -9:
+            return f"gconv<bf16,{pl.nt}>"
         return f"igemm<{'bf16' if inp.dtype == L.BF16 else 'f32'},{pl.nt},{pl.mtw}>"
 
     def _ew_meta(self, name: str, level: int, passes_c: int, dtype_es: Optional[int] = None) -> dict:

@@ -242,6 +242,42 @@ def march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmP
     return out
 
 
+# ---- gathering marching kernel (csrc/gconv.hip): depth -9 ------------------------------------------------------------------
+# (input channels, 16-channel output tiles, tz, M-tiles per wave): gc_table of csrc/gconv.hip
+GATHER_SHAPES = {(16, 1, 4, 2), (16, 1, 8, 4), (16, 1, 4, 4), (16, 2, 4, 2), (16, 2, 8, 4), (16, 2, 4, 4), (32, 2, 2, 1), (32, 2, 4, 2), (32, 3, 2, 1), (32, 3, 4, 2)}
+
+
+def gather_lds_bytes(kc, nt, tz, mt) -> int:
+    """Mirror of gc_lds() in csrc/gconv.hip: packed weights | ring of six fine planes (two half planes of tyb + 1 rows each, padded to 256 bytes; the plane to whole 1 KiB DMA rows) | epilogue constants."""
+    g = kc // 8
+    tyb = mt * 4 * (16 // tz)
+    hs16 = round_up((tyb + 1) * tz * g, 16)
+    return ((9 * g + 3) // 4) * nt * 1024 + 6 * round_up(2 * hs16 * 16, 1024) + 3 * nt * 16 * 4 + 16
+
+
+def gather_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n=1) -> List["IgemmPlan"]:
+    """The depth -9 candidates: the gathering marching kernel on the stride-(2,2,1) 3x3x1 bf16 launches that read the fine level and write the coarse one (strided convolution,
+    data gradient of a transposed convolution): a workgroup owns a column of `tyb` coarse rows x `tz` slices and walks along x with a ring of FINE planes in LDS.
+    tile = (x steps per workgroup, coarse rows per workgroup, tz)."""
+    offs = [tuple(t[0]) for t in cls.taps]
+    if es != 2 or tuple(cls.is_) != (2, 2, 1) or tuple(cls.os) != (1, 1, 1) or tuple(cls.oo) != (0, 0, 0) or offs != _TAPS_3x3x1 or kc != round_up(kreal, 8):
+        return []
+    nt = (nreal + 15) // 16
+    out = []
+    for (c, t, tz, mt) in sorted(GATHER_SHAPES):
+        tyb = 64 * mt // tz
+        if c != kc or t != nt or q[1] % tyb or q[2] % tz or gather_lds_bytes(kc, nt, tz, mt) > 158 * 1024:
+            continue
+        cols = n * (q[1] // tyb) * (q[2] // tz)
+        for target in (512, 1024):
+            nxs = max(1, min(q[0] // 8, -(-target // cols)))
+            lx = -(-q[0] // nxs)
+            pl = IgemmPlan(kind, cls, tuple(q), kc, nreal, kreal, (lx, tyb, tz), mt, nt, 1, kc, 1, (9 * (kc // 8) + 3) // 4, gather_lds_bytes(kc, nt, tz, mt), -9)
+            if not any(o.tile == pl.tile and o.mtw == pl.mtw for o in out):
+                out.append(pl)
+    return out
+
+
 def chain_plan(cin: int, compact: bool, q, n: int = 1, cmid: int = 16) -> Optional[dict]:
     """Plan of a chained marching launch (csrc/chain.hip: two stride-1 3x3x1 convolutions with the tensor between them in LDS; inference only) for the pairs it is
     instantiated and measured for (tools/bench_chain.py) — the compact one-channel network input (1 -> 16 -> 16) and a 32-channel input (32 -> 16 -> 1) on columns of 128 rows,
@@ -833,6 +869,8 @@ def candidate_plans(kind, wshape, cls: LatticeClass, q, es, kc_pad=None, aux_es=
     if not in_split_unsupported(in_split, kc):
         rest = rest + march_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n)
     rest = rest + deep_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n, in_split)
+    if not in_split:
+        rest = rest + gather_plans(kind, wshape, cls, q, es, kc, nreal, kreal, n)
     for pl in rest:
         if pl.pack_map is None:
             pl.pack_map = pack_map(pl, wshape)
