@@ -147,7 +147,8 @@ def sliding_window_inference(inputs: torch.Tensor, roi_size, sw_batch_size: int,
     The default is 1 for an arbitrary `predictor` — a callable that reuses buffers between calls, or returns views of them, would race on two
     streams — and 2 for a predictor that declares itself `stream_safe` (`UNet2d5_spvPA.segmentation_predictor()`: one set of eval activation
     buffers, packed weights and hipGraph per stream, i.e. twice the eval memory and lowering time of the serial schedule).  Three groups (round 5, with the shorter launch
-    list): 42.7 against 41.8 volumes/s in an inference-only process, 38.6-41.0 against 40.8-42.9 in a process that has also trained (bench.py) — not the default."""
+    list): 42.7 against 41.8 volumes/s in an inference-only process, 38.6-41.0 against 40.8-42.9 in a process that has also trained (bench.py); round 6: 44.3-44.8 against 42.1-42.2
+    in an inference-only process, 44.3-44.5 against 44.1-44.9 inside bench.py's (four groups: 42.1) — not the default."""
     if concurrent_groups is None:
         concurrent_groups = 2 if getattr(predictor, "stream_safe", False) else 1
     if not inputs.is_cuda:
