@@ -215,7 +215,7 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 7: + vsseg_dice_pred_bwd_to; 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------
@@ -340,6 +340,10 @@ int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t
 int vsseg_dice_finalize(const double* pred_sums, const double* att_sums, int32_t n, int32_t nlevels, float* loss, float* coef /* [n][2][2] + [levels][n][2] */, void* stream);
 int vsseg_dice_pred_bwd(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, float* dlogits, void* stream);
 int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, const float* coef, float inv_levels, const float* gscale, float* datt, void* stream);
+/* vsseg_dice_pred_bwd writing the gradient in a layout the training plan stages it in (the fused train step of vs_seg_amd.parallel.DataParallelTrainer: no fp32
+   gradient tensor, no cast pass): dst = 2 channels of `n * nvox` voxels, fp32 or bf16 (round-to-nearest-even, as vsseg_copy_cast), pitch 2, or pitch 8 =
+   VSSEG_ZERO_PADDED rows whose channels 2..7 are written as zeros (bf16) / left as they are (fp32).  gscale may be NULL (= 1). */
+int vsseg_dice_pred_bwd_to(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, vsseg_tensor dst, void* stream);
 
 /* torch.optim.Adam(lr, weight_decay) over the flat parameter buffer (ref:params/VSparams.py:388-391,462). */
 int vsseg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2, float gscale, void* stream);

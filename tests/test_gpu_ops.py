@@ -2105,6 +2105,59 @@ def test_dice_spvpa_loss_matches_reference_golden(att, hard):
         np.testing.assert_allclose(a.grad.cpu().numpy(), g[f"{tag}:datt{i}"], atol=2e-9, rtol=2e-4)
 
 
+@pytest.mark.parametrize("layout", ["bf16x2", "bf16x8", "f32x2", "f32x8"])
+@pytest.mark.parametrize("nvox_dims", [(32, 32, 8), (5, 3, 7)])  # (16-byte loads, four voxels per thread) / (odd voxel count: the scalar path)
+def test_dice_gradient_written_in_the_staged_layouts_equals_the_fp32_gradient_cast(layout, nvox_dims):
+    """vsseg_dice_pred_bwd_to (the fused train step) = vsseg_dice_pred_bwd followed by vsseg_copy_cast, bit for bit, in every layout the training plan stages the gradient in."""
+    lib = L.lib()
+    n, dims = 2, nvox_dims
+    nvox = dims[0] * dims[1] * dims[2]
+    lg = (2.0 * synth_input(32, (n, *dims, 2))).cuda().contiguous()
+    lab = synth_label(31, (n, 1, *dims)).cuda().contiguous()
+    coef = torch.tensor([-0.3, 0.02, -0.25, 0.015, -0.31, 0.021, -0.2, 0.017], device="cuda")
+    want32 = torch.empty(n, *dims, 2, device="cuda")
+    L.check(lib.vsseg_dice_pred_bwd(lg.data_ptr(), 2, lab.data_ptr(), n, nvox, 1, coef.data_ptr(), None, want32.data_ptr(), H.stream()))
+    dt = torch.bfloat16 if layout.startswith("bf16") else torch.float32
+    pitch = int(layout[-1])
+    got = torch.full((n, *dims, pitch), 7.0, device="cuda", dtype=dt)
+    want = torch.full((n, *dims, pitch), 7.0, device="cuda", dtype=dt)
+    tdt = L.BF16 if dt == torch.bfloat16 else L.F32
+    flags = L.ZERO_PADDED if pitch == 8 else 0
+    L.check(lib.vsseg_copy_cast(L.Tensor(want32.data_ptr(), L.F32, 2, 2, n, *dims), L.Tensor(want.data_ptr(), tdt, 2, pitch, n, *dims, None, 0, flags), H.stream()))
+    L.check(lib.vsseg_dice_pred_bwd_to(lg.data_ptr(), 2, lab.data_ptr(), n, nvox, 1, coef.data_ptr(), None, L.Tensor(got.data_ptr(), tdt, 2, pitch, n, *dims, None, 0, flags), H.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(got[..., :2], want[..., :2])
+    if pitch == 8:  # bf16 rows are written whole (channels 2..7 = 0, as the cast pass writes them); fp32 rows keep what was there
+        assert torch.equal(got[..., 2:], want[..., 2:]) if dt == torch.bfloat16 else float(got[..., 2:].min()) == 7.0
+    # a destination that is not a 2-channel tensor of the right size is refused
+    assert lib.vsseg_dice_pred_bwd_to(lg.data_ptr(), 2, lab.data_ptr(), n, nvox, 1, coef.data_ptr(), None, L.Tensor(got.data_ptr(), tdt, 3, pitch, n, *dims), H.stream()) == L.EINVAL
+
+
+@pytest.mark.parametrize("att", [True, False])
+def test_dice_loss_and_gradients_in_one_call_equal_the_autograd_route(att):
+    """Dice_spvPA.forward_backward_into (outside autograd, gradients written into caller-named buffers) = loss.backward(): same loss, same gradients."""
+    import vs_seg_amd as V
+
+    shape = (2, 1, 32, 32, 8)
+    att_shapes = [(2, 1, 1, 1, 1), (2, 1, 2, 2, 2), (2, 1, 4, 4, 4), (2, 1, 8, 8, 8), (2, 1, 16, 16, 8), (2, 1, 32, 32, 8)]
+    y = synth_label(31, shape).cuda()
+    lg_cl = (2.0 * synth_input(32, (2, 32, 32, 8, 2))).cuda()
+    logits = lg_cl.permute(0, 4, 1, 2, 3).detach().requires_grad_(True)  # channels-last storage, as the network hands it out
+    atts = [torch.sigmoid(synth_input(40 + i, s)).cuda().requires_grad_(True) for i, s in enumerate(att_shapes)]
+    fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=att, hardness_weighting=True)
+    loss = fn((logits, atts), y)
+    loss.backward()
+    dst = torch.zeros(2, 32, 32, 8, 2, device="cuda", dtype=torch.bfloat16)
+    bufs = [torch.zeros(s[0], *s[2:], device="cuda") for s in att_shapes]
+    bufs[2] = None  # a map without a gradient path is skipped
+    loss2, written = fn.forward_backward_into((logits.detach(), [a.detach() for a in atts]), y, (L.Tensor(dst.data_ptr(), L.BF16, 2, 2, 2, 32, 32, 8), bufs))
+    assert float(loss2) == float(loss)
+    assert torch.equal(dst, logits.grad.permute(0, 2, 3, 4, 1).to(torch.bfloat16))
+    assert written == ([5, 4, 3, 1, 0] if att else [])
+    for i in written:
+        assert torch.equal(bufs[i].reshape(-1), atts[i].grad.reshape(-1))
+
+
 def test_adam_matches_torch_golden():
     g = load("adam.npz")
     lib = L.lib()

@@ -34,6 +34,41 @@ def _model(dropout=0.0):
     return m.to("cuda")
 
 
+def _model_dt(dtype, dropout):
+    torch.manual_seed(77)
+    m = V.UNet2d5_spvPA(dimensions=3, in_channels=1, out_channels=2, channels=HP["channels"], strides=HP["strides"], kernel_sizes=HP["kernel_sizes"], sample_kernel_sizes=HP["sample_kernel_sizes"],
+                        num_res_units=2, norm="batch", dropout=dropout, attention_module=True, compute_dtype=dtype)
+    m.load_state_dict(O.seeded_state_dict(True, SEED))
+    return m.to("cuda")
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+@pytest.mark.parametrize("supervised", [True, False])
+def test_fused_loss_train_step_is_bit_identical_to_the_autograd_route(dtype, supervised):
+    """DataParallelTrainer.step with the loss writing its gradients where the backward reads them (train_forward_landing / forward_backward_into / backward_landed)
+    against the same step through loss.backward(): losses, gradients, parameters and BatchNorm buffers after two steps, bit for bit.  `supervised=False` leaves the
+    attention-map buffers without a gradient in both routes (after a supervised step has filled them: they must go back to zeros)."""
+    from vs_seg_amd import parallel as DP
+
+    x, y = _batch(0)
+    res = []
+    for fused in (True, False):
+        m = _model_dt(dtype, 0.1)
+        trainer = DP.DataParallelTrainer(m.train(), V.Dice_spvPA(to_onehot_y=True, softmax=True), V.Adam(m.parameters(), lr=1e-3, weight_decay=1e-7))
+        assert trainer.fused_loss
+        trainer.fused_loss = fused
+        losses = [float(trainer.step(x, y))]
+        trainer.loss_fn = V.Dice_spvPA(to_onehot_y=True, softmax=True, supervised_attention=supervised)
+        losses.append(float(trainer.step(x, y)))
+        flat, gflat = m.flat_parameters()
+        torch.cuda.synchronize()
+        res.append((losses, gflat.clone(), flat.clone(), m._bflat.clone()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, b)
+    assert float(res[0][1].abs().max()) > 0
+
+
 def _batch(rank):
     return synth_input(SEED + 10 * rank, SHAPE).cuda(), synth_label(SEED + 10 * rank, SHAPE).cuda()
 

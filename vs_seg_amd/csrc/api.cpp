@@ -13,7 +13,7 @@ extern "C" void vsseg_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* vsseg_last_error(void) { return g_err; }
-extern "C" int vsseg_version(void) { return 6; }
+extern "C" int vsseg_version(void) { return 7; }
 
 // Sticky flag of the fixed-point accumulators (csrc/common.h, vsseg_fx_add): one word of device memory PER DEVICE (the current device of the calling thread: one
 // process per GPU is the product's layout, a second device in the same process gets its own word), allocated once under a lock.  nullptr only if the allocation

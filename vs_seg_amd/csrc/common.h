@@ -242,12 +242,44 @@ __device__ __forceinline__ float vsseg_slab_sum(const float* __restrict__ slab, 
   return r;
 }
 
+// The same sum for FOUR consecutive elements i .. i+3 per thread (i % 4 == 0, total % 4 == 0, 16-byte loads: a wave reads 1 KiB of a slab per instruction
+// instead of 256 bytes).  Per element the additions are the ones of vsseg_slab_sum in the same order: the two give bit-identical sums.  lds4096: 1024 float4.
+__device__ __forceinline__ f32x4 vsseg_slab_sum4(const float* __restrict__ slab, int64_t total, int64_t i, int nblk, f32x4* lds4096) {
+  const int il = threadIdx.x & 63, bl = threadIdx.x >> 6;
+  const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 s[8] = {z, z, z, z, z, z, z, z};
+  if (i < total) {
+    const float* p = slab + i;
+    int b = bl;
+    for (; b + 112 < nblk; b += 128) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += *reinterpret_cast<const f32x4*>(p + (int64_t)(b + 16 * j) * total);
+    }
+    for (; b < nblk; b += 16) s[0] += *reinterpret_cast<const f32x4*>(p + (int64_t)b * total);
+  }
+  lds4096[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  f32x4 r = z;
+  if (bl == 0) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r += lds4096[j * 64 + il];
+  }
+  return r;
+}
+
 // dst[i] += sum over rows b of slab[b][i], i < nvalid <= total (bias-gradient rows of the weight-gradient kernels): the same fixed-order sum
 static __global__ __launch_bounds__(VSSEG_SLAB_THREADS) void vsseg_slab_add_kernel(const float* __restrict__ slab, int nrows, int total, int nvalid, float* __restrict__ dst) {
   __shared__ float lds[VSSEG_SLAB_THREADS];
   const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
   const float s = vsseg_slab_sum(slab, total, i, nrows, lds);
   if (threadIdx.x < 64 && i < nvalid) dst[i] += s;
+}
+
+// n / d for 0 <= n < 2^22, d >= 1 with inv = 1.0f / d: a float multiply and one correction step instead of the ~40-instruction sequence hipcc emits for a
+// 32-bit division by a run-time value (the coordinate tables of a kernel prologue are made of such divisions: 6.3 us of a 17 us wgrad launch)
+__device__ __forceinline__ int vsseg_fdiv(int n, int d, float inv) {
+  const int q = (int)((float)n * inv), r = n - q * d;
+  return q + (r >= d) - (r < 0);
 }
 
 // Workgroup b runs on XCD b % 8 (round-robin dispatch).  Work item of workgroup b such that XCD x owns the contiguous item range

@@ -325,20 +325,7 @@ __global__ __launch_bounds__(256, 1) void cwgrad_kernel(const CwK k) {
   }
 }
 
-// dw[cp][ch][tap] += sum over the workgroups' slabs (vsseg_slab_sum: 64 elements x 16 slab lanes per block, fixed summation order); element e of a slab =
-// (chunk, tap, P tile, lane, r) as the flush wrote it
-__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void cwgrad_reduce_kernel(const float* __restrict__ slab, int nslab, int hchunks, int ntp, int slab_chunk, vsseg_wgrad_desc d) {
-  __shared__ float lds[VSSEG_SLAB_THREADS];
-  const int64_t total = (int64_t)hchunks * slab_chunk;
-  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const float s = vsseg_slab_sum(slab, total, i, nslab, lds);
-  if (threadIdx.x >= 64 || i >= total) return;
-  const int chunk = (int)(i / slab_chunk), e = (int)(i - (int64_t)chunk * slab_chunk);
-  const int r = e & 3, lane = (e >> 2) & 63, tile = e >> 8, ptile = tile % ntp, tap = tile / ntp;
-  const int cp = ptile * 16 + (lane >> 4) * 4 + r, ch = chunk * 16 + (lane & 15);
-  if (cp >= d.cp_valid || ch >= d.ch_valid) return;
-  d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[tap] * d.stride_tap] += s;
-}
+int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, int hchunks, int slab_chunk, hipStream_t s);  // wgrad.hip: sums slabs of this layout
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 constexpr int CW_ZERO_BYTES = 16384;
@@ -442,11 +429,8 @@ int vsseg_cwgrad_launch(const vsseg_wgrad_desc* d, const void* /*zeros*/, hipStr
   else if (d->ntp == 3) rc = b ? cw_launch_inst<3, 1, 2, true>(k, G, s) : cw_launch_inst<3, 1, 2, false>(k, G, s);
   else rc = b ? cw_launch_inst<2, 2, 1, true>(k, G, s) : cw_launch_inst<2, 2, 1, false>(k, G, s);
   if (rc) return rc;
-  {
-    const int total = k.hchunks * k.slab_chunk;
-    hipLaunchKernelGGL(cwgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)d->scratch, gpc * ksh, k.hchunks, d->ntp, k.slab_chunk, *d);
-    VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel, reduce)");
-  }
+  rc = vsseg_wgrad_reduce_launch(d, d->scratch, gpc * ksh, k.hchunks, k.slab_chunk, s);
+  if (rc) return rc;
   if (!d->dbias_p) return VSSEG_OK;
   hipLaunchKernelGGL(vsseg_slab_add_kernel, dim3((d->ntp * 16 + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)k.bias_slab, gpc * ksh, d->ntp * 16, d->cp_valid, d->dbias_p);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad (compute kernel, bias)");

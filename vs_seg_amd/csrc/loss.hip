@@ -50,53 +50,97 @@ __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double
   }
 }
 
-// sums[b][c][0..2] = (I, G, P) of the (optionally hardness-weighted) 2-class soft Dice
-__global__ void dice_pred_sums_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, double* __restrict__ sums, unsigned* fxflag) {
+// Launch shape of the three reductions below: every workgroup ends with one fixed-point atomic per sum into the SAME 3-6 addresses of its sample, and
+// same-address atomics retire one after the other (~45 ns each: with the 1024 workgroups per sample of the first version the attention-map sums of the
+// 96x32x128 level took 49 us for 6 MB, profiles/r06_kernel_stats.txt).  ~512 workgroups of 512 threads in total (2 per CU, 16 waves per CU), 16-byte loads.
+constexpr int DICE_THREADS = 512;
+static inline int dice_blocks(int64_t items, int n) {
+  int64_t want = (items + DICE_THREADS * 2 - 1) / (DICE_THREADS * 2);
+  const int cap = n >= 512 ? 1 : 512 / n;
+  return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+// the six terms of one voxel of the (optionally hardness-weighted) 2-class soft Dice (ref :279-283)
+__device__ __forceinline__ void dice_pred_terms(float l0, float l1, float lab, int hardness, float* t) {
+  const float m = fmaxf(l0, l1), e0 = __expf(l0 - m), e1 = __expf(l1 - m), inv = 1.f / (e0 + e1);
+  const float p0 = e0 * inv, p1 = e1 * inv;
+  const int cls = (int)(long long)lab;
+  const float g1 = cls == 1 ? 1.f : 0.f, g0 = cls == 0 ? 1.f : 0.f;
+  float w0 = 1.f, w1 = 1.f;
+  if (hardness) { w0 = 0.6f * fabsf(p0 - g0) + 0.4f; w1 = 0.6f * fabsf(p1 - g1) + 0.4f; }
+  t[0] += w0 * g0 * p0; t[1] += w0 * g0; t[2] += w0 * p0;
+  t[3] += w1 * g1 * p1; t[4] += w1 * g1; t[5] += w1 * p1;
+}
+
+// sums[b][c][0..2] = (I, G, P) of the (optionally hardness-weighted) 2-class soft Dice.  A thread adds four voxels in fp32 and keeps its running sums in fp64.
+__global__ __launch_bounds__(DICE_THREADS) void dice_pred_sums_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, double* __restrict__ sums, unsigned* fxflag) {
   const int b = blockIdx.y;
   const float* lg = logits + (int64_t)b * nvox * pitch;
   const float* lb = label + (int64_t)b * nvox;
-  float I0 = 0, G0 = 0, P0 = 0, I1 = 0, G1 = 0, P1 = 0;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-    float2 l = *reinterpret_cast<const float2*>(lg + v * pitch);
-    float m = fmaxf(l.x, l.y), e0 = __expf(l.x - m), e1 = __expf(l.y - m), inv = 1.f / (e0 + e1);
-    float p0 = e0 * inv, p1 = e1 * inv;
-    int cls = (int)(long long)lb[v];
-    float g1 = cls == 1 ? 1.f : 0.f, g0 = cls == 0 ? 1.f : 0.f;
-    float w0 = 1.f, w1 = 1.f;
-    if (hardness) { w0 = 0.6f * fabsf(p0 - g0) + 0.4f; w1 = 0.6f * fabsf(p1 - g1) + 0.4f; }
-    I0 += w0 * g0 * p0; G0 += w0 * g0; P0 += w0 * p0;
-    I1 += w1 * g1 * p1; G1 += w1 * g1; P1 += w1 * p1;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if (pitch == 2 && (nvox & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(label) & 15) == 0) {
+    const float4* lg4 = reinterpret_cast<const float4*>(lg);
+    const float4* lb4 = reinterpret_cast<const float4*>(lb);
+    for (int64_t i = tid; i < (nvox >> 2); i += nthr) {
+      const float4 a = lg4[2 * i], c = lg4[2 * i + 1], g = lb4[i];
+      float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      dice_pred_terms(a.x, a.y, g.x, hardness, t);
+      dice_pred_terms(a.z, a.w, g.y, hardness, t);
+      dice_pred_terms(c.x, c.y, g.z, hardness, t);
+      dice_pred_terms(c.z, c.w, g.w, hardness, t);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += (double)t[k];
+    }
+  } else {
+    for (int64_t v = tid; v < nvox; v += nthr) {
+      const float2 l = *reinterpret_cast<const float2*>(lg + v * pitch);
+      float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      dice_pred_terms(l.x, l.y, lb[v], hardness, t);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += (double)t[k];
+    }
   }
-  double vals[6] = {I0, G0, P0, I1, G1, P1};
-  block_reduce_add(vals, 6, sums + (int64_t)b * 6, VSSEG_FX_DICE, fxflag);
+  block_reduce_add(acc, 6, sums + (int64_t)b * 6, VSSEG_FX_DICE, fxflag);
 }
 extern "C" int vsseg_dice_pred_sums(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, double* sums, void* stream) {
   VSSEG_CHECK(logits && label && sums && pitch >= 2 && pitch % 2 == 0 && n >= 1, "vsseg_dice_pred_sums: bad arguments");
-  dim3 g(grid_for(nvox, 256, 1024), n);
+  dim3 g(dice_blocks(nvox / 4, n), n);
   VSSEG_FX_FLAG(fxflag, "vsseg_dice_pred_sums");
-  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums, fxflag);
+  hipLaunchKernelGGL(dice_pred_sums_kernel, g, dim3(DICE_THREADS), 0, as_stream(stream), logits, pitch, label, nvox, hardness, sums, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_pred_sums");
   return VSSEG_OK;
 }
 
 // sums[b][0..2] = (I, G, P) of the single-channel Dice between an attention map and the pooled label
-__global__ void dice_att_sums_kernel(const float* __restrict__ att, const float* __restrict__ label, int64_t nvox, double* __restrict__ sums, unsigned* fxflag) {
+__global__ __launch_bounds__(DICE_THREADS) void dice_att_sums_kernel(const float* __restrict__ att, const float* __restrict__ label, int64_t nvox, double* __restrict__ sums, unsigned* fxflag) {
   const int b = blockIdx.y;
   const float* a = att + (int64_t)b * nvox;
   const float* lb = label + (int64_t)b * nvox;
-  float I = 0, G = 0, P = 0;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-    float p = a[v], g = lb[v];
-    I += g * p; G += g; P += p;
+  double acc[3] = {0, 0, 0};
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if ((nvox & 3) == 0 && (reinterpret_cast<uintptr_t>(att) & 15) == 0 && (reinterpret_cast<uintptr_t>(label) & 15) == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* l4 = reinterpret_cast<const float4*>(lb);
+    for (int64_t i = tid; i < (nvox >> 2); i += nthr) {
+      const float4 p = a4[i], g = l4[i];
+      acc[0] += (double)((g.x * p.x + g.y * p.y) + (g.z * p.z + g.w * p.w));
+      acc[1] += (double)((g.x + g.y) + (g.z + g.w));
+      acc[2] += (double)((p.x + p.y) + (p.z + p.w));
+    }
+  } else {
+    for (int64_t v = tid; v < nvox; v += nthr) {
+      const float p = a[v], g = lb[v];
+      acc[0] += (double)(g * p); acc[1] += (double)g; acc[2] += (double)p;
+    }
   }
-  double vals[3] = {I, G, P};
-  block_reduce_add(vals, 3, sums + (int64_t)b * 3, VSSEG_FX_DICE, fxflag);
+  block_reduce_add(acc, 3, sums + (int64_t)b * 3, VSSEG_FX_DICE, fxflag);
 }
 extern "C" int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t nvox, double* sums, void* stream) {
   VSSEG_CHECK(att && label && sums && n >= 1, "vsseg_dice_att_sums: bad arguments");
-  dim3 g(grid_for(nvox, 256, 1024), n);
+  dim3 g(dice_blocks(nvox / 4, n), n);
   VSSEG_FX_FLAG(fxflag, "vsseg_dice_att_sums");
-  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(256), 0, as_stream(stream), att, label, nvox, sums, fxflag);
+  hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(DICE_THREADS), 0, as_stream(stream), att, label, nvox, sums, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_sums");
   return VSSEG_OK;
 }
@@ -133,52 +177,111 @@ extern "C" int vsseg_dice_finalize(const double* pred_sums, const double* att_su
   return VSSEG_OK;
 }
 
-// d(loss)/d(logits): through the Dice sums, the (non-detached) hardness weight (ref :279-283) and the softmax
-__global__ void dice_pred_bwd_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, const float* __restrict__ coef, const float* __restrict__ gscale, float* __restrict__ dlogits) {
+// d(loss)/d(logits) of one voxel: through the Dice sums, the (non-detached) hardness weight (ref :279-283) and the softmax
+__device__ __forceinline__ float2 dice_pred_grad(float l0, float l1, float lab, int hardness, float A0, float B0, float A1, float B1) {
+  const float m = fmaxf(l0, l1), e0 = __expf(l0 - m), e1 = __expf(l1 - m), inv = 1.f / (e0 + e1);
+  const float p0 = e0 * inv, p1 = e1 * inv;
+  const int cls = (int)(long long)lab;
+  const float g1 = cls == 1 ? 1.f : 0.f, g0 = cls == 0 ? 1.f : 0.f;
+  float w0 = 1.f, w1 = 1.f, s0 = 0.f, s1 = 0.f;
+  if (hardness) {
+    const float d0 = p0 - g0, d1 = p1 - g1;
+    w0 = 0.6f * fabsf(d0) + 0.4f; w1 = 0.6f * fabsf(d1) + 0.4f;
+    s0 = d0 > 0.f ? 0.6f : (d0 < 0.f ? -0.6f : 0.f);
+    s1 = d1 > 0.f ? 0.6f : (d1 < 0.f ? -0.6f : 0.f);
+  }
+  const float t0 = w0 + p0 * s0, t1 = w1 + p1 * s1;  // d(w*p)/dp
+  const float dp0 = A0 * g0 * t0 + B0 * (g0 * s0 + t0);
+  const float dp1 = A1 * g1 * t1 + B1 * (g1 * s1 + t1);
+  const float dot = dp0 * p0 + dp1 * p1;
+  return make_float2(p0 * (dp0 - dot), p1 * (dp1 - dot));
+}
+// OUT 0: fp32 [voxel][2];  1: bf16 [voxel][2] (the compact operand of the marching backward kernels);  2: bf16 rows of 8 channels, channels 2..7 written as zeros;
+// 3: fp32, any pitch (channels >= 2 are not touched).  1-3 are the layouts the training plan stages the gradient in (vsseg_dice_pred_bwd_to): written here, the
+// fp32 tensor and the cast pass over it (0.3 GB read + written per step at 4 x 384x128x128) do not exist.  Same values: the cast was the same round-to-nearest-even.
+template <int OUT> __global__ __launch_bounds__(256) void dice_pred_bwd_kernel(const float* __restrict__ logits, int pitch, const float* __restrict__ label, int64_t nvox, int hardness, const float* __restrict__ coef,
+                                                                                 const float* __restrict__ gscale, void* __restrict__ dst, int dpitch) {
   const int b = blockIdx.y;
   const float* lg = logits + (int64_t)b * nvox * pitch;
   const float* lb = label + (int64_t)b * nvox;
-  float* dl = dlogits + (int64_t)b * nvox * 2;
   const float gs = gscale ? *gscale : 1.f;
   const float A0 = coef[(b * 2 + 0) * 2] * gs, B0 = coef[(b * 2 + 0) * 2 + 1] * gs, A1 = coef[(b * 2 + 1) * 2] * gs, B1 = coef[(b * 2 + 1) * 2 + 1] * gs;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
-    float2 l = *reinterpret_cast<const float2*>(lg + v * pitch);
-    float m = fmaxf(l.x, l.y), e0 = __expf(l.x - m), e1 = __expf(l.y - m), inv = 1.f / (e0 + e1);
-    float p0 = e0 * inv, p1 = e1 * inv;
-    int cls = (int)(long long)lb[v];
-    float g1 = cls == 1 ? 1.f : 0.f, g0 = cls == 0 ? 1.f : 0.f;
-    float w0 = 1.f, w1 = 1.f, s0 = 0.f, s1 = 0.f;
-    if (hardness) {
-      float d0 = p0 - g0, d1 = p1 - g1;
-      w0 = 0.6f * fabsf(d0) + 0.4f; w1 = 0.6f * fabsf(d1) + 0.4f;
-      s0 = d0 > 0.f ? 0.6f : (d0 < 0.f ? -0.6f : 0.f);
-      s1 = d1 > 0.f ? 0.6f : (d1 < 0.f ? -0.6f : 0.f);
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  auto store = [&](int64_t v, float2 g) {
+    const int64_t e = ((int64_t)b * nvox + v) * dpitch;
+    if constexpr (OUT == 1) *reinterpret_cast<unsigned*>(reinterpret_cast<bf16_t*>(dst) + e) = f2bf2(g.x, g.y);
+    else if constexpr (OUT == 2) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + e) = make_uint4(f2bf2(g.x, g.y), 0u, 0u, 0u);
+    else *reinterpret_cast<float2*>(reinterpret_cast<float*>(dst) + e) = g;
+  };
+  if (pitch == 2 && (nvox & 3) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(label) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    const float4* lg4 = reinterpret_cast<const float4*>(lg);
+    const float4* lb4 = reinterpret_cast<const float4*>(lb);
+    for (int64_t i = tid; i < (nvox >> 2); i += nthr) {
+      const float4 a = lg4[2 * i], c = lg4[2 * i + 1], g = lb4[i];
+      const float2 r0 = dice_pred_grad(a.x, a.y, g.x, hardness, A0, B0, A1, B1), r1 = dice_pred_grad(a.z, a.w, g.y, hardness, A0, B0, A1, B1);
+      const float2 r2 = dice_pred_grad(c.x, c.y, g.z, hardness, A0, B0, A1, B1), r3 = dice_pred_grad(c.z, c.w, g.w, hardness, A0, B0, A1, B1);
+      if constexpr (OUT == 0) {
+        float4* o = reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + ((int64_t)b * nvox + 4 * i) * 2);
+        o[0] = make_float4(r0.x, r0.y, r1.x, r1.y);
+        o[1] = make_float4(r2.x, r2.y, r3.x, r3.y);
+      } else if constexpr (OUT == 1) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + ((int64_t)b * nvox + 4 * i) * 2) = make_uint4(f2bf2(r0.x, r0.y), f2bf2(r1.x, r1.y), f2bf2(r2.x, r2.y), f2bf2(r3.x, r3.y));
+      } else {
+        store(4 * i, r0); store(4 * i + 1, r1); store(4 * i + 2, r2); store(4 * i + 3, r3);
+      }
     }
-    float t0 = w0 + p0 * s0, t1 = w1 + p1 * s1;  // d(w*p)/dp
-    float dp0 = A0 * g0 * t0 + B0 * (g0 * s0 + t0);
-    float dp1 = A1 * g1 * t1 + B1 * (g1 * s1 + t1);
-    float dot = dp0 * p0 + dp1 * p1;
-    *reinterpret_cast<float2*>(dl + v * 2) = make_float2(p0 * (dp0 - dot), p1 * (dp1 - dot));
+  } else {
+    for (int64_t v = tid; v < nvox; v += nthr) {
+      const float2 l = *reinterpret_cast<const float2*>(lg + v * pitch);
+      store(v, dice_pred_grad(l.x, l.y, lb[v], hardness, A0, B0, A1, B1));
+    }
   }
 }
-extern "C" int vsseg_dice_pred_bwd(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, float* dlogits, void* stream) {
-  VSSEG_CHECK(logits && label && coef && dlogits && pitch >= 2 && pitch % 2 == 0, "vsseg_dice_pred_bwd: bad arguments");
-  dim3 g(grid_for(nvox, 256, 2048), n);
-  hipLaunchKernelGGL(dice_pred_bwd_kernel, g, dim3(256), 0, as_stream(stream), logits, pitch, label, nvox, hardness, coef, gscale, dlogits);
-  VSSEG_LAUNCH_CHECK("vsseg_dice_pred_bwd");
+static int dice_pred_bwd_launch(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, void* dst, int out, int dpitch, void* stream,
+                                const char* who) {
+  VSSEG_CHECK(logits && label && coef && dst && pitch >= 2 && pitch % 2 == 0 && n >= 1, "%s: bad arguments", who);
+  dim3 g(grid_for((nvox + 3) / 4, 256, 2048), n), t(256);
+  hipStream_t s = as_stream(stream);
+  if (out == 0) hipLaunchKernelGGL(dice_pred_bwd_kernel<0>, g, t, 0, s, logits, pitch, label, nvox, hardness, coef, gscale, dst, 2);
+  else if (out == 1) hipLaunchKernelGGL(dice_pred_bwd_kernel<1>, g, t, 0, s, logits, pitch, label, nvox, hardness, coef, gscale, dst, 2);
+  else if (out == 2) hipLaunchKernelGGL(dice_pred_bwd_kernel<2>, g, t, 0, s, logits, pitch, label, nvox, hardness, coef, gscale, dst, 8);
+  else hipLaunchKernelGGL(dice_pred_bwd_kernel<3>, g, t, 0, s, logits, pitch, label, nvox, hardness, coef, gscale, dst, dpitch);
+  VSSEG_LAUNCH_CHECK(who);
   return VSSEG_OK;
+}
+extern "C" int vsseg_dice_pred_bwd(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, float* dlogits, void* stream) {
+  return dice_pred_bwd_launch(logits, pitch, label, n, nvox, hardness, coef, gscale, dlogits, 0, 2, stream, "vsseg_dice_pred_bwd");
+}
+extern "C" int vsseg_dice_pred_bwd_to(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, vsseg_tensor dst, void* stream) {
+  VSSEG_CHECK(dst.ptr && !dst.ptr2 && dst.c == 2 && dst.pitch >= 2 && tensor_voxels(dst) == (int64_t)n * nvox, "vsseg_dice_pred_bwd_to: destination is not a 2-channel tensor of %lld voxels", (long long)n * nvox);
+  int out;
+  if (dst.dtype == VSSEG_BF16 && dst.pitch == 2) out = 1;
+  else if (dst.dtype == VSSEG_BF16 && dst.pitch == 8 && (reinterpret_cast<uintptr_t>(dst.ptr) & 15) == 0) out = 2;
+  else if (dst.dtype == VSSEG_F32 && dst.pitch % 2 == 0) out = dst.pitch == 2 ? 0 : 3;
+  else { vsseg_set_error("vsseg_dice_pred_bwd_to: destination layout (dtype %d, pitch %d) is not one the training plan stages the gradient in", dst.dtype, dst.pitch); return VSSEG_EINVAL; }
+  return dice_pred_bwd_launch(logits, pitch, label, n, nvox, hardness, coef, gscale, dst.ptr, out, dst.pitch, stream, "vsseg_dice_pred_bwd_to");
 }
 
 __global__ void dice_att_bwd_kernel(const float* __restrict__ label, int64_t nvox, const float* __restrict__ coef, const float* __restrict__ gscale, float* __restrict__ datt) {
   const int b = blockIdx.y;
   const float gs = gscale ? *gscale : 1.f;
   const float A = coef[b * 2] * gs, B = coef[b * 2 + 1] * gs;
-  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) datt[(int64_t)b * nvox + v] = A * label[(int64_t)b * nvox + v] + B;
+  const float* lb = label + (int64_t)b * nvox;
+  float* o = datt + (int64_t)b * nvox;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if ((nvox & 3) == 0 && (reinterpret_cast<uintptr_t>(label) & 15) == 0 && (reinterpret_cast<uintptr_t>(datt) & 15) == 0) {
+    for (int64_t i = tid; i < (nvox >> 2); i += nthr) {
+      const float4 g = reinterpret_cast<const float4*>(lb)[i];
+      reinterpret_cast<float4*>(o)[i] = make_float4(A * g.x + B, A * g.y + B, A * g.z + B, A * g.w + B);
+    }
+  } else {
+    for (int64_t v = tid; v < nvox; v += nthr) o[v] = A * lb[v] + B;
+  }
 }
 extern "C" int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, const float* coef, float inv_levels, const float* gscale, float* datt, void* stream) {
   (void)inv_levels;  // the 1/L factor is already folded into coef by vsseg_dice_finalize
   VSSEG_CHECK(label && coef && datt, "vsseg_dice_att_bwd: bad arguments");
-  dim3 g(grid_for(nvox, 256, 2048), n);
+  dim3 g(grid_for((nvox + 3) / 4, 256, 2048), n);
   hipLaunchKernelGGL(dice_att_bwd_kernel, g, dim3(256), 0, as_stream(stream), label, nvox, coef, gscale, datt);
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_bwd");
   return VSSEG_OK;

@@ -24,7 +24,7 @@ constexpr int MW_NR = 4;  // ring slots of H: planes x-1, x, x+1 + the one in fl
 struct MwgradK {
   const char* h0; const char* h1;  // H (ring operand): channels [0, csplit) / [csplit, c) biased by -csplit channels
   const char* p;                   // P (centre operand), one part
-  float* slab;                     // [gridDim.x][NTH][9][NTP*16][16]
+  float* slab;                     // [gridDim.x][NTH][9][NTP][64 lanes][4] (wgrad.hip's slab layout: a tile leaves as one 1 KiB store)
   float* dbias;                    // optional: [gridDim.x][NTP*16] rows of partial bias gradients sum_q P[q][cP] (summed in a fixed order by vsseg_slab_add_kernel)
   const float* h_gate;             // GIN: fp32 attention map of H: voxel v of H is multiplied by (1 + h_gate[v]) on load (mconv.hip, MODE 3)
   const void* zeros;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
     }
   }
 
-  // ---- flush.  Lane holds rows g*4 + r (P channel) x column l15 (H channel) of every owned (tap, cH tile, cP tile).
+  // ---- flush.  Lane holds rows g*4 + r (P channel) x column l15 (H channel) of every owned (tap, cH tile, cP tile): its four values are 16 bytes of the slab.
   __syncthreads();  // the ring is free: it becomes the cross-wave reduction buffer
   float* red = reinterpret_cast<float*>(smem);
   float* slab = k.slab + (int64_t)blockIdx.x * (NTH * 9 * NTP * 256);
@@ -266,9 +266,7 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
       if (unit >= UNITS) break;
       const int tap = unit / NTH, th = unit % NTH;
 #pragma unroll
-      for (int tp = 0; tp < NTP; ++tp)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) slab[((int64_t)(th * 9 + tap) * (NTP * 16) + tp * 16 + g * 4 + r) * 16 + l15] = acc[u][tp][r];
+      for (int tp = 0; tp < NTP; ++tp) *reinterpret_cast<f32x4*>(slab + ((th * 9 + tap) * NTP + tp) * 256 + lane * 4) = acc[u][tp];
     }
   } else {  // the four waves hold partial sums over their K-steps: added in wave order through LDS (run-to-run bit-identical)
     constexpr int NACC = UNITS * NTP * 256;  // floats
@@ -279,14 +277,12 @@ __global__ __launch_bounds__(256, 2) void mwgrad_kernel(const MwgradK k) {
         for (int u = 0; u < MYU; ++u) {
           const int tap = u / NTH, th = u % NTH;
 #pragma unroll
-          for (int tp = 0; tp < NTP; ++tp)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* dst = red + ((th * 9 + tap) * (NTP * 16) + tp * 16 + g * 4 + r) * 16 + l15;
-              if (w == 0) *dst = acc[u][tp][r];
-              else if (w < 3) *dst += acc[u][tp][r];
-              else slab[dst - red] = *dst + acc[u][tp][r];
-            }
+          for (int tp = 0; tp < NTP; ++tp) {
+            f32x4* dst = reinterpret_cast<f32x4*>(red + ((th * 9 + tap) * NTP + tp) * 256 + lane * 4);
+            if (w == 0) *dst = acc[u][tp];
+            else if (w < 3) *dst += acc[u][tp];
+            else *reinterpret_cast<f32x4*>(slab + (reinterpret_cast<float*>(dst) - red)) = *dst + acc[u][tp];
+          }
         }
       }
       __syncthreads();

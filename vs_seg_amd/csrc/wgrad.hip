@@ -65,9 +65,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   const int chunk0 = blockIdx.y * HG;  // first 16-channel chunk of H this workgroup owns
   const int p_bytes = k.tvox * k.p_row, h_bytes = hvox * HROW;
 
+  // (run-time divisors, values < 2^16: vsseg_fdiv.  With plain `/` and `%` the coordinate tables below took 6.3 us per workgroup, more than its first tile)
+  const int T1 = d.tile[1], T2 = d.tile[2];
+  const float iT1 = 1.0f / (float)T1, iT2 = 1.0f / (float)T2, iHY = 1.0f / (float)HY, iHZ = 1.0f / (float)HZ;
   for (int v = tid; v < k.tvox; v += 256) {
-    int vz = v % d.tile[2], r = v / d.tile[2];
-    int vy = r % d.tile[1], vx = r / d.tile[1];
+    const int r = vsseg_fdiv(v, T2, iT2), vz = v - r * T2;
+    const int vx = vsseg_fdiv(r, T1, iT1), vy = r - vx * T1;
     hbase[v] = ((vx * d.hs[0]) * HY + vy * d.hs[1]) * HZ + vz * d.hs[2];
   }
   int toff[MAXT];  // LDS byte offset of each owned tap inside the halo tile (-1: not owned)
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
   // ---- per-thread constants of the two DMA tiles (same scheme as igemm.hip: tile-independent part precomputed once) ----
   const int PX = d.p.x, PY = d.p.y, PZ = d.p.z, QX = d.h.x, QY = d.h.y, QZ = d.h.z;
   const unsigned p_vox_bytes = (unsigned)d.p.pitch * ES, h_vox_bytes = (unsigned)d.h.pitch * ES;
-  const int ppp = k.p_row >> 4;   // 16-byte pieces per P voxel row (NTP*16 channels)
+  constexpr int ppp = NTP * ES;   // 16-byte pieces per P voxel row (NTP*16 channels; = k.p_row >> 4)
   const int ppieces = k.tvox * ppp;
   const int hpieces = hvox * HPP;
   unsigned prel[WPP], hrel[WPH];  // 0xffffffff: no piece
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     unsigned info = 0xffffffffu, rel = 0xffffffffu;
     if (j < ppieces) {
       const int v = j / ppp, c16 = j - v * ppp;
-      int vz = v % d.tile[2], r = v / d.tile[2];
-      int vy = r % d.tile[1], vx = r / d.tile[1];
+      const int r = vsseg_fdiv(v, T2, iT2), vz = v - r * T2;
+      const int vx = vsseg_fdiv(r, T1, iT1), vy = r - vx * T1;
       const bool cok = c16 * EPP + EPP <= d.p.c;  // channels beyond the tensor are zero-filled
       info = (unsigned)vx | ((unsigned)vy << 8) | ((unsigned)vz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
       rel = (unsigned)((vx * PY + vy) * PZ + vz) * p_vox_bytes + (unsigned)c16 * 16u;
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
     unsigned info = 0xffffffffu, rel = 0xffffffffu;
     if (j < hpieces) {
       const int hv = j / HPP, c16 = j - hv * HPP;
-      int hz = hv % HZ, r = hv / HZ;
-      int hy = r % HY, hx = r / HY;
+      const int r = vsseg_fdiv(hv, HZ, iHZ), hz = hv - r * HZ;
+      const int hx = vsseg_fdiv(r, HY, iHY), hy = r - hx * HY;
       const int ch = chunk0 * 16 + c16 * EPP;  // first channel of the piece inside H
       const bool cok = ch + EPP <= d.h.c;
       info = (unsigned)hx | ((unsigned)hy << 8) | ((unsigned)hz << 16) | ((unsigned)(cok ? c16 : 255) << 24);
@@ -315,41 +318,41 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradK k) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) brow[p * 16 + g * 4 + r] = accb[p][r];
   }
-  // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) -> this workgroup's slab [tap][cP][16]
+  // flush: lane holds rows g*4+r (P channel) x col l15 (H channel) of every owned tile -> this workgroup's slab [chunk][tap][P tile][64 lanes][4]: a tile
+  // leaves as ONE coalesced 1 KiB store per wave (the first layout, [tap][cP][16], took four 4-byte stores of four 64-byte segments each: on the levels
+  // with few voxels and many channels, where a workgroup's slab is as large as the weight gradient itself, the flush was the longest phase of the launch)
 #pragma unroll
   for (int h = 0; h < HG; ++h) {
     if (chunk0 + h >= k.hchunks) break;  // the last group may be short
-    float* slab = k.slab + (((int64_t)blockIdx.x * k.wv + wv) * k.hchunks + chunk0 + h) * k.slab_chunk;  // K-steps split over waves (1x1x1 kernels): one slab per share
+    float* slab = k.slab + (((int64_t)blockIdx.x * k.wv + wv) * k.hchunks + chunk0 + h) * k.slab_chunk + lane * 4;  // K-steps split over waves (1x1x1 kernels): one slab per share
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       const int t = wt + i * k.wt;
       if (t >= d.ntaps) continue;
 #pragma unroll
-      for (int p = 0; p < NTP; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cp = p * 16 + g * 4 + r;
-          float* dst = slab + ((int64_t)t * (NTP * 16) + cp) * 16 + l15;
-          *dst = acc[i][h][p][r];
-        }
+      for (int p = 0; p < NTP; ++p) *reinterpret_cast<f32x4*>(slab + (t * NTP + p) * 256) = acc[i][h][p];
     }
   }
 }
 
 #ifndef WG_INST
-// dw[cp][ch][tap] += sum over workgroups of their slabs (vsseg_slab_sum: 64 elements x 16 slab lanes per block, fixed summation order).
+// dw[cp][ch][tap] += sum over workgroups of their slabs (vsseg_slab_sum4: 64 x 4 elements x 16 slab lanes per block, fixed summation order); element e of a
+// slab = (chunk, tap, P tile, lane, r) as the flushes of wgrad_kernel, mwgrad_kernel and cwgrad_kernel write it: value (cP = tile*16 + (lane>>4)*4 + r, cH = chunk*16 + (lane&15)).
 // (One thread per element walking all <= 1024 slabs was a 41 us latency chain per layer: 1.9 ms per step in 45 launches, profiles/r02_kernel_stats.txt.)
-__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntaps, int cpad, int slab_chunk, vsseg_wgrad_desc d) {
-  __shared__ float lds[VSSEG_SLAB_THREADS];
+__global__ __launch_bounds__(VSSEG_SLAB_THREADS) void wgrad_reduce_kernel(const float* __restrict__ slab, int nblk, int hchunks, int ntp, int slab_chunk, vsseg_wgrad_desc d) {
+  __shared__ f32x4 lds[VSSEG_SLAB_THREADS];
   const int64_t total = (int64_t)hchunks * slab_chunk;
-  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const float s = vsseg_slab_sum(slab, total, i, nblk, lds);
+  const int64_t i = ((int64_t)blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  const f32x4 s = vsseg_slab_sum4(slab, total, i, nblk, lds);
   if (threadIdx.x >= 64 || i >= total) return;
-  const int chunk = (int)(i / slab_chunk), r = (int)(i - (int64_t)chunk * slab_chunk);
-  const int l15 = r & 15, cp = (r >> 4) % cpad, t = (r >> 4) / cpad;
-  const int ch = chunk * 16 + l15;
-  if (cp >= d.cp_valid || ch >= d.ch_valid) return;
-  d.dw[cp * d.stride_p + ch * d.stride_h + d.tap_widx[t] * d.stride_tap] += s;
+  const int chunk = (int)(i / slab_chunk), e = (int)(i - (int64_t)chunk * slab_chunk);
+  const int lane = (e >> 2) & 63, tile = e >> 8, ptile = tile % ntp, tap = tile / ntp;
+  const int cp0 = ptile * 16 + (lane >> 4) * 4, ch = chunk * 16 + (lane & 15);
+  if (ch >= d.ch_valid) return;
+  float* dst = d.dw + (int64_t)ch * d.stride_h + (int64_t)d.tap_widx[tap] * d.stride_tap;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (cp0 + r < d.cp_valid) dst[(int64_t)(cp0 + r) * d.stride_p] += s[r];
 }
 
 #endif  // WG_INST
@@ -417,8 +420,8 @@ int vsseg_wgrad_launch_bf16(WgradK& k, int maxt, int hg, dim3& grid, int lds, hi
 #ifndef WG_INST
 // sums `nblk` partial-sum slabs [nblk][hchunks][slab_chunk] into d->dw
 int vsseg_wgrad_reduce_launch(const vsseg_wgrad_desc* d, float* slab, int nblk, int hchunks, int slab_chunk, hipStream_t s) {
-  const int total = hchunks * slab_chunk;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)slab, nblk, hchunks, d->ntaps, d->ntp * 16, slab_chunk, *d);
+  const int total = hchunks * slab_chunk;  // a multiple of 256
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total / 4 + 63) / 64), dim3(VSSEG_SLAB_THREADS), 0, s, (const float*)slab, nblk, hchunks, d->ntp, slab_chunk, *d);
   VSSEG_LAUNCH_CHECK("vsseg_wgrad(reduce)");
   return VSSEG_OK;
 }

@@ -937,11 +937,12 @@ class Plan:
                 if compact:
                     buf = self._raw("g:logits2", 0, prog.logits.c)
                     staged["c"] = self._tdesc(buf, 0)
-                    self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), staged["c"]]])
+                    self.glogits_dst = staged["c"]
                 else:
                     buf = self._raw("g:logits8", 0, 8)  # channels 2..7 stay zero
                     staged["p"] = self._tdesc(buf, 0)
-                    self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), L.Tensor(buf.data_ptr(), _tdtype(buf), prog.logits.c, 8, self.n, x0, y0, z0, None, 0, L.ZERO_PADDED)]])
+                    self.glogits_dst = L.Tensor(buf.data_ptr(), _tdtype(buf), prog.logits.c, 8, self.n, x0, y0, z0, None, 0, L.ZERO_PADDED)
+                self.bwd_pre.append([lib.vsseg_copy_cast, [_Slot("glogits"), self.glogits_dst]])
             return staged["c" if compact else "p"]
 
         def gdesc(spec: TensorSpec) -> L.Tensor:
@@ -1363,6 +1364,24 @@ class Plan:
                 self._gatt_set[name] = True
             elif self._gatt_set.get(name):  # no external gradient this time: back to zeros
                 L.check(lib.vsseg_memset_zero(buf.data_ptr(), nbytes, stream), "memset_zero")
+                self._gatt_set[name] = False
+
+    def grad_landing(self):
+        """Where a loss that runs between this plan's forward and backward may write its gradients itself (the fused train step, vs_seg_amd.parallel):
+        the descriptor the eager prelude stages the gradient of the logits in (compute dtype; compact two channels, or the first two of VSSEG_ZERO_PADDED rows
+        of 8) and, per attention map in the network's order, the fp32 buffer the captured backward reads (None: that map has no gradient path)."""
+        assert self.train and getattr(self, "glogits_dst", None) is not None, "no backward was lowered for this plan"
+        return self.glogits_dst, [self.gatt_buf.get(spec.name) for spec in self.eng.prog.att_maps]
+
+    def grads_landed(self, att_written, stream=None):
+        """The loss wrote the staged gradient of the logits and the attention-map buffers named in `att_written` in place: what set_external_grads + the
+        eager prelude would have copied is already there.  Buffers of maps without a gradient this time go back to zeros."""
+        stream = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        for name, buf in self.gatt_buf.items():
+            if name in att_written:
+                self._gatt_set[name] = True
+            elif self._gatt_set.get(name):
+                L.check(self.eng.lib.vsseg_memset_zero(buf.data_ptr(), buf.numel() * 4, stream), "memset_zero")
                 self._gatt_set[name] = False
 
     def zero_stats(self, stream, row=None):

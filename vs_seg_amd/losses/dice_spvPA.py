@@ -32,66 +32,82 @@ def _c1(x: torch.Tensor) -> torch.Tensor:
     return v
 
 
+class _State:
+    """What the forward leaves for the backward: channels-last logits, labels (full resolution + the pyramid), the coefficients of vsseg_dice_finalize."""
+    __slots__ = ("lg", "lab", "labels", "coef", "hardness", "nl", "shape", "att_shapes", "loss")
+
+
+def _dice_forward(logits, target, supervised, hardness, atts) -> _State:
+    lib = L.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = logits.device
+    B, Cc, X, Y, Z = logits.shape
+    if Cc != 2:
+        raise NotImplementedError("Dice_spvPA HIP path: 2-class logits (the configuration VSparams uses)")
+    if target.shape != (B, 1, X, Y, Z):
+        raise AssertionError(f"ground truth has differing shape ({tuple(target.shape)}) from input ({tuple(logits.shape)})")
+    lg, lab = _cl_logits(logits), _c1(target)
+    nvox = X * Y * Z
+    nl = len(atts) if supervised else 0
+    sums = torch.empty(B * 6 + max(nl, 1) * B * 3, dtype=torch.float64, device=dev)  # [pred | att levels], zeroed through the C ABI (no ATen fill kernels on the step)
+    L.check(lib.vsseg_memset_zero(sums.data_ptr(), sums.numel() * 8, stream), "memset_zero")
+    pred_sums, att_sums = sums[: B * 6], sums[B * 6 :]
+    L.check(lib.vsseg_dice_pred_sums(lg.data_ptr(), 2, lab.data_ptr(), B, nvox, int(hardness), pred_sums.data_ptr(), stream), "dice_pred_sums")
+    labels: List[torch.Tensor] = []
+    if nl:
+        g, gdims = lab, (X, Y, Z)
+        for level in range(nl):  # finest attention map first (ref :256-277)
+            a = atts[nl - level - 1]
+            adims = tuple(a.shape[2:])
+            if adims != gdims:
+                assert all(x % y == 0 for x, y in zip(gdims, adims)), "attention-map pyramid must divide (ref dice_spvPA.py:273)"
+                ratio = tuple(x // y for x, y in zip(gdims, adims))
+                g2 = torch.empty((B, 1, *adims), dtype=torch.float32, device=dev)
+                L.check(lib.vsseg_maxpool_label(g.data_ptr(), B, L.i3(gdims), L.i3(ratio), g2.data_ptr(), stream), "maxpool_label")
+                g, gdims = g2, adims
+            ac = _c1(a)
+            if tuple(ac.shape) != (B, 1, *adims):
+                raise AssertionError(f"ground truth has differing shape ({(B, 1, *gdims)}) from input ({tuple(ac.shape)})")
+            L.check(lib.vsseg_dice_att_sums(ac.data_ptr(), g.data_ptr(), B, adims[0] * adims[1] * adims[2], att_sums.data_ptr() + 8 * level * B * 3, stream), "dice_att_sums")
+            labels.append(g)
+    loss = torch.empty((), dtype=torch.float32, device=dev)  # vsseg_dice_finalize assigns the loss and every coefficient it is asked for
+    coef = torch.empty(B * 4 + max(nl, 1) * B * 2, dtype=torch.float32, device=dev)
+    L.check(lib.vsseg_dice_finalize(pred_sums.data_ptr(), att_sums.data_ptr(), B, nl, loss.data_ptr(), coef.data_ptr(), stream), "dice_finalize")
+    st = _State()
+    st.lg, st.lab, st.labels, st.coef, st.hardness, st.nl, st.shape = lg, lab, labels, coef, int(hardness), nl, (B, X, Y, Z)
+    st.att_shapes = [tuple(a.shape) for a in atts]
+    st.loss = loss
+    return st
+
+
+def _att_backward(st: _State, level: int, gs_ptr, dst: torch.Tensor):
+    B = st.shape[0]
+    shp = st.att_shapes[st.nl - level - 1]
+    L.check(L.lib().vsseg_dice_att_bwd(st.labels[level].data_ptr(), B, shp[2] * shp[3] * shp[4], st.coef.data_ptr() + 4 * (B * 4 + level * B * 2), 1.0 / st.nl, gs_ptr, dst.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "dice_att_bwd")
+
+
 class _DiceFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target, supervised, hardness, *atts):
-        lib = L.lib()
-        stream = torch.cuda.current_stream().cuda_stream
-        dev = logits.device
-        B, Cc, X, Y, Z = logits.shape
-        if Cc != 2:
-            raise NotImplementedError("Dice_spvPA HIP path: 2-class logits (the configuration VSparams uses)")
-        if target.shape != (B, 1, X, Y, Z):
-            raise AssertionError(f"ground truth has differing shape ({tuple(target.shape)}) from input ({tuple(logits.shape)})")
-        lg, lab = _cl_logits(logits), _c1(target)
-        nvox = X * Y * Z
-        nl = len(atts) if supervised else 0
-        sums = torch.empty(B * 6 + max(nl, 1) * B * 3, dtype=torch.float64, device=dev)  # [pred | att levels], zeroed through the C ABI (no ATen fill kernels on the step)
-        L.check(lib.vsseg_memset_zero(sums.data_ptr(), sums.numel() * 8, stream), "memset_zero")
-        pred_sums, att_sums = sums[: B * 6], sums[B * 6 :]
-        L.check(lib.vsseg_dice_pred_sums(lg.data_ptr(), 2, lab.data_ptr(), B, nvox, int(hardness), pred_sums.data_ptr(), stream), "dice_pred_sums")
-        labels: List[torch.Tensor] = []
-        amaps = []
-        if nl:
-            g, gdims = lab, (X, Y, Z)
-            for level in range(nl):  # finest attention map first (ref :256-277)
-                a = atts[nl - level - 1]
-                adims = tuple(a.shape[2:])
-                if adims != gdims:
-                    assert all(x % y == 0 for x, y in zip(gdims, adims)), "attention-map pyramid must divide (ref dice_spvPA.py:273)"
-                    ratio = tuple(x // y for x, y in zip(gdims, adims))
-                    g2 = torch.empty((B, 1, *adims), dtype=torch.float32, device=dev)
-                    L.check(lib.vsseg_maxpool_label(g.data_ptr(), B, L.i3(gdims), L.i3(ratio), g2.data_ptr(), stream), "maxpool_label")
-                    g, gdims = g2, adims
-                ac = _c1(a)
-                if tuple(ac.shape) != (B, 1, *adims):
-                    raise AssertionError(f"ground truth has differing shape ({(B, 1, *gdims)}) from input ({tuple(ac.shape)})")
-                L.check(lib.vsseg_dice_att_sums(ac.data_ptr(), g.data_ptr(), B, adims[0] * adims[1] * adims[2], att_sums.data_ptr() + 8 * level * B * 3, stream), "dice_att_sums")
-                labels.append(g)
-                amaps.append(ac)
-        loss = torch.empty((), dtype=torch.float32, device=dev)  # vsseg_dice_finalize assigns the loss and every coefficient it is asked for
-        coef = torch.empty(B * 4 + max(nl, 1) * B * 2, dtype=torch.float32, device=dev)
-        L.check(lib.vsseg_dice_finalize(pred_sums.data_ptr(), att_sums.data_ptr(), B, nl, loss.data_ptr(), coef.data_ptr(), stream), "dice_finalize")
-        ctx.lg, ctx.lab, ctx.labels, ctx.coef, ctx.hardness, ctx.nl, ctx.shape = lg, lab, labels, coef, int(hardness), nl, (B, X, Y, Z)
-        ctx.att_shapes = [tuple(a.shape) for a in atts]
-        return loss
+        ctx.st = st = _dice_forward(logits, target, supervised, hardness, atts)
+        return st.loss
 
     @staticmethod
     def backward(ctx, gout):
         lib = L.lib()
+        st = ctx.st
         stream = torch.cuda.current_stream().cuda_stream
-        B, X, Y, Z = ctx.shape
-        dev = ctx.lg.device
+        B, X, Y, Z = st.shape
+        dev = st.lg.device
         gs = gout.detach().to(torch.float32).contiguous()
         dlog = torch.empty((B, X, Y, Z, 2), dtype=torch.float32, device=dev)
-        L.check(lib.vsseg_dice_pred_bwd(ctx.lg.data_ptr(), 2, ctx.lab.data_ptr(), B, X * Y * Z, ctx.hardness, ctx.coef.data_ptr(), gs.data_ptr(), dlog.data_ptr(), stream), "dice_pred_bwd")
-        datts: List[Optional[torch.Tensor]] = [None] * len(ctx.att_shapes)
-        for level in range(ctx.nl):
-            i = ctx.nl - level - 1
-            shp = ctx.att_shapes[i]
-            d = torch.empty(shp, dtype=torch.float32, device=dev)
-            nv = shp[2] * shp[3] * shp[4]
-            L.check(lib.vsseg_dice_att_bwd(ctx.labels[level].data_ptr(), B, nv, ctx.coef.data_ptr() + 4 * (B * 4 + level * B * 2), 1.0 / ctx.nl, gs.data_ptr(), d.data_ptr(), stream), "dice_att_bwd")
+        L.check(lib.vsseg_dice_pred_bwd(st.lg.data_ptr(), 2, st.lab.data_ptr(), B, X * Y * Z, st.hardness, st.coef.data_ptr(), gs.data_ptr(), dlog.data_ptr(), stream), "dice_pred_bwd")
+        datts: List[Optional[torch.Tensor]] = [None] * len(st.att_shapes)
+        for level in range(st.nl):
+            i = st.nl - level - 1
+            d = torch.empty(st.att_shapes[i], dtype=torch.float32, device=dev)
+            _att_backward(st, level, gs.data_ptr(), d)
             datts[i] = d
         return (dlog.permute(0, 4, 1, 2, 3), None, None, None, *datts)
 
@@ -118,3 +134,31 @@ class Dice_spvPA(_Loss):
             raise NotImplementedError("smooth is fixed at 1e-5 (the value the reference always uses)")
         atts: Sequence[torch.Tensor] = list(att_maps) if self.supervised_attention else []
         return _DiceFn.apply(x, target, bool(self.supervised_attention), bool(self.hardness_weighting), *atts)
+
+    def forward_backward_into(self, input, target: torch.Tensor, landing):
+        """The loss AND its gradients in one call, outside autograd (the fused train step of vs_seg_amd.parallel.DataParallelTrainer): d(loss)/d(logits) and
+        d(loss)/d(att_i) are written where `landing` says — `(descriptor of the staged gradient of the logits, [fp32 buffer per attention map or None])`, as
+        UNet2d5_spvPA.train_forward_landing hands it out — in the layout and dtype the network's backward reads, instead of fp32 tensors that the backward
+        would copy and cast (7 passes per step).  The values are those of `loss.backward()` (upstream gradient 1).  Returns (loss, indices of the attention
+        maps whose buffer was written)."""
+        x, att_maps = input
+        if not x.is_cuda:
+            raise RuntimeError("vs_seg_amd.Dice_spvPA runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
+        atts: Sequence[torch.Tensor] = list(att_maps) if self.supervised_attention else []
+        glogits_dst, gatt_bufs = landing
+        with torch.no_grad():
+            st = _dice_forward(x, target, bool(self.supervised_attention), bool(self.hardness_weighting), atts)
+            B, X, Y, Z = st.shape
+            stream = torch.cuda.current_stream().cuda_stream
+            L.check(L.lib().vsseg_dice_pred_bwd_to(st.lg.data_ptr(), 2, st.lab.data_ptr(), B, X * Y * Z, st.hardness, st.coef.data_ptr(), None, glogits_dst, stream), "dice_pred_bwd_to")
+            written = []
+            for level in range(st.nl):
+                i = st.nl - level - 1
+                buf = gatt_bufs[i]
+                if buf is None:
+                    continue  # this map has no gradient path in the network
+                if buf.numel() != B * st.att_shapes[i][2] * st.att_shapes[i][3] * st.att_shapes[i][4] or buf.dtype != torch.float32:
+                    raise AssertionError(f"gradient buffer of attention map {i} does not match its shape {st.att_shapes[i]}")
+                _att_backward(st, level, None, buf)
+                written.append(i)
+        return st.loss, written

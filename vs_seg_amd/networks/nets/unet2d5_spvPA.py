@@ -290,24 +290,61 @@ class UNet2d5_spvPA(nn.Module):
             atts = [a.clone(memory_format=torch.preserve_format) for a in atts]
         return plan, (logits, *atts)
 
-    def _run_backward(self, plan: Plan, g_logits: Optional[torch.Tensor], g_atts):
+    # ---- the fused train step (vs_seg_amd.parallel.DataParallelTrainer): forward, a loss that writes its gradients where the backward reads them, backward ----
+    def train_forward_landing(self, x: torch.Tensor):
+        """Training forward outside autograd.  Returns ((logits, att_maps), landing): the outputs are VIEWS of the plan's buffers (valid until the next training
+        forward of this shape), `landing` = (descriptor of the staged gradient of the logits, [fp32 gradient buffer per attention map]) — see Plan.grad_landing.
+        A loss with `forward_backward_into` writes there; `backward_landed()` then runs the backward without the copy / cast passes of the autograd route."""
+        if not self.training:
+            raise RuntimeError("train_forward_landing: the module is in eval mode")
+        if not x.is_cuda:
+            raise RuntimeError("vs_seg_amd.UNet2d5_spvPA runs on an MI355X only (got a CPU tensor); there is no CPU fallback")
+        if x.dim() != 5 or x.shape[1] != self.in_channels:
+            raise ValueError(f"expected input [B,{self.in_channels},X,Y,Z], got {tuple(x.shape)}")
+        self._ensure_flat()
+        keep, self.reuse_output_buffers = self.reuse_output_buffers, True
+        try:
+            with torch.no_grad():
+                plan, outs = self._run_forward(x, True)
+        finally:
+            self.reuse_output_buffers = keep
+        self._landed = (plan, plan.generation)
+        logits, atts = outs[0], list(outs[1:])
+        if self.attention_module:
+            self.att_maps = atts
+        return (logits, self.att_maps), plan.grad_landing()
+
+    def backward_landed(self, att_written):
+        """Backward of the last `train_forward_landing`; `att_written`: indices of the attention maps whose gradient buffer the loss wrote."""
+        plan, generation = getattr(self, "_landed", (None, None))
+        if plan is None or plan.generation != generation:
+            raise RuntimeError("vs_seg_amd.UNet2d5_spvPA.backward_landed: no training forward of train_forward_landing is pending (or a later one overwrote its activations)")
+        self._landed = (None, None)
+        names = {spec.name for i, spec in enumerate(self._engine.prog.att_maps) if i in set(att_written)}
+        self._run_backward(plan, None, (), landed=names)
+
+    def _run_backward(self, plan: Plan, g_logits: Optional[torch.Tensor], g_atts, landed=None):
         eng = self._engine
         stream = torch.cuda.current_stream().cuda_stream
         n, (X, Y, Z) = plan.n, plan.dims
-        if g_logits is None:
-            g_logits = torch.zeros((n, self.out_channels, X, Y, Z), device=self._flat.device)
-        gl = g_logits.permute(0, 2, 3, 4, 1)
-        if gl.dtype != torch.float32 or not gl.is_contiguous():
-            gl = gl.to(torch.float32).contiguous()
-        keep = [gl]
-        gatt = {}
-        for spec, g in zip(eng.prog.att_maps, g_atts):
-            if g is None:
-                continue
-            g = g.to(torch.float32).contiguous() if (g.dtype != torch.float32 or not g.is_contiguous()) else g
-            keep.append(g)
-            gatt[spec.name] = g.data_ptr()
-        plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt, stream)
+        keep = []
+        if landed is not None:  # the loss wrote its gradients where the backward reads them
+            plan.grads_landed(landed, stream)
+        else:
+            if g_logits is None:
+                g_logits = torch.zeros((n, self.out_channels, X, Y, Z), device=self._flat.device)
+            gl = g_logits.permute(0, 2, 3, 4, 1)
+            if gl.dtype != torch.float32 or not gl.is_contiguous():
+                gl = gl.to(torch.float32).contiguous()
+            keep.append(gl)
+            gatt = {}
+            for spec, g in zip(eng.prog.att_maps, g_atts):
+                if g is None:
+                    continue
+                g = g.to(torch.float32).contiguous() if (g.dtype != torch.float32 or not g.is_contiguous()) else g
+                keep.append(g)
+                gatt[spec.name] = g.data_ptr()
+            plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt, stream)
         plan.set_seed(plan.step_seed, stream)
         plan.zero_stats(stream, 1)
         lib, nbytes = eng.lib, self._gflat.numel() * 4
@@ -317,7 +354,8 @@ class UNet2d5_spvPA(nn.Module):
                 self._gprev = torch.empty_like(self._gflat)
             L.check(lib.vsseg_copy_bytes(self._gflat.data_ptr(), self._gprev.data_ptr(), nbytes, stream), "copy_bytes")
         L.check(lib.vsseg_memset_zero(self._gflat.data_ptr(), nbytes, stream), "memset_zero")
-        plan.run(plan.bwd_pre, stream)  # reads the caller's gradient tensor: always eager
+        if landed is None:
+            plan.run(plan.bwd_pre, stream)  # reads the caller's gradient tensor: always eager
         plan.run(plan.bwd, stream, "bwd")
         if accumulate:
             n4 = self._gflat.numel() // 4  # every tensor is padded to 4 elements inside the flat buffer

@@ -238,6 +238,8 @@ class DataParallelTrainer:
         flat, _ = model.flat_parameters()
         broadcast_parameters(flat, 0)
         self.fused_mean = hasattr(optimizer, "grad_scale")
+        # VSSEG_FUSED_LOSS=0: the autograd route (loss.backward() through fp32 gradient tensors), for A/B measurements
+        self.fused_loss = hasattr(model, "train_forward_landing") and hasattr(loss_fn, "forward_backward_into") and os.environ.get("VSSEG_FUSED_LOSS", "1") != "0"
         if self.fused_mean:
             optimizer.grad_scale = 1.0 / self.world  # the fused Adam kernel multiplies the summed gradient by 1/world
         if self.world > 1 and hasattr(model, "decorrelate_dropout"):
@@ -249,16 +251,23 @@ class DataParallelTrainer:
         self.opt.zero_grad()
         # logits and attention maps never leave this function: the loss reads them and its backward has run before the next forward overwrites the plan's buffers, so the
         # forward may hand out views of them instead of clones (7 device copies, 0.15 ms of a 28 ms step at the benchmark shape)
-        keep = getattr(self.model, "reuse_output_buffers", None)
-        if keep is not None:
-            self.model.reuse_output_buffers = True
-        try:
-            outputs = self.model(inputs)
-            loss = self.loss_fn(outputs, labels)
-            loss.backward()
-        finally:
+        if self.fused_loss and self.model.training:
+            # the loss writes its gradients where the network's backward reads them, in the backward's layout and dtype: no fp32 gradient tensors, no copies of the six
+            # attention-map gradients, no cast pass over the gradient of the logits (7 launches and 0.7 GB of traffic per step at the benchmark shape)
+            outputs, landing = self.model.train_forward_landing(inputs)
+            loss, written = self.loss_fn.forward_backward_into(outputs, labels, landing)
+            self.model.backward_landed(written)
+        else:
+            keep = getattr(self.model, "reuse_output_buffers", None)
             if keep is not None:
-                self.model.reuse_output_buffers = keep
+                self.model.reuse_output_buffers = True
+            try:
+                outputs = self.model(inputs)
+                loss = self.loss_fn(outputs, labels)
+                loss.backward()
+            finally:
+                if keep is not None:
+                    self.model.reuse_output_buffers = keep
         _, gflat = self.model.flat_parameters()
         allreduce_gradients(gflat)
         if self.world > 1 and not self.fused_mean:
