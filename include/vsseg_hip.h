@@ -215,7 +215,7 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 7: + vsseg_dice_pred_bwd_to; 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+int vsseg_version(void); /* 7: + vsseg_dice_pred_bwd_to, vsseg_dice_level_sums, vsseg_dice_tail_sums, vsseg_dice_att_bwd_levels; 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------
@@ -340,6 +340,34 @@ int vsseg_dice_att_sums(const float* att, const float* label, int32_t n, int64_t
 int vsseg_dice_finalize(const double* pred_sums, const double* att_sums, int32_t n, int32_t nlevels, float* loss, float* coef /* [n][2][2] + [levels][n][2] */, void* stream);
 int vsseg_dice_pred_bwd(const float* logits, int32_t pitch, const float* label, int32_t n, int64_t nvox, int32_t hardness, const float* coef, const float* gscale, float* dlogits, void* stream);
 int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, const float* coef, float inv_levels, const float* gscale, float* datt, void* stream);
+/* The same sums with fewer passes and launches (the fused train step; the values feed the same vsseg_dice_finalize):
+   vsseg_dice_level_sums — one pass over a level whose NEXT level pools (2, 2, 1) (the two finest levels of the 2.5D network): att_sums[n][3] of `att` against `label`,
+   pooled = MaxPool3d((2,2,1))(label) (NULL: not wanted) and, when `logits` is given ([n][dims][2], the finest level), pred_sums[n][2][3].  dims must be made of
+   2 x 2 x 4 blocks, operands 16-byte aligned.
+   vsseg_dice_tail_sums — the remaining (coarse) levels in one launch: level i's label = MaxPool3d(sdims / dims[i])(src) is written to label[i] (NULL allowed when
+   dims[i] == sdims: the level is src itself) and sums[i][n][3] are those of att[i] against it. */
+#define VSSEG_DICE_MAX_LEVELS 8
+typedef struct {
+  int32_t n, nlevels;
+  const float* src;   /* [n][sdims] */
+  int32_t sdims[3];
+  const float* att[VSSEG_DICE_MAX_LEVELS];
+  float* label[VSSEG_DICE_MAX_LEVELS];
+  int32_t dims[VSSEG_DICE_MAX_LEVELS][3];
+  double* sums;       /* [nlevels][n][3], fixed-point (see below) */
+} vsseg_dice_tail_desc;
+int vsseg_dice_level_sums(const float* logits, const float* att, const float* label, int32_t n, const int32_t dims[3], int32_t hardness, double* pred_sums, double* att_sums, float* pooled, void* stream);
+int vsseg_dice_tail_sums(const vsseg_dice_tail_desc* d, void* stream);
+/* vsseg_dice_att_bwd of several levels in one launch: datt[i][b][v] = coef[i][b][0] * label[i][b][v] + coef[i][b][1] (times *gscale when given) */
+typedef struct {
+  int32_t n, nlevels;
+  const float* label[VSSEG_DICE_MAX_LEVELS];
+  float* datt[VSSEG_DICE_MAX_LEVELS];
+  const float* coef[VSSEG_DICE_MAX_LEVELS]; /* this level's [n][2] slice of vsseg_dice_finalize's coef */
+  int64_t nvox[VSSEG_DICE_MAX_LEVELS];
+  const float* gscale;                      /* NULL = 1 */
+} vsseg_dice_bwd_levels_desc;
+int vsseg_dice_att_bwd_levels(const vsseg_dice_bwd_levels_desc* d, void* stream);
 /* vsseg_dice_pred_bwd writing the gradient in a layout the training plan stages it in (the fused train step of vs_seg_amd.parallel.DataParallelTrainer: no fp32
    gradient tensor, no cast pass): dst = 2 channels of `n * nvox` voxels, fp32 or bf16 (round-to-nearest-even, as vsseg_copy_cast), pitch 2, or pitch 8 =
    VSSEG_ZERO_PADDED rows whose channels 2..7 are written as zeros (bf16) / left as they are (fp32).  gscale may be NULL (= 1). */

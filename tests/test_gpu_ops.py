@@ -2158,6 +2158,43 @@ def test_dice_loss_and_gradients_in_one_call_equal_the_autograd_route(att):
         assert torch.equal(bufs[i].reshape(-1), atts[i].grad.reshape(-1))
 
 
+@pytest.mark.parametrize("shape,att_dims", [((2, 1, 32, 32, 8), [(1, 1, 1), (2, 2, 2), (4, 4, 4), (8, 8, 8), (16, 16, 8), (32, 32, 8)]),  # two fused levels + a tail of four
+                                            ((1, 1, 24, 8, 12), [(3, 1, 3), (6, 2, 6), (12, 4, 12), (24, 8, 12)]),                       # one fused level + a tail of three
+                                            ((2, 1, 16, 16, 4), [(8, 8, 4), (16, 16, 4)])])                                                # one fused level + a tail that is the pooled label itself
+def test_dice_fused_passes_equal_the_pass_per_level_sequence(shape, att_dims, monkeypatch):
+    """vsseg_dice_level_sums / vsseg_dice_tail_sums / vsseg_dice_att_bwd_levels (fewer passes, fewer launches) against the generic sequence pred_sums + per level maxpool /
+    att_sums / att_bwd: same loss and gradients up to the fp32 partial sums of a thread (the sums themselves are fixed-point: order-independent)."""
+    import vs_seg_amd as V
+    from vs_seg_amd.losses import dice_spvPA as D
+
+    B = shape[0]
+    y = synth_label(31, shape).cuda()
+    lg_cl = (2.0 * synth_input(32, (B, *shape[2:], 2))).cuda()
+    fn = V.Dice_spvPA(to_onehot_y=True, softmax=True)
+    res = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setattr(D, "_fused_plan", lambda *a, **k: None)
+        else:
+            assert D._fused_plan(B, shape[2:], [(B, 1, *d) for d in att_dims], lg_cl, y, []) is not None
+        logits = lg_cl.permute(0, 4, 1, 2, 3).detach().requires_grad_(True)
+        atts = [torch.sigmoid(synth_input(40 + i, (B, 1, *d))).cuda().requires_grad_(True) for i, d in enumerate(att_dims)]
+        loss = fn((logits, atts), y)
+        loss.backward()
+        dst = torch.zeros(B, *shape[2:], 2, device="cuda")
+        bufs = [torch.zeros(B, *d, device="cuda") for d in att_dims]
+        loss2, written = fn.forward_backward_into((logits.detach(), [a.detach() for a in atts]), y, (L.Tensor(dst.data_ptr(), L.F32, 2, 2, B, *shape[2:]), bufs))
+        assert float(loss2) == float(loss) and sorted(written) == list(range(len(att_dims)))
+        assert torch.equal(dst, logits.grad.permute(0, 2, 3, 4, 1))
+        for i in written:
+            assert torch.equal(bufs[i].reshape(-1), atts[i].grad.reshape(-1))
+        res.append((float(loss), logits.grad.clone(), [a.grad.clone() for a in atts]))
+    assert abs(res[0][0] - res[1][0]) < 2e-6
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), rtol=2e-5, atol=1e-10)
+    for a, b in zip(res[0][2], res[1][2]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-10)
+
+
 def test_adam_matches_torch_golden():
     g = load("adam.npz")
     lib = L.lib()

@@ -35,7 +35,7 @@ extern "C" int vsseg_maxpool_label(const float* src, int32_t n, const int32_t sd
 // counts: integers, exact in fp64 whatever the order)
 constexpr double VSSEG_FX_DICE = 4294967296.0;  // 2^32: sums of at most 2^31 voxel weights in [0, 1], 2.3e-10 resolution
 __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double* dst, double fx, unsigned* fxflag) {
-  __shared__ double sh[16][8];
+  __shared__ double sh[16][12];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int k = 0; k < nvals; ++k) {
     double v = wave_sum_d(vals[k]);
@@ -142,6 +142,150 @@ extern "C" int vsseg_dice_att_sums(const float* att, const float* label, int32_t
   VSSEG_FX_FLAG(fxflag, "vsseg_dice_att_sums");
   hipLaunchKernelGGL(dice_att_sums_kernel, g, dim3(DICE_THREADS), 0, as_stream(stream), att, label, nvox, sums, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_sums");
+  return VSSEG_OK;
+}
+
+// One pass over one level of the supervision pyramid whose next level pools (2, 2, 1) (the two finest levels of the 2.5D network): the attention-map sums against the
+// level's label, the next level's label G' = MaxPool3d((2,2,1))(G) (ref :268-277) and, at the finest level (PRED), the sums of the softmax Dice of the logits — what
+// vsseg_dice_pred_sums + vsseg_dice_att_sums + vsseg_maxpool_label do in three passes that read the label three times (0.63 GB instead of 0.43 at 4 x 384x128x128).
+// A thread owns a 2 x 2 x 4 block of voxels = four z-quads of one pooling window row: sixteen 16-byte loads in flight, one 16-byte store of pooled labels.
+template <bool PRED>
+__global__ __launch_bounds__(DICE_THREADS) void dice_level_kernel(const float* __restrict__ logits, const float* __restrict__ att, const float* __restrict__ label, int X, int Y, int Z, int hardness,
+                                                                    double* __restrict__ pred_sums, double* __restrict__ att_sums, float* __restrict__ pooled, unsigned* fxflag) {
+  const int b = blockIdx.y;
+  const int64_t nvox = (int64_t)X * Y * Z;
+  const int X2 = X >> 1, Y2 = Y >> 1, Zq = Z >> 2;
+  const float4* lg4 = PRED ? reinterpret_cast<const float4*>(logits + (int64_t)b * nvox * 2) : nullptr;
+  const float4* at4 = reinterpret_cast<const float4*>(att + (int64_t)b * nvox);
+  const float4* lb4 = reinterpret_cast<const float4*>(label + (int64_t)b * nvox);
+  float4* po4 = pooled ? reinterpret_cast<float4*>(pooled + (int64_t)b * (nvox >> 2)) : nullptr;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t items = (int64_t)X2 * Y2 * Zq, nthr = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < items; i += nthr) {
+    const int zq = (int)(i % Zq);
+    const int64_t r = i / Zq;
+    const int y2 = (int)(r % Y2), x2 = (int)(r / Y2);
+    float4 g[4], p[4], la[4], lc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t q = ((int64_t)(2 * x2 + (j >> 1)) * Y + 2 * y2 + (j & 1)) * Zq + zq;  // float4 index of the quad
+      g[j] = lb4[q];
+      p[j] = at4[q];
+      if constexpr (PRED) { la[j] = lg4[2 * q]; lc[j] = lg4[2 * q + 1]; }
+    }
+    float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ai = 0.f, ag = 0.f, ap = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (PRED) {
+        dice_pred_terms(la[j].x, la[j].y, g[j].x, hardness, t);
+        dice_pred_terms(la[j].z, la[j].w, g[j].y, hardness, t);
+        dice_pred_terms(lc[j].x, lc[j].y, g[j].z, hardness, t);
+        dice_pred_terms(lc[j].z, lc[j].w, g[j].w, hardness, t);
+      }
+      ai += (g[j].x * p[j].x + g[j].y * p[j].y) + (g[j].z * p[j].z + g[j].w * p[j].w);
+      ag += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      ap += (p[j].x + p[j].y) + (p[j].z + p[j].w);
+    }
+    if constexpr (PRED) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc[k] += (double)t[k];
+    }
+    acc[6] += (double)ai; acc[7] += (double)ag; acc[8] += (double)ap;
+    if (po4) {
+      float4 m;
+      m.x = fmaxf(fmaxf(g[0].x, g[1].x), fmaxf(g[2].x, g[3].x));
+      m.y = fmaxf(fmaxf(g[0].y, g[1].y), fmaxf(g[2].y, g[3].y));
+      m.z = fmaxf(fmaxf(g[0].z, g[1].z), fmaxf(g[2].z, g[3].z));
+      m.w = fmaxf(fmaxf(g[0].w, g[1].w), fmaxf(g[2].w, g[3].w));
+      po4[((int64_t)x2 * Y2 + y2) * Zq + zq] = m;
+    }
+  }
+  // (block_reduce_add: threads 0..nvals-1 add one value each — the two groups go to their own buffers in two calls)
+  if constexpr (PRED) block_reduce_add(acc, 6, pred_sums + (int64_t)b * 6, VSSEG_FX_DICE, fxflag);
+  if constexpr (PRED) __syncthreads();
+  block_reduce_add(acc + 6, 3, att_sums + (int64_t)b * 3, VSSEG_FX_DICE, fxflag);
+}
+extern "C" int vsseg_dice_level_sums(const float* logits, const float* att, const float* label, int32_t n, const int32_t dims[3], int32_t hardness, double* pred_sums, double* att_sums, float* pooled, void* stream) {
+  VSSEG_CHECK(att && label && att_sums && n >= 1 && (!logits || pred_sums), "vsseg_dice_level_sums: bad arguments");
+  VSSEG_CHECK(dims[0] >= 2 && dims[1] >= 2 && dims[2] >= 4 && dims[0] % 2 == 0 && dims[1] % 2 == 0 && dims[2] % 4 == 0, "vsseg_dice_level_sums: %d x %d x %d is not made of 2 x 2 x 4 blocks", dims[0], dims[1], dims[2]);
+  VSSEG_CHECK(((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(att) | reinterpret_cast<uintptr_t>(label) | reinterpret_cast<uintptr_t>(pooled)) & 15) == 0, "vsseg_dice_level_sums: operands must be 16-byte aligned");
+  const int64_t items = (int64_t)(dims[0] / 2) * (dims[1] / 2) * (dims[2] / 4);
+  dim3 g(dice_blocks(items * 2, n), n);  // (an item is sixteen voxels: twice the loads of the other reductions' eight per thread and round)
+  VSSEG_FX_FLAG(fxflag, "vsseg_dice_level_sums");
+  if (logits) hipLaunchKernelGGL(dice_level_kernel<true>, g, dim3(DICE_THREADS), 0, as_stream(stream), logits, att, label, dims[0], dims[1], dims[2], hardness, pred_sums, att_sums, pooled, fxflag);
+  else hipLaunchKernelGGL(dice_level_kernel<false>, g, dim3(DICE_THREADS), 0, as_stream(stream), logits, att, label, dims[0], dims[1], dims[2], hardness, pred_sums, att_sums, pooled, fxflag);
+  VSSEG_LAUNCH_CHECK("vsseg_dice_level_sums");
+  return VSSEG_OK;
+}
+
+// The coarse levels of the supervision pyramid in ONE launch: level i's label = MaxPool3d(sdims / dims_i)(src) straight from the finest of them (a max-pool of a max-pool
+// is the max-pool over the product window) and its attention-map sums.  Level by level this was two launches of a few thousand voxels each, ~6 us apiece whatever their size.
+struct DiceTailK {
+  vsseg_dice_tail_desc d;
+  int first[VSSEG_DICE_MAX_LEVELS + 1];  // workgroup range of level i: [first[i], first[i+1])
+};
+__global__ __launch_bounds__(256) void dice_tail_kernel(const DiceTailK k, unsigned* fxflag) {
+  const int b = blockIdx.y;
+  int l = 0;
+  while (l + 1 < k.d.nlevels && (int)blockIdx.x >= k.first[l + 1]) ++l;
+  const int nb = k.first[l + 1] - k.first[l], lb = (int)blockIdx.x - k.first[l];
+  const int dx = k.d.dims[l][0], dy = k.d.dims[l][1], dz = k.d.dims[l][2];
+  const int sx = k.d.sdims[0], sy = k.d.sdims[1], sz = k.d.sdims[2];
+  const int rx = sx / dx, ry = sy / dy, rz = sz / dz;
+  const int nvox = dx * dy * dz;
+  const float* src = k.d.src + (int64_t)b * sx * sy * sz;
+  const float* att = k.d.att[l] + (int64_t)b * nvox;
+  float* out = k.d.label[l] ? k.d.label[l] + (int64_t)b * nvox : nullptr;
+  double acc[3] = {0, 0, 0};
+  // T lanes (a power of two <= 64) share the pooling window of one voxel — the coarsest level of the benchmark network pools 8 x 8 x 8 = 512 values per voxel for 768 voxels:
+  // one thread per voxel walked them one dependent load after the other (170 us for the launch) — and meet in a butterfly of lane exchanges (max: exact in any order)
+  const int win = rx * ry * rz;
+  int T = 1;
+  while (T < 64 && T * 2 <= win) T *= 2;
+  const int vpb = 256 / T, sub = (int)threadIdx.x % T, slot = (int)threadIdx.x / T;
+  for (int base = lb * vpb; base < nvox; base += nb * vpb) {  // (block-uniform trip count: every lane takes part in the exchanges)
+    const int i = base + slot;
+    const bool live = i < nvox;
+    const int z = live ? i % dz : 0, r = live ? i / dz : 0, y = r % dy, x = r / dy;
+    float m = -INFINITY;
+    for (int w = sub; w < win; w += T) {
+      const int e = w % rz, ac = w / rz, c = ac % ry, a = ac / ry;
+      m = fmaxf(m, src[((int64_t)(x * rx + a) * sy + y * ry + c) * sz + z * rz + e]);
+    }
+    for (int off = T >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (live && sub == 0) {
+      if (out) out[i] = m;
+      const float p = att[i];
+      acc[0] += (double)(m * p); acc[1] += (double)m; acc[2] += (double)p;
+    }
+  }
+  block_reduce_add(acc, 3, k.d.sums + ((int64_t)l * k.d.n + b) * 3, VSSEG_FX_DICE, fxflag);
+}
+extern "C" int vsseg_dice_tail_sums(const vsseg_dice_tail_desc* d, void* stream) {
+  VSSEG_CHECK(d && d->src && d->sums && d->n >= 1 && d->nlevels >= 1 && d->nlevels <= VSSEG_DICE_MAX_LEVELS, "vsseg_dice_tail_sums: bad arguments");
+  DiceTailK k;
+  k.d = *d;
+  int nb = 0;
+  for (int l = 0; l < d->nlevels; ++l) {
+    VSSEG_CHECK(d->att[l], "vsseg_dice_tail_sums: level %d has no attention map", l);
+    bool same = true;
+    for (int a = 0; a < 3; ++a) {
+      VSSEG_CHECK(d->dims[l][a] >= 1 && d->sdims[a] % d->dims[l][a] == 0, "vsseg_dice_tail_sums: attention pyramid shapes must divide (ref dice_spvPA.py:273)");
+      same = same && d->dims[l][a] == d->sdims[a];
+    }
+    VSSEG_CHECK(d->label[l] || same, "vsseg_dice_tail_sums: level %d pools but has no label buffer", l);
+    const int64_t nvox = (int64_t)d->dims[l][0] * d->dims[l][1] * d->dims[l][2];
+    VSSEG_CHECK(nvox < (1ll << 30), "vsseg_dice_tail_sums: level %d is too large for the tail launch", l);
+    k.first[l] = nb;
+    int64_t win = 1, T = 1;
+    for (int a = 0; a < 3; ++a) win *= d->sdims[a] / d->dims[l][a];
+    while (T < 64 && T * 2 <= win) T *= 2;
+    nb += (int)std::min<int64_t>(64, (nvox * T + 1023) / 1024);  // T lanes per voxel (dice_tail_kernel)
+  }
+  for (int l = d->nlevels; l <= VSSEG_DICE_MAX_LEVELS; ++l) k.first[l] = nb;
+  VSSEG_FX_FLAG(fxflag, "vsseg_dice_tail_sums");
+  hipLaunchKernelGGL(dice_tail_kernel, dim3(nb, d->n), dim3(256), 0, as_stream(stream), k, fxflag);
+  VSSEG_LAUNCH_CHECK("vsseg_dice_tail_sums");
   return VSSEG_OK;
 }
 
@@ -284,6 +428,39 @@ extern "C" int vsseg_dice_att_bwd(const float* label, int32_t n, int64_t nvox, c
   dim3 g(grid_for((nvox + 3) / 4, 256, 2048), n);
   hipLaunchKernelGGL(dice_att_bwd_kernel, g, dim3(256), 0, as_stream(stream), label, nvox, coef, gscale, datt);
   VSSEG_LAUNCH_CHECK("vsseg_dice_att_bwd");
+  return VSSEG_OK;
+}
+
+// d(loss)/d(att) of several levels in one launch (the coarse levels: a few thousand voxels each)
+struct DiceBwdLevelsK {
+  vsseg_dice_bwd_levels_desc d;
+  int first[VSSEG_DICE_MAX_LEVELS + 1];
+};
+__global__ __launch_bounds__(256) void dice_att_bwd_levels_kernel(const DiceBwdLevelsK k) {
+  const int b = blockIdx.y;
+  int l = 0;
+  while (l + 1 < k.d.nlevels && (int)blockIdx.x >= k.first[l + 1]) ++l;
+  const int nb = k.first[l + 1] - k.first[l], lb = (int)blockIdx.x - k.first[l];
+  const float gs = k.d.gscale ? *k.d.gscale : 1.f;
+  const float A = k.d.coef[l][b * 2] * gs, B = k.d.coef[l][b * 2 + 1] * gs;
+  const int64_t nvox = k.d.nvox[l];
+  const float* lb_ = k.d.label[l] + (int64_t)b * nvox;
+  float* o = k.d.datt[l] + (int64_t)b * nvox;
+  for (int64_t v = (int64_t)lb * 256 + threadIdx.x; v < nvox; v += (int64_t)nb * 256) o[v] = A * lb_[v] + B;
+}
+extern "C" int vsseg_dice_att_bwd_levels(const vsseg_dice_bwd_levels_desc* d, void* stream) {
+  VSSEG_CHECK(d && d->n >= 1 && d->nlevels >= 1 && d->nlevels <= VSSEG_DICE_MAX_LEVELS, "vsseg_dice_att_bwd_levels: bad arguments");
+  DiceBwdLevelsK k;
+  k.d = *d;
+  int nb = 0;
+  for (int l = 0; l < d->nlevels; ++l) {
+    VSSEG_CHECK(d->label[l] && d->datt[l] && d->coef[l] && d->nvox[l] >= 1, "vsseg_dice_att_bwd_levels: level %d is incomplete", l);
+    k.first[l] = nb;
+    nb += (int)std::min<int64_t>(256, (d->nvox[l] + 2047) / 2048);
+  }
+  for (int l = d->nlevels; l <= VSSEG_DICE_MAX_LEVELS; ++l) k.first[l] = nb;
+  hipLaunchKernelGGL(dice_att_bwd_levels_kernel, dim3(nb, d->n), dim3(256), 0, as_stream(stream), k);
+  VSSEG_LAUNCH_CHECK("vsseg_dice_att_bwd_levels");
   return VSSEG_OK;
 }
 

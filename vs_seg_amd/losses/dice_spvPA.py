@@ -52,9 +52,34 @@ def _dice_forward(logits, target, supervised, hardness, atts) -> _State:
     sums = torch.empty(B * 6 + max(nl, 1) * B * 3, dtype=torch.float64, device=dev)  # [pred | att levels], zeroed through the C ABI (no ATen fill kernels on the step)
     L.check(lib.vsseg_memset_zero(sums.data_ptr(), sums.numel() * 8, stream), "memset_zero")
     pred_sums, att_sums = sums[: B * 6], sums[B * 6 :]
-    L.check(lib.vsseg_dice_pred_sums(lg.data_ptr(), 2, lab.data_ptr(), B, nvox, int(hardness), pred_sums.data_ptr(), stream), "dice_pred_sums")
     labels: List[torch.Tensor] = []
-    if nl:
+    plan = _fused_plan(B, (X, Y, Z), [tuple(a.shape) for a in atts], lg, lab, [_c1(a) for a in atts]) if nl else None
+    if plan is not None:
+        # fewer passes and launches (csrc/loss.hip): a level whose next level pools (2, 2, 1) computes its sums, the logits' sums (finest level) and the next level's label
+        # in one pass; the remaining coarse levels are one launch.  Same sums (fixed-point, order-independent up to the fp32 partial sums of a thread).
+        g, gdims = lab, (X, Y, Z)
+        for level in range(plan):
+            ac = _c1(atts[nl - level - 1])
+            ndims = tuple(atts[nl - level - 2].shape[2:])
+            g2 = torch.empty((B, 1, *ndims), dtype=torch.float32, device=dev)
+            L.check(lib.vsseg_dice_level_sums(lg.data_ptr() if level == 0 else None, ac.data_ptr(), g.data_ptr(), B, L.i3(gdims), int(hardness), pred_sums.data_ptr(), att_sums.data_ptr() + 8 * level * B * 3,
+                                              g2.data_ptr(), stream), "dice_level_sums")
+            labels.append(g)
+            g, gdims = g2, ndims
+        td = L.DiceTailDesc()
+        td.n, td.nlevels, td.src, td.sdims, td.sums = B, nl - plan, g.data_ptr(), L.i3(gdims), att_sums.data_ptr() + 8 * plan * B * 3
+        for j, level in enumerate(range(plan, nl)):
+            a = atts[nl - level - 1]
+            adims = tuple(a.shape[2:])
+            assert all(x % y == 0 for x, y in zip(gdims, adims)), "attention-map pyramid must divide (ref dice_spvPA.py:273)"
+            gl = g if adims == gdims else torch.empty((B, 1, *adims), dtype=torch.float32, device=dev)
+            td.att[j], td.label[j] = _c1(a).data_ptr(), (None if gl is g else gl.data_ptr())
+            td.dims[j][0], td.dims[j][1], td.dims[j][2] = adims
+            labels.append(gl)
+        L.check(lib.vsseg_dice_tail_sums(td, stream), "dice_tail_sums")
+    else:
+        L.check(lib.vsseg_dice_pred_sums(lg.data_ptr(), 2, lab.data_ptr(), B, nvox, int(hardness), pred_sums.data_ptr(), stream), "dice_pred_sums")
+    if nl and plan is None:
         g, gdims = lab, (X, Y, Z)
         for level in range(nl):  # finest attention map first (ref :256-277)
             a = atts[nl - level - 1]
@@ -78,6 +103,23 @@ def _dice_forward(logits, target, supervised, hardness, atts) -> _State:
     st.att_shapes = [tuple(a.shape) for a in atts]
     st.loss = loss
     return st
+
+
+def _fused_plan(B, dims, att_shapes, lg, lab, acs) -> Optional[int]:
+    """How many of the finest levels take the fused pass of csrc/loss.hip (vsseg_dice_level_sums: the level is made of 2 x 2 x 4 blocks and the next one pools (2, 2, 1)),
+    the rest going to the one tail launch; None when not even the finest level qualifies or a level is too many for the tail (the generic sequence is used)."""
+    nl = len(att_shapes)
+    if tuple(att_shapes[nl - 1][2:]) != tuple(dims) or any(t.data_ptr() % 16 for t in (lg, lab, *acs)):
+        return None
+    k, g = 0, tuple(dims)
+    while k + 1 < nl:
+        nxt = tuple(att_shapes[nl - k - 2][2:])
+        if tuple(att_shapes[nl - k - 1][2:]) != g or g[0] % 2 or g[1] % 2 or g[2] % 4 or nxt != (g[0] // 2, g[1] // 2, g[2]) or (B * nxt[0] * nxt[1] * nxt[2]) % 4:
+            break
+        k, g = k + 1, nxt
+    if k == 0 or nl - k > L.DICE_MAX_LEVELS:
+        return None
+    return k
 
 
 def _att_backward(st: _State, level: int, gs_ptr, dst: torch.Tensor):
@@ -151,14 +193,25 @@ class Dice_spvPA(_Loss):
             B, X, Y, Z = st.shape
             stream = torch.cuda.current_stream().cuda_stream
             L.check(L.lib().vsseg_dice_pred_bwd_to(st.lg.data_ptr(), 2, st.lab.data_ptr(), B, X * Y * Z, st.hardness, st.coef.data_ptr(), None, glogits_dst, stream), "dice_pred_bwd_to")
-            written = []
+            written, coarse = [], []
             for level in range(st.nl):
                 i = st.nl - level - 1
                 buf = gatt_bufs[i]
                 if buf is None:
                     continue  # this map has no gradient path in the network
-                if buf.numel() != B * st.att_shapes[i][2] * st.att_shapes[i][3] * st.att_shapes[i][4] or buf.dtype != torch.float32:
+                nv = st.att_shapes[i][2] * st.att_shapes[i][3] * st.att_shapes[i][4]
+                if buf.numel() != B * nv or buf.dtype != torch.float32:
                     raise AssertionError(f"gradient buffer of attention map {i} does not match its shape {st.att_shapes[i]}")
-                _att_backward(st, level, None, buf)
+                if nv * B >= (1 << 22) or len(coarse) == L.DICE_MAX_LEVELS:
+                    _att_backward(st, level, None, buf)  # a level large enough to fill the GPU: its own launch
+                else:
+                    coarse.append((level, buf, nv))
                 written.append(i)
+            if coarse:  # the coarse levels: one launch
+                bd = L.DiceBwdLevelsDesc()
+                bd.n, bd.nlevels, bd.gscale = B, len(coarse), None
+                for j, (level, buf, nv) in enumerate(coarse):
+                    bd.label[j], bd.datt[j], bd.nvox[j] = st.labels[level].data_ptr(), buf.data_ptr(), nv
+                    bd.coef[j] = st.coef.data_ptr() + 4 * (B * 4 + level * B * 2)
+                L.check(L.lib().vsseg_dice_att_bwd_levels(bd, stream), "dice_att_bwd_levels")
         return st.loss, written

@@ -265,6 +265,7 @@ class UNet2d5_spvPA(nn.Module):
             plan.set_seed(plan.step_seed, stream)
             plan.generation += 1
             plan.zero_stats(stream)
+            plan.bwd_prepared = True  # the dropout seed is stored and the backward's statistics row is zero: the backward of THIS forward need not do either again
             torch.autograd.graph.increment_version(self._bflat)  # bn_finalize updates the running statistics through raw pointers
         else:
             # eval: packed weights and folded BatchNorm constants depend on parameters / buffers only — the 14 windows of a
@@ -345,8 +346,10 @@ class UNet2d5_spvPA(nn.Module):
                 keep.append(g)
                 gatt[spec.name] = g.data_ptr()
             plan.set_external_grads(L.Tensor(gl.data_ptr(), L.F32, self.out_channels, self.out_channels, n, X, Y, Z), gatt, stream)
-        plan.set_seed(plan.step_seed, stream)
-        plan.zero_stats(stream, 1)
+        if not getattr(plan, "bwd_prepared", False):  # a second backward of the same forward (retain_graph): the first one used the row up
+            plan.set_seed(plan.step_seed, stream)
+            plan.zero_stats(stream, 1)
+        plan.bwd_prepared = False
         lib, nbytes = eng.lib, self._gflat.numel() * 4
         accumulate = any(p.grad is not None for p in self._params.values())
         if accumulate:  # gradient accumulation (no zero_grad between two backwards): this backward's gradients are added to the previous sum
