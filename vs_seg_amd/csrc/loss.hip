@@ -50,9 +50,10 @@ __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double
   }
 }
 
-// Launch shape of the three reductions below: every workgroup ends with one fixed-point atomic per sum into the SAME 3-6 addresses of its sample, and
-// same-address atomics retire one after the other (~45 ns each: with the 1024 workgroups per sample of the first version the attention-map sums of the
-// 96x32x128 level took 49 us for 6 MB, profiles/r06_kernel_stats.txt).  ~512 workgroups of 512 threads in total (2 per CU, 16 waves per CU), 16-byte loads.
+// Launch shape of the three reductions below: every workgroup ends with one fixed-point atomic per sum, all of a launch's sums share one or two cache lines, and the
+// atomics of one LINE retire one after the other (~4.5 ns each: with the 1024 workgroups per sample of the first version — 12288 atomics into 96 bytes — the
+// attention-map sums of the 96x32x128 level took 49 us for 6 MB, profiles/r06_kernel_stats.txt).  ~512 workgroups of 512 threads in total (2 per CU, 16 waves per CU),
+// 16-byte loads.
 constexpr int DICE_THREADS = 512;
 static inline int dice_blocks(int64_t items, int n) {
   int64_t want = (items + DICE_THREADS * 2 - 1) / (DICE_THREADS * 2);
@@ -220,11 +221,14 @@ extern "C" int vsseg_dice_level_sums(const float* logits, const float* att, cons
 
 // The coarse levels of the supervision pyramid in ONE launch: level i's label = MaxPool3d(sdims / dims_i)(src) straight from the finest of them (a max-pool of a max-pool
 // is the max-pool over the product window) and its attention-map sums.  Level by level this was two launches of a few thousand voxels each, ~6 us apiece whatever their size.
+// 1024-thread workgroups: the sums of all levels and samples of this launch share three cache lines, and the fixed-point atomics of one LINE retire one after the other
+// (~4.5 ns each: 2112 workgroups of 256 threads spent 32 us on their 6336 atomics; a quarter of the workgroups, four times the threads)
+constexpr int DICE_TAIL_THREADS = 1024;
 struct DiceTailK {
   vsseg_dice_tail_desc d;
   int first[VSSEG_DICE_MAX_LEVELS + 1];  // workgroup range of level i: [first[i], first[i+1])
 };
-__global__ __launch_bounds__(256) void dice_tail_kernel(const DiceTailK k, unsigned* fxflag) {
+__global__ __launch_bounds__(DICE_TAIL_THREADS) void dice_tail_kernel(const DiceTailK k, unsigned* fxflag) {
   const int b = blockIdx.y;
   int l = 0;
   while (l + 1 < k.d.nlevels && (int)blockIdx.x >= k.first[l + 1]) ++l;
@@ -233,30 +237,50 @@ __global__ __launch_bounds__(256) void dice_tail_kernel(const DiceTailK k, unsig
   const int sx = k.d.sdims[0], sy = k.d.sdims[1], sz = k.d.sdims[2];
   const int rx = sx / dx, ry = sy / dy, rz = sz / dz;
   const int nvox = dx * dy * dz;
-  const float* src = k.d.src + (int64_t)b * sx * sy * sz;
-  const float* att = k.d.att[l] + (int64_t)b * nvox;
-  float* out = k.d.label[l] ? k.d.label[l] + (int64_t)b * nvox : nullptr;
+  const float* __restrict__ src = k.d.src + (int64_t)b * sx * sy * sz;
+  const float* __restrict__ att = k.d.att[l] + (int64_t)b * nvox;
+  float* __restrict__ out = k.d.label[l] ? k.d.label[l] + (int64_t)b * nvox : nullptr;
   double acc[3] = {0, 0, 0};
   // T lanes (a power of two <= 64) share the pooling window of one voxel — the coarsest level of the benchmark network pools 8 x 8 x 8 = 512 values per voxel for 768 voxels:
   // one thread per voxel walked them one dependent load after the other (170 us for the launch) — and meet in a butterfly of lane exchanges (max: exact in any order)
   const int win = rx * ry * rz;
   int T = 1;
   while (T < 64 && T * 2 <= win) T *= 2;
-  const int vpb = 256 / T, sub = (int)threadIdx.x % T, slot = (int)threadIdx.x / T;
-  for (int base = lb * vpb; base < nvox; base += nb * vpb) {  // (block-uniform trip count: every lane takes part in the exchanges)
-    const int i = base + slot;
-    const bool live = i < nvox;
-    const int z = live ? i % dz : 0, r = live ? i / dz : 0, y = r % dy, x = r / dy;
-    float m = -INFINITY;
-    for (int w = sub; w < win; w += T) {
-      const int e = w % rz, ac = w / rz, c = ac % ry, a = ac / ry;
-      m = fmaxf(m, src[((int64_t)(x * rx + a) * sy + y * ry + c) * sz + z * rz + e]);
+  const int vpb = DICE_TAIL_THREADS / T, sub = (int)threadIdx.x % T, slot = (int)threadIdx.x / T;
+  const float idz = 1.0f / (float)dz, idy = 1.0f / (float)dy, irz = 1.0f / (float)rz, iry = 1.0f / (float)ry;
+  if (win == 1 && (nvox & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(att) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    // the level IS the source level: dice_att_sums_kernel's loop (16-byte loads, no coordinates)
+    for (int i = lb * DICE_TAIL_THREADS + (int)threadIdx.x; i < (nvox >> 2); i += nb * DICE_TAIL_THREADS) {
+      const float4 g = reinterpret_cast<const float4*>(src)[i], p = reinterpret_cast<const float4*>(att)[i];
+      if (out) reinterpret_cast<float4*>(out)[i] = g;
+      acc[0] += (double)((g.x * p.x + g.y * p.y) + (g.z * p.z + g.w * p.w));
+      acc[1] += (double)((g.x + g.y) + (g.z + g.w));
+      acc[2] += (double)((p.x + p.y) + (p.z + p.w));
     }
-    for (int off = T >> 1; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if (live && sub == 0) {
-      if (out) out[i] = m;
-      const float p = att[i];
-      acc[0] += (double)(m * p); acc[1] += (double)m; acc[2] += (double)p;
+  } else
+  for (int base = lb * vpb * 4; base < nvox; base += nb * vpb * 4) {  // (block-uniform trip count: every lane takes part in the exchanges)
+    // four voxels per lane group and round: their loads are issued together (one voxel per round was a chain of dependent ~1 us loads: 8 rounds, 30 us)
+    int iv[4];
+    float m[4], p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = base + u * vpb + slot;
+      iv[u] = i < nvox ? i : -1;
+      const int ic = i < nvox ? i : 0, r = vsseg_fdiv(ic, dz, idz), z = ic - r * dz, x = vsseg_fdiv(r, dy, idy), y = r - x * dy;  // (values < 2^22: common.h)
+      m[u] = -INFINITY;
+      for (int w = sub; w < win; w += T) {
+        const int ac = vsseg_fdiv(w, rz, irz), e = w - ac * rz, a = vsseg_fdiv(ac, ry, iry), c = ac - a * ry;
+        m[u] = fmaxf(m[u], src[((int64_t)(x * rx + a) * sy + y * ry + c) * sz + z * rz + e]);
+      }
+      p[u] = att[ic];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      for (int off = T >> 1; off > 0; off >>= 1) m[u] = fmaxf(m[u], __shfl_xor(m[u], off));
+      if (iv[u] >= 0 && sub == 0) {
+        if (out) out[iv[u]] = m[u];
+        acc[0] += (double)(m[u] * p[u]); acc[1] += (double)m[u]; acc[2] += (double)p[u];
+      }
     }
   }
   block_reduce_add(acc, 3, k.d.sums + ((int64_t)l * k.d.n + b) * 3, VSSEG_FX_DICE, fxflag);
@@ -275,16 +299,16 @@ extern "C" int vsseg_dice_tail_sums(const vsseg_dice_tail_desc* d, void* stream)
     }
     VSSEG_CHECK(d->label[l] || same, "vsseg_dice_tail_sums: level %d pools but has no label buffer", l);
     const int64_t nvox = (int64_t)d->dims[l][0] * d->dims[l][1] * d->dims[l][2];
-    VSSEG_CHECK(nvox < (1ll << 30), "vsseg_dice_tail_sums: level %d is too large for the tail launch", l);
+    VSSEG_CHECK(nvox < (1ll << 22), "vsseg_dice_tail_sums: level %d is too large for the tail launch (>= 2^22 voxels per sample)", l);
     k.first[l] = nb;
     int64_t win = 1, T = 1;
     for (int a = 0; a < 3; ++a) win *= d->sdims[a] / d->dims[l][a];
     while (T < 64 && T * 2 <= win) T *= 2;
-    nb += (int)std::min<int64_t>(64, (nvox * T + 1023) / 1024);  // T lanes per voxel (dice_tail_kernel)
+    nb += (int)std::min<int64_t>(48, win == 1 ? (nvox + 8191) / 8192 : (nvox * T + 2047) / 2048);  // T lanes per voxel (dice_tail_kernel)
   }
   for (int l = d->nlevels; l <= VSSEG_DICE_MAX_LEVELS; ++l) k.first[l] = nb;
   VSSEG_FX_FLAG(fxflag, "vsseg_dice_tail_sums");
-  hipLaunchKernelGGL(dice_tail_kernel, dim3(nb, d->n), dim3(256), 0, as_stream(stream), k, fxflag);
+  hipLaunchKernelGGL(dice_tail_kernel, dim3(nb, d->n), dim3(DICE_TAIL_THREADS), 0, as_stream(stream), k, fxflag);
   VSSEG_LAUNCH_CHECK("vsseg_dice_tail_sums");
   return VSSEG_OK;
 }

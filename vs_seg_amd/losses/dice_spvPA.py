@@ -119,6 +119,8 @@ def _fused_plan(B, dims, att_shapes, lg, lab, acs) -> Optional[int]:
         k, g = k + 1, nxt
     if k == 0 or nl - k > L.DICE_MAX_LEVELS:
         return None
+    if any(s[2] * s[3] * s[4] >= (1 << 22) for s in att_shapes[: nl - k]):  # the tail launch takes levels of < 2^22 voxels per sample
+        return None
     return k
 
 
