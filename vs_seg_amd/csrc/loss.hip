@@ -51,7 +51,7 @@ __device__ __forceinline__ void block_reduce_add(double* vals, int nvals, double
 }
 
 // Launch shape of the three reductions below: every workgroup ends with one fixed-point atomic per sum, all of a launch's sums share one or two cache lines, and the
-// atomics of one LINE retire one after the other (~4.5 ns each: with the 1024 workgroups per sample of the first version — 12288 atomics into 96 bytes — the
+// atomics of one LINE retire one after the other (~4 ns each: with the 1024 workgroups per sample of the first version — 12288 atomics into 96 bytes — the
 // attention-map sums of the 96x32x128 level took 49 us for 6 MB, profiles/r06_kernel_stats.txt).  ~512 workgroups of 512 threads in total (2 per CU, 16 waves per CU),
 // 16-byte loads.
 constexpr int DICE_THREADS = 512;
@@ -221,8 +221,8 @@ extern "C" int vsseg_dice_level_sums(const float* logits, const float* att, cons
 
 // The coarse levels of the supervision pyramid in ONE launch: level i's label = MaxPool3d(sdims / dims_i)(src) straight from the finest of them (a max-pool of a max-pool
 // is the max-pool over the product window) and its attention-map sums.  Level by level this was two launches of a few thousand voxels each, ~6 us apiece whatever their size.
-// 1024-thread workgroups: the sums of all levels and samples of this launch share three cache lines, and the fixed-point atomics of one LINE retire one after the other
-// (~4.5 ns each: 2112 workgroups of 256 threads spent 32 us on their 6336 atomics; a quarter of the workgroups, four times the threads)
+// 1024-thread workgroups: the sums of all levels and samples of this launch share three cache lines and the fixed-point atomics of one LINE retire one after the other:
+// a quarter of the workgroups of a 256-thread launch, four times the threads (measured the same 32 us either way: the launch is bound by its dependent loads, not by these)
 constexpr int DICE_TAIL_THREADS = 1024;
 struct DiceTailK {
   vsseg_dice_tail_desc d;
