@@ -69,6 +69,34 @@ def test_fused_loss_train_step_is_bit_identical_to_the_autograd_route(dtype, sup
     assert float(res[0][1].abs().max()) > 0
 
 
+def test_late_weight_gradient_launches_change_the_order_and_nothing_else(monkeypatch):
+    """The schedule of DESIGN 3.18 — the last weight-gradient launch (and the first unit's residual-convolution one) moved from the side stream to the end of the main
+    stream's list, with the main stream's slab scratch — against the list order (VSSEG_LATE_WGRAD=0, VSSEG_EARLY_RES_WGRAD=0) and the early variant: two bf16 steps with
+    dropout, losses / gradients / parameters / BatchNorm buffers bit for bit; and the moved launches are where they should be."""
+    from vs_seg_amd import parallel as DP
+
+    x, y = _batch(0)
+    res = []
+    for late, early in (("0", "0"), ("1", "late"), ("2", "1")):
+        monkeypatch.setenv("VSSEG_LATE_WGRAD", late)
+        monkeypatch.setenv("VSSEG_EARLY_RES_WGRAD", early)
+        m = _model_dt("bf16", 0.1)
+        trainer = DP.DataParallelTrainer(m.train(), V.Dice_spvPA(to_onehot_y=True, softmax=True), V.Adam(m.parameters(), lr=1e-3, weight_decay=1e-7))
+        losses = [float(trainer.step(x, y)) for _ in range(2)]
+        flat, gflat = m.flat_parameters()
+        torch.cuda.synchronize()
+        plan = next(p for k, p in m._engine.plans.items() if k[2])
+        moved = [rec for rec in plan.bwd if len(rec) > 2 and rec[2].get("late")]
+        assert len(moved) == {"0": 0, "1": 2, "2": 2}[late]
+        if moved:
+            assert plan.bwd[-len(moved):] == moved and not any(rec[2].get("side") for rec in moved)
+        res.append((losses, gflat.clone(), flat.clone(), m._bflat.clone()))
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        for a, b in zip(res[0][1:], other[1:]):
+            assert torch.equal(a, b)
+
+
 def _batch(rank):
     return synth_input(SEED + 10 * rank, SHAPE).cuda(), synth_label(SEED + 10 * rank, SHAPE).cuda()
 

@@ -983,7 +983,7 @@ class Plan:
                 x1 = self._xdesc(x, True)  # the compact one-channel copy of the network input
                 assert not bias_grad, "the 1 -> C narrow weight gradient does not reduce a bias gradient (those convolutions sit in front of a BatchNorm)"
                 B.append([lib.vsseg_wgrad_narrow, [dy, x1.ptr, k3, 1, self._gp(Lr.wkey), k3 * k3, None, scr.data_ptr(), scr.numel()],
-                          dict(name="wgrad_narrow", kind="hbm", side=True, flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
+                          dict(name="wgrad_narrow", kind="hbm", side=True, late_ok=(k3 == 1), flops=0.0, bytes=float(self.eng.es) * self._vox(Lr.level) * (Lr.cout + 1), tag=f"{Lr.prefix[-40:]} 1->{Lr.cout} k={Lr.kernel}")])
                 return True
             if Lr.cout == 1 and Lr.cin in (8, 16, 32, 64) and dy_compact is not None and x.parts is None and x.base is None:
                 # (the bias gradient of the C -> 1 convolution = sum of its one-channel dY rides in the same slabs: fixed summation order)
@@ -992,7 +992,7 @@ class Plan:
                 return True
             return False
 
-        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None, gate=None):
+        def conv_backward(Lr: Layer, x: TensorSpec, dy: L.Tensor, bias_grad: bool, relumask: Optional[TensorSpec] = None, dy_compact: Optional[L.Tensor] = None, gate=None, own_dy: bool = False):
             cp = self.cplans[Lr.prefix]
             wg = cp.wgrad
             if narrow_wgrad(Lr, x, dy, dy_compact, bias_grad):
@@ -1116,7 +1116,7 @@ class Plan:
             d.tile = live_tile
             set_blocks(wpc)
             nq = self.n * wg.q[0] * wg.q[1] * wg.q[2]
-            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} " + (f"compute chunks/wg={d.hgroup}" if d.march == 2 else f"march tile={tuple(d.tile)}" if d.march else f"tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}") + tuned,
+            B.append([lib.vsseg_wgrad, [C.byref(d)], dict(own_dy=own_dy, tag=f"{Lr.prefix[-40:]} q={wg.q} taps={len(wg.taps)} cin={Lr.cin} cout={Lr.cout} " + (f"compute chunks/wg={d.hgroup}" if d.march == 2 else f"march tile={tuple(d.tile)}" if d.march else f"tile={wg.tile} blocks={d.persistent_blocks}x{hch} sb={d.single_buffer} hg={d.hgroup} lds={wg.lds}") + tuned,
                                                           name=(f"cwgrad<bf16,{wg.ntp}>" if d.march == 2 else f"mwgrad<bf16,{wg.ntp}>" if d.march else f"wgrad<{'bf16' if self.eng.es == 2 else 'f32'},{wg.ntp}>"), kind="mfma", side=True, flops=2.0 * nq * len(wg.taps) * Lr.cin * Lr.cout,
                                                           bytes=float(self.eng.es) * (nq * (Lr.cout if not Lr.transposed else Lr.cin) + self._vox(Lr.level if not Lr.transposed else Lr.out_level) * (Lr.cin if not Lr.transposed else Lr.cout)))])
             if bias_grad and Lr.transposed:  # (does not occur in this network: transposed convolutions are followed by BatchNorm)
@@ -1243,7 +1243,7 @@ class Plan:
         def fused_narrow(op: ConvBnAct, yd: L.Tensor, dA: L.Tensor) -> bool:
             """The 1 -> C 3x3x1 block on the network input (no data gradient): vsseg_bn_act_bwd_apply is applied on load by the narrow weight-gradient reduction."""
             Lr, pre = op.layer, op.layer.prefix
-            if (eng.fused_bwd == "0" or eng.es != 2 or not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cin != 1 or Lr.cout not in (8, 16, 32, 64)
+            if (eng.fused_bwd == "0" or not eng.fused_narrow or eng.es != 2 or not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cin != 1 or Lr.cout not in (8, 16, 32, 64)
                     or op.x.root.name != prog.input.name or self.lv[Lr.level][1] % 4 or dA.ptr2 or dA.c != Lr.cout or (p_drop > 0.0 and keep_ptr(Lr) is None)):
                 return False
             x1 = self._xdesc(op.x, True)  # the compact one-channel copy of the network input
@@ -1254,6 +1254,7 @@ class Plan:
             return True
 
         absorbed_res = set()  # residual convolutions whose data / weight gradient a fused launch produces
+        early_res = set()  # residual convolutions whose backward was issued with the block their output is added to
         gate_fuse: Dict[str, tuple] = {}  # relu-conv prefix -> (d(gated) descriptor, attention map pointer) of the gate fused into its data gradient
         relu_out = {op.out.name: op.out for op in ops if isinstance(op, ConvPlain) and op.act == "relu"}
         producer = {op.out.name: op for op in ops if isinstance(op, ConvPlain)}  # residual convs / attention convs by output tensor
@@ -1272,6 +1273,14 @@ class Plan:
                     folded_bias.add(producer[op.res.name].layer.prefix)
                 B.append([lib.vsseg_bn_act_bwd_finalize, [sptr(1, pre), cpad[pre], aptr(pre), Lr.cout, float(self._vox(Lr.out_level)), self._gp(pre + ".norm.weight"), self._gp(pre + ".norm.bias"),
                                                           self._gp(pre + ".act.weight"), vptr(4, pre), vptr(5, pre), dres_bias]])
+                if op.res is not None and op.res.name in producer and eng.early_res_wgrad == "1":
+                    # The 1x1x1 residual convolution of the network input (first ResidualUnit): its weight gradient needs d(out) of the unit only — which exists from here on — but in list
+                    # order it came LAST, behind the unit's first block, where nothing else is left to run beside it (0.13 ms at the end of the step with the main stream idle,
+                    # profiles/r06_loss_phase.txt's run).  Issued here it shares the GPU with the unit's own backward instead.
+                    pr = producer[op.res.name]
+                    if pr.layer.cin == 1 and pr.x.root.name == prog.input.name and pr.layer.prefix not in self.merged and pr.act != "sigmoid":
+                        conv_backward(pr.layer, pr.x, dA, bias_grad=pr.layer.prefix not in folded_bias)
+                        early_res.add(pr.layer.prefix)
                 fused = (op.res is None or op.res.name.endswith(":res")) and (fused_backward(op, yd, dA) or fused_narrow(op, yd, dA))  # (an identity residual re-uses dA's buffer below: keep those unfused)
                 if not fused:
                     dyd = self._tdesc(self._raw("dy:" + pre, Lr.out_level, Lr.cout), Lr.out_level)
@@ -1290,7 +1299,7 @@ class Plan:
                     else:
                         B.append([lib.vsseg_copy_cast, [dA, gdesc(op.res)], self._ew_meta("grad_add/copy", Lr.out_level, 2 * Lr.cout)])
                 if not fused:
-                    conv_backward(Lr, op.x, dyd, bias_grad=False)  # a bias in front of a training-mode BatchNorm has zero gradient
+                    conv_backward(Lr, op.x, dyd, bias_grad=False, own_dy=True)  # a bias in front of a training-mode BatchNorm has zero gradient
             elif isinstance(op, ConvPlain):
                 Lr = op.layer
                 if Lr.prefix in self.merged:  # gradients of a merged residual conv = centre-tap slice / bias gradient of the absorbing conv
@@ -1298,6 +1307,8 @@ class Plan:
                     kx, ky, kz = big.kernel
                     centre = ((kx // 2) * ky + ky // 2) * kz + kz // 2
                     B.append([lib.vsseg_merge_residual_grads, [self._gp(big.wkey), self._gp(big.bkey), self._gp(Lr.wkey), self._gp(Lr.bkey), Lr.cout, Lr.cin, kx * ky * kz, centre], dict(name="vsseg_merge_residual_grads", kind="hbm", flops=0.0, bytes=0.0, side=True)])
+                    continue
+                if Lr.prefix in early_res:  # issued with the unit's last block (above)
                     continue
                 if Lr.prefix in absorbed_res:  # data + weight gradient came out of the fused launch of the unit's 3x3x1 block (csrc/mbwd.hip, RES); bias gradient: folded_bias
                     continue
@@ -1333,6 +1344,29 @@ class Plan:
                 gbuf = self.gatt_buf[op.att.name] = torch.zeros((self.n, *self.lv[op.att.level]), dtype=torch.float32, device=dev)  # the loss' gradient of this attention map is staged here
                 B.append([lib.vsseg_att_apply_bwd, [self._desc(op.x), self._alloc(op.att, self.bufs).data_ptr(), gout, gbuf.data_ptr(), gdesc(op.x), acc, self._dpre_desc(dpre, op.att.level) if dpre is not None else L.Tensor(), None, dpre1],
                           self._ew_meta("att_apply_bwd", op.x.level, (2 if acc == 2 else (4 if acc else 3)) * op.x.c + (8 if dpre is not None else 1) + 4)])
+        if eng.late_wgrad > 0:
+            # The LAST weight-gradient launches of the list leave the side stream for the END of the main stream's list: the step ends with the first block's chain
+            # (statistics pass -> finalize -> narrow weight gradient, ~0.7 ms) in which the main stream has nothing left to issue and the side stream runs one VALU-bound
+            # launch; weight gradients that would have shared the GPU with the main stream's last convolutions run beside that launch instead.  Only launches whose operands
+            # nothing writes again (P = the block's own dy buffer, H = a forward activation); their slabs go to the main stream's scratch (the fused launches are done by then).
+            cands = [i for i, rec in enumerate(B) if len(rec) > 2 and rec[2].get("side") and rec[2].get("own_dy") and rec[0] is lib.vsseg_wgrad]
+            late = set(cands[-eng.late_wgrad:])
+            fs = eng.fused_scratch()
+            moved = []
+            for i in sorted(late):
+                rec = B[i]
+                d = rec[1][0]._obj
+                d.scratch, d.scratch_elems = fs.data_ptr(), fs.numel()
+                rec[2] = dict(rec[2], side=False, late=True)
+                moved.append(rec)
+            if eng.early_res_wgrad == "late":  # + the first unit's 1x1x1 residual-convolution weight gradient (the last launch of the side stream's list)
+                for i, rec in enumerate(B):
+                    if len(rec) > 2 and rec[2].get("late_ok") and rec[0] is lib.vsseg_wgrad_narrow and i not in late:
+                        rec[1][7], rec[1][8] = fs.data_ptr(), fs.numel()
+                        rec[2] = dict(rec[2], side=False, late=True)
+                        moved.append(rec)
+                        late.add(i)
+            B[:] = [r for j, r in enumerate(B) if j not in late] + moved
         self._finish_pack()
 
     def _index_slots(self):
@@ -1500,6 +1534,9 @@ class Engine:
         self.keepmask = True  # dropout keep-masks stored by the forward (1 bit per element) instead of regenerated twice in backward
         self.compute_wgrad = os.environ.get("VSSEG_COMPUTE_WGRAD", "1") != "0"  # A/B switch of round 6: the compute weight-gradient kernel (csrc/cwgrad.hip) as a candidate for the 3x3x3 layers of levels 2-3
         self.wide_dpre = os.environ.get("VSSEG_WIDE_DPRE", "1") != "0"  # A/B switch of round 6: 16-channel rows for d(pre-sigmoid) of the 3x3x3 sigmoid convolutions (compute-kernel data gradient)
+        self.early_res_wgrad = os.environ.get("VSSEG_EARLY_RES_WGRAD", "late")  # round 6, where the first unit's 1x1x1 residual-convolution weight gradient runs: "late" = with the late launches (next line), "1" = with the unit's last block, "0" = last on the side stream
+        self.late_wgrad = int(os.environ.get("VSSEG_LATE_WGRAD", "1"))  # the last N tile / marching / compute weight-gradient launches run at the end of the main stream's list (see the end of the backward lowering)
+        self.fused_narrow = os.environ.get("VSSEG_FUSED_NARROW", "1") != "0"  # A/B switch: BatchNorm backward applied on load by the first block's narrow weight-gradient reduction (vsseg_wgrad_narrow_bn)
         self.transition = os.environ.get("VSSEG_TRANSITION", "1") != "0"  # A/B switch of round 6: the level 2 <-> 3 transition kernel (csrc/tconv.hip, depth -8)
         self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
