@@ -1243,7 +1243,7 @@ class Plan:
         def fused_narrow(op: ConvBnAct, yd: L.Tensor, dA: L.Tensor) -> bool:
             """The 1 -> C 3x3x1 block on the network input (no data gradient): vsseg_bn_act_bwd_apply is applied on load by the narrow weight-gradient reduction."""
             Lr, pre = op.layer, op.layer.prefix
-            if (eng.fused_bwd == "0" or not eng.fused_narrow or eng.es != 2 or not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cin != 1 or Lr.cout not in (8, 16, 32, 64)
+            if (eng.fused_bwd == "0" or eng.es != 2 or not eng.narrow_wgrad or Lr.transposed or tuple(Lr.stride) != (1, 1, 1) or Lr.kernel != (3, 3, 1) or Lr.cin != 1 or Lr.cout not in (8, 16, 32, 64)
                     or op.x.root.name != prog.input.name or self.lv[Lr.level][1] % 4 or dA.ptr2 or dA.c != Lr.cout or (p_drop > 0.0 and keep_ptr(Lr) is None)):
                 return False
             x1 = self._xdesc(op.x, True)  # the compact one-channel copy of the network input
@@ -1536,7 +1536,6 @@ class Engine:
         self.wide_dpre = os.environ.get("VSSEG_WIDE_DPRE", "1") != "0"  # A/B switch of round 6: 16-channel rows for d(pre-sigmoid) of the 3x3x3 sigmoid convolutions (compute-kernel data gradient)
         self.early_res_wgrad = os.environ.get("VSSEG_EARLY_RES_WGRAD", "late")  # round 6, where the first unit's 1x1x1 residual-convolution weight gradient runs: "late" = with the late launches (next line), "1" = with the unit's last block, "0" = last on the side stream
         self.late_wgrad = int(os.environ.get("VSSEG_LATE_WGRAD", "1"))  # the last N tile / marching / compute weight-gradient launches run at the end of the main stream's list (see the end of the backward lowering)
-        self.fused_narrow = os.environ.get("VSSEG_FUSED_NARROW", "1") != "0"  # A/B switch: BatchNorm backward applied on load by the first block's narrow weight-gradient reduction (vsseg_wgrad_narrow_bn)
         self.transition = os.environ.get("VSSEG_TRANSITION", "1") != "0"  # A/B switch of round 6: the level 2 <-> 3 transition kernel (csrc/tconv.hip, depth -8)
         self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
