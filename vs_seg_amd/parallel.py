@@ -251,7 +251,7 @@ class DataParallelTrainer:
         self.opt.zero_grad()
         # logits and attention maps never leave this function: the loss reads them and its backward has run before the next forward overwrites the plan's buffers, so the
         # forward may hand out views of them instead of clones (7 device copies, 0.15 ms of a 28 ms step at the benchmark shape)
-        if self.fused_loss and self.model.training:
+        if getattr(self, "fused_loss", False) and self.model.training:
             # the loss writes its gradients where the network's backward reads them, in the backward's layout and dtype: no fp32 gradient tensors, no copies of the six
             # attention-map gradients, no cast pass over the gradient of the logits (7 launches and 0.7 GB of traffic per step at the benchmark shape)
             outputs, landing = self.model.train_forward_landing(inputs)
