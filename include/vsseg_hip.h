@@ -215,7 +215,16 @@ int vsseg_conv_chain(const vsseg_chain_desc* d, void* stream);
 int vsseg_conv_chain_lds_bytes(const vsseg_chain_desc* d); /* LDS bytes of the launch, or VSSEG_EINVAL (vsseg_last_error: why the descriptor is outside the kernel's domain) */
 
 const char* vsseg_last_error(void);
-int vsseg_version(void); /* 7: + vsseg_dice_pred_bwd_to, vsseg_dice_level_sums, vsseg_dice_tail_sums, vsseg_dice_att_bwd_levels; 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
+/* Forking a second stream without a marker packet on the first (ABI version 7).  Between vsseg_fork_arm(ev) and vsseg_fork_disarm() every kernel this library launches on the
+   calling thread carries `ev` as the stop event of its own dispatch (a later kernel replaces an earlier one); vsseg_fork_disarm returns how many kernels carried it.
+   vsseg_stream_wait_event(stream, ev) = hipStreamWaitEvent.  The training backward forks its weight-gradient stream this way: a hipEventRecord on the main stream delays the main
+   stream's next kernel by ~5 us, 42 times per step. */
+void* vsseg_fork_event_create(void);
+int vsseg_fork_event_destroy(void* ev);
+int vsseg_fork_arm(void* ev);
+int vsseg_fork_disarm(void);
+int vsseg_stream_wait_event(void* stream, void* ev);
+int vsseg_version(void); /* 7: + vsseg_dice_pred_bwd_to, vsseg_dice_level_sums, vsseg_dice_tail_sums, vsseg_dice_att_bwd_levels, vsseg_fork_*, vsseg_stream_wait_event; 6: + launch plans with depth -8 (transition kernel) and -9 (gathering marching kernel); 5: vsseg_wgrad march = 2 (compute weight-gradient kernel), + vsseg_conv_to1, vsseg_conv_chain_desc without h_out (the training variant measured no gain and was deleted); 4: + vsseg_conv_chain; 3: the BatchNorm-block-on-load fields (in_bn_*, keep_*, x_bn_*: round-4 experiment, measured a loss, deleted) left the descriptors, depth -7 plans;
                             * 2: fixed-point accumulators documented + vsseg_fx_status; 1: the buffers below were described as plain doubles */
 
 /* ---- Accumulator buffers are 64-bit FIXED-POINT integers, not doubles ------------------------------------------------------------------

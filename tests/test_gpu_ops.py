@@ -2073,6 +2073,33 @@ def test_logits_gradient_staging_copy_fast_path_equals_the_generic_copy():
     assert float(a[..., 2:].float().min()) == 7.0 and float(b[..., 2:].float().abs().max()) == 0.0
 
 
+def test_fork_event_bound_to_a_kernel_orders_a_second_stream():
+    """vsseg_fork_arm / vsseg_fork_disarm / vsseg_stream_wait_event: the kernels a library call launches while an event is armed carry it as their stop event; a second stream
+    that waits for it sees what they wrote (a 1 GB cast takes ~0.4 ms: a consumer that did not wait would copy the zeros in front of it); a call that launches no kernel reports 0."""
+    lib = L.lib()
+    n, dims = 4, (256, 128, 128)
+    src = torch.randn(n, *dims, 16, device="cuda")
+    mid = torch.zeros(n, *dims, 16, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros_like(mid)
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = lib.vsseg_fork_event_create()
+    assert ev
+    torch.cuda.synchronize()
+    L.check(lib.vsseg_fork_arm(ev))
+    L.check(lib.vsseg_memset_zero(out.data_ptr(), 64, a.cuda_stream))
+    assert lib.vsseg_fork_disarm() == 0  # a memset is not a kernel of the library
+    L.check(lib.vsseg_fork_arm(ev))
+    L.check(lib.vsseg_copy_cast(L.Tensor(src.data_ptr(), L.F32, 16, 16, n, *dims), L.Tensor(mid.data_ptr(), L.BF16, 16, 16, n, *dims), a.cuda_stream))
+    assert lib.vsseg_fork_disarm() == 1
+    assert lib.vsseg_fork_disarm() == 0  # nothing armed
+    L.check(lib.vsseg_stream_wait_event(b.cuda_stream, ev))
+    L.check(lib.vsseg_copy_cast(L.Tensor(mid.data_ptr(), L.BF16, 16, 16, n, *dims), L.Tensor(out.data_ptr(), L.BF16, 16, 16, n, *dims), b.cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out, src.to(torch.bfloat16))
+    assert lib.vsseg_fork_arm(None) == L.EINVAL
+    L.check(lib.vsseg_fork_event_destroy(ev))
+
+
 def test_two_part_tensors_are_rejected_where_unsupported():
     lib = L.lib()
     a = torch.zeros(1, 4, 4, 4, 16, device="cuda")

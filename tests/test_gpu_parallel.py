@@ -77,15 +77,17 @@ def test_late_weight_gradient_launches_change_the_order_and_nothing_else(monkeyp
 
     x, y = _batch(0)
     res = []
-    for late, early in (("0", "0"), ("1", "late"), ("2", "1")):
+    for late, early, bound in (("0", "0", "0"), ("1", "late", "1"), ("2", "1", "1")):  # (bound: the side stream forks on events bound to the main-stream kernels, or on event records)
         monkeypatch.setenv("VSSEG_LATE_WGRAD", late)
         monkeypatch.setenv("VSSEG_EARLY_RES_WGRAD", early)
+        monkeypatch.setenv("VSSEG_BOUND_FORKS", bound)
         m = _model_dt("bf16", 0.1)
         trainer = DP.DataParallelTrainer(m.train(), V.Dice_spvPA(to_onehot_y=True, softmax=True), V.Adam(m.parameters(), lr=1e-3, weight_decay=1e-7))
         losses = [float(trainer.step(x, y)) for _ in range(2)]
         flat, gflat = m.flat_parameters()
         torch.cuda.synchronize()
         plan = next(p for k, p in m._engine.plans.items() if k[2])
+        assert (len(plan._fork_events) > 20) == (bound == "1")
         moved = [rec for rec in plan.bwd if len(rec) > 2 and rec[2].get("late")]
         assert len(moved) == {"0": 0, "1": 2, "2": 2}[late]
         if moved:

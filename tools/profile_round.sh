@@ -38,6 +38,7 @@ rm -rf $OUT/ktd
 python bench.py --steps 2 --warmup 1 --swi-volumes 0 --fp32-steps 0 --no-cpu-baseline --no-parity --swi-cases 242 2> /dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['sharded_cases']))" > $OUT/sharded_242.json
 # what a dependent stage boundary costs (launch / hipGraph node / in-kernel grid barrier) and the deep-level kernel against the other plans, launch by launch
 (tools/probes/chain_probe > $OUT/chain_probe.txt 2>&1 || true)
+(tools/probes/fork_probe > $OUT/fork_probe.txt 2>&1 || true)  # what a fork of the side stream costs the main one: event record against an event bound to the kernel
 (timeout 600 python tools/bench_dconv.py 4 > $OUT/dconv_bench.txt 2>&1 || true)
 (timeout 300 python tools/bench_chain.py 1 2>&1 | grep -v amdgpu.ids > $OUT/chain_bench.txt || true)
 # round 6: the compute weight-gradient kernel against the tile kernel on the six 3x3x3 stride-1 layers of levels 2-3, and the narrow-output convolution

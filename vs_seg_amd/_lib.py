@@ -202,7 +202,7 @@ SYMBOLS = [
     "vsseg_last_error", "vsseg_version", "vsseg_fx_status", "vsseg_memset_zero", "vsseg_copy_bytes", "vsseg_store_u64", "vsseg_crop_flip", "vsseg_normalize_intensity", "vsseg_igemm", "vsseg_igemm_lds_bytes", "vsseg_conv_chain", "vsseg_conv_chain_lds_bytes", "vsseg_conv_to1", "vsseg_wgrad", "vsseg_conv_bwd_fused", "vsseg_wgrad_narrow", "vsseg_wgrad_narrow_bn", "vsseg_gather_cast", "vsseg_merge_residual_grads", "vsseg_stage_input",
     "vsseg_bn_finalize", "vsseg_bn_fold_eval", "vsseg_bn_act_fwd", "vsseg_bn_act_fwd_res1", "vsseg_bn_act_bwd_reduce", "vsseg_bn_act_bwd_finalize", "vsseg_bn_act_bwd_apply",
     "vsseg_dropout_mask", "vsseg_att_apply_fwd", "vsseg_att_apply_bwd", "vsseg_channel_sum", "vsseg_add_inplace", "vsseg_copy_cast",
-    "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_pred_bwd_to", "vsseg_dice_att_bwd", "vsseg_dice_level_sums", "vsseg_dice_tail_sums", "vsseg_dice_att_bwd_levels",
+    "vsseg_maxpool_label", "vsseg_dice_pred_sums", "vsseg_dice_att_sums", "vsseg_dice_finalize", "vsseg_dice_pred_bwd", "vsseg_dice_pred_bwd_to", "vsseg_dice_att_bwd", "vsseg_dice_level_sums", "vsseg_dice_tail_sums", "vsseg_dice_att_bwd_levels", "vsseg_fork_event_create", "vsseg_fork_event_destroy", "vsseg_fork_arm", "vsseg_fork_disarm", "vsseg_stream_wait_event",
     "vsseg_adam", "vsseg_swi_accumulate", "vsseg_swi_finalize", "vsseg_hard_dice_counts", "vsseg_argmax2",
 ]  # fmt: skip
 
@@ -264,6 +264,11 @@ def lib():
         L.vsseg_dice_level_sums.argtypes = [vp, vp, vp, i32, I3, i32, vp, vp, vp, vp]
         L.vsseg_dice_tail_sums.argtypes = [C.POINTER(DiceTailDesc), vp]
         L.vsseg_dice_att_bwd_levels.argtypes = [C.POINTER(DiceBwdLevelsDesc), vp]
+        L.vsseg_fork_event_create.argtypes, L.vsseg_fork_event_create.restype = [], vp
+        L.vsseg_fork_event_destroy.argtypes = [vp]
+        L.vsseg_fork_arm.argtypes = [vp]
+        L.vsseg_fork_disarm.argtypes = []
+        L.vsseg_stream_wait_event.argtypes = [vp, vp]
         L.vsseg_adam.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, vp]
         L.vsseg_swi_accumulate.argtypes = [vp, vp, I3, I3, i32, vp, vp, I3, vp]
         L.vsseg_swi_finalize.argtypes = [vp, vp, I3, I3, I3, i32, vp, vp]

@@ -15,6 +15,39 @@ extern "C" void vsseg_set_error(const char* fmt, ...) {
 extern "C" const char* vsseg_last_error(void) { return g_err; }
 extern "C" int vsseg_version(void) { return 7; }
 
+// Forks without a marker packet (common.h, vsseg_launch_kernel): between vsseg_fork_arm(ev) and vsseg_fork_disarm() every kernel the library launches on the calling
+// thread carries `ev` as the stop event of its own dispatch; a later record replaces an earlier one, so after a launch record of several kernels the event stands for the
+// last of them.  vsseg_fork_disarm returns how many kernels carried it (0: the record launched none — a memset — and the caller forks with a plain event record).
+static thread_local hipEvent_t g_fork_ev = nullptr;
+static thread_local int g_fork_n = 0;
+hipEvent_t vsseg_fork_event() {
+  if (g_fork_ev) ++g_fork_n;
+  return g_fork_ev;
+}
+// (the events order streams of ONE device: no system-scope fence)
+extern "C" void* vsseg_fork_event_create(void) {
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { vsseg_set_error("vsseg_fork_event_create: hipEventCreateWithFlags failed"); return nullptr; }
+  return ev;
+}
+extern "C" int vsseg_fork_event_destroy(void* ev) { return ev && hipEventDestroy(reinterpret_cast<hipEvent_t>(ev)) == hipSuccess ? VSSEG_OK : VSSEG_EINVAL; }
+extern "C" int vsseg_fork_arm(void* ev) {
+  if (!ev) { vsseg_set_error("vsseg_fork_arm: null event"); return VSSEG_EINVAL; }
+  g_fork_ev = reinterpret_cast<hipEvent_t>(ev);
+  g_fork_n = 0;
+  return VSSEG_OK;
+}
+extern "C" int vsseg_fork_disarm(void) {
+  const int n = g_fork_ev ? g_fork_n : 0;
+  g_fork_ev = nullptr;
+  g_fork_n = 0;
+  return n;
+}
+extern "C" int vsseg_stream_wait_event(void* stream, void* ev) {
+  if (!ev || hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), reinterpret_cast<hipEvent_t>(ev), 0) != hipSuccess) { vsseg_set_error("vsseg_stream_wait_event: hipStreamWaitEvent failed"); return VSSEG_ELAUNCH; }
+  return VSSEG_OK;
+}
+
 // Sticky flag of the fixed-point accumulators (csrc/common.h, vsseg_fx_add): one word of device memory PER DEVICE (the current device of the calling thread: one
 // process per GPU is the product's layout, a second device in the same process gets its own word), allocated once under a lock.  nullptr only if the allocation
 // failed: every launcher checks (VSSEG_FX_FLAG in common.h) instead of handing a null pointer to a kernel.

@@ -12,6 +12,18 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 extern "C" void vsseg_set_error(const char* fmt, ...);
 
+// Every kernel launch of the library goes through vsseg_launch_kernel: while the calling thread has an event armed (vsseg_fork_arm, api.cpp) the kernel is launched with
+// that event BOUND TO ITS OWN COMPLETION SIGNAL (hipExtLaunchKernelGGL's stopEvent) — how the training backward forks its side stream without a marker packet on the main
+// stream: hipEventRecord costs the main stream's next kernel ~4.7 us (5-8 in the step), the bound event ~1.3 (tools/probes/fork_probe.hip).
+#include <hip/hip_ext.h>
+hipEvent_t vsseg_fork_event();  // the armed event of the calling thread (counted as used), or nullptr
+template <typename F, typename... Args> static inline void vsseg_launch_kernel(F kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+  if (hipEvent_t ev = vsseg_fork_event()) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, nullptr, ev, 0, args...);
+  else hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, s, ...) vsseg_launch_kernel(kernel, dim3(grid), dim3(block), lds, s, ##__VA_ARGS__)
+
 #define VSSEG_CHECK(cond, ...)            \
   do {                                    \
     if (!(cond)) {                        \

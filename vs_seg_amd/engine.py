@@ -147,6 +147,7 @@ class Plan:
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=eng.device)
         self.gatt_buf: Dict[str, torch.Tensor] = {}
         self._gatt_set: Dict[str, bool] = {}
+        self._fork_events: list = []  # events of the side-stream forks (created once, re-recorded every step)
         self.bwd_pre: List[list] = []  # backward launches that read caller-owned memory (the loss' gradient of the logits): never captured
         self._graphs: Dict[str, object] = {}
         self._graph_runs: Dict[str, int] = {}
@@ -1465,15 +1466,36 @@ class Plan:
         stream at the end of the list.  Under hipGraph capture the fork / join events become graph edges."""
         side = None
         overlap = self.eng.overlap
-        for rec in lst:
-            if overlap and len(rec) > 2 and rec[2].get("side"):
-                main = torch.cuda.current_stream()
+        lib = self.eng.lib
+        # A fork = the side stream waits for the main-stream launch in front of it.  With Engine.bound_forks that launch's kernels carry the fork's event as the stop event of
+        # their own dispatch (vsseg_fork_arm: no marker packet on the main stream, whose next kernel a hipEventRecord delays by 5-8 us, 42 times per step: DESIGN 3.18)
+        bound = overlap and self.eng.bound_forks and not torch.cuda.is_current_stream_capturing()
+        is_side = [overlap and len(rec) > 2 and bool(rec[2].get("side")) for rec in lst]
+        events = self._fork_events if bound else None
+        nfork, ready = 0, None  # ready: the event the launch in front of the next side launch carried
+        for i, rec in enumerate(lst):
+            if is_side[i]:
                 if side is None:
                     side = self.eng.side_stream()
-                side.wait_stream(main)
+                if ready is not None:
+                    L.check(lib.vsseg_stream_wait_event(side.cuda_stream, ready), "stream_wait_event")
+                elif i == 0 or not is_side[i - 1]:  # (consecutive side launches share the fork of the first)
+                    side.wait_stream(torch.cuda.current_stream())
+                ready = None
                 rc = rec[0](*rec[1], side.cuda_stream)
             else:
-                rc = rec[0](*rec[1], stream)
+                arm = bound and i + 1 < len(lst) and is_side[i + 1]
+                if arm:
+                    if nfork == len(events):
+                        events.append(lib.vsseg_fork_event_create())
+                    ev = events[nfork]
+                    nfork += 1
+                    L.check(lib.vsseg_fork_arm(ev), "fork_arm")
+                try:
+                    rc = rec[0](*rec[1], stream)
+                finally:
+                    if arm:
+                        ready = ev if lib.vsseg_fork_disarm() > 0 else None  # 0: the record launched no kernel of the library (a memset): plain fork
             if rc:
                 L.check(rc, getattr(rec[0], "__name__", "launch"))
         if side is not None:
@@ -1536,6 +1558,7 @@ class Engine:
         self.wide_dpre = os.environ.get("VSSEG_WIDE_DPRE", "1") != "0"  # A/B switch of round 6: 16-channel rows for d(pre-sigmoid) of the 3x3x3 sigmoid convolutions (compute-kernel data gradient)
         self.early_res_wgrad = os.environ.get("VSSEG_EARLY_RES_WGRAD", "late")  # round 6, where the first unit's 1x1x1 residual-convolution weight gradient runs: "late" = with the late launches (next line), "1" = with the unit's last block, "0" = last on the side stream
         self.late_wgrad = int(os.environ.get("VSSEG_LATE_WGRAD", "1"))  # the last N tile / marching / compute weight-gradient launches run at the end of the main stream's list (see the end of the backward lowering)
+        self.bound_forks = os.environ.get("VSSEG_BOUND_FORKS", "1") != "0"  # round 6: the side stream forks on events bound to the main-stream kernels' own completion (no marker packets); 0: hipEventRecord per fork
         self.transition = os.environ.get("VSSEG_TRANSITION", "1") != "0"  # A/B switch of round 6: the level 2 <-> 3 transition kernel (csrc/tconv.hip, depth -8)
         self.narrow_fwd = os.environ.get("VSSEG_NARROW_FWD", "1") != "0"  # A/B switch of round 6: the C -> 1 attention convolutions of levels 0-1 on the vector ALUs (csrc/nconv.hip)
         self.narrow_wgrad = True  # weight gradients of the 1-channel-input / 1-channel-output convolutions as bandwidth reductions
