@@ -22,6 +22,10 @@ def main():
     img, lab = B.synth_batch(4, B.PATCH, 0, dev)
     for _ in range(6):
         tr.step(img, lab)
+    live = os.environ.get("VSSEG_TIME_LIVE")  # e.g. "mconv<bf16,2>": two HIP events around every launch of that kernel group, as bench.py's timed region has them
+    if live:
+        plan = next(p for k, p in model._engine.plans.items() if k[2])
+        plan.timer = dict(only={live}, events=[])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
